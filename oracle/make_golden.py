@@ -1,0 +1,210 @@
+"""Generate tests/golden/*.npz by running the REAL reference (/root/reference) on CPU.
+
+Build-container only (the reference does not travel to the GPU box); the vectors it writes are committed.
+    python -m oracle.make_golden            # regenerate everything
+Every case: weights = oracle.synth.synth_state_dict(reference state_dict shapes, seed 0), inputs from
+oracle.synth (numpy RandomState streams), fp32, torch CPU.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+from . import loss_ref, ref_shim, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+CFG = os.path.join(ROOT, 'multiyolov5_amd', 'cfg')
+H, W = 64, 128     # golden image size (stride-32 multiple; P5 map 2x4)
+
+
+def tap(t, k=6):
+    """small fingerprint of a tensor: mean, std, abs-max and k strided samples."""
+    f = t.detach().float().reshape(-1)
+    idx = torch.linspace(0, f.numel() - 1, k).long()
+    return np.concatenate(([f.mean().item(), f.std().item() if f.numel() > 1 else 0.0, f.abs().max().item()],
+                           f[idx].numpy())).astype(np.float32)
+
+
+def build_ref(ref, cfg_name):
+    torch.manual_seed(0)
+    m = ref.yolo.Model(os.path.join(CFG, cfg_name))
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    sd = synth.synth_state_dict(sd0, seed=0)
+    m.load_state_dict(sd, strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0                      # train-mode parity is pinned with dropout off
+    return m, sd0
+
+
+def model_case(ref, cfg_name, tag, with_backward):
+    m, sd_init = build_ref(ref, cfg_name)
+    out = {}
+    # state right after construction (stride probe side effects, yolo.py:261): pinned for the drop-in ctor
+    bn0 = [k for k in sd_init if k.endswith('running_var')][0]
+    out['init_running_var0'] = sd_init[bn0][:4].numpy()
+    out['init_nbt0'] = np.array(sd_init[bn0.replace('running_var', 'num_batches_tracked')].item())
+    out['init_anchors'] = sd_init[[k for k in sd_init if k.endswith('.anchors')][0]].numpy()
+    out['n_params'] = np.array(sum(p.numel() for p in m.parameters()))
+
+    x = synth.synth_images(2, H, W, seed=1)
+    # ---- train-mode forward (batch-stat BN) ----
+    m.train()
+    feats = {}
+    hooks = [mod.register_forward_hook(lambda mod_, i_, o_, idx=i: feats.__setitem__(idx, o_))
+             for i, mod in enumerate(m.model)]
+    det, seg = m(x)
+    for h in hooks:
+        h.remove()
+    for i, o in feats.items():
+        if torch.is_tensor(o):
+            out[f'train_layer{i}'] = tap(o)
+    for i, d in enumerate(det):
+        out[f'train_det{i}'] = d.detach().numpy()
+    segs = seg if isinstance(seg, list) else [seg]
+    for j, s in enumerate(segs):
+        out[f'train_seg{j}_sub'] = s.detach()[:, :, ::4, ::4].numpy()
+        out[f'train_seg{j}_argmax'] = s.detach().argmax(1).numpy().astype(np.uint8)
+    sd_after = m.state_dict()
+    for k in list(sd_after)[:]:
+        if k.endswith('running_mean') or k.endswith('running_var'):
+            out['train_rs/' + k] = tap(sd_after[k], 4)
+
+    if with_backward:
+        nc = 10
+        m.nc, m.gr = nc, 1.0
+        m.hyp = loss_ref.scaled_hyp(1024, nc, 3)
+        targets = synth.synth_det_targets(2, 8, nc, seed=1)
+        mask = synth.synth_seg_targets(2, H, W, 19, seed=1)
+        cl = ref.loss.ComputeLoss(m)
+        loss, items = cl(det, targets)
+        if isinstance(seg, list):
+            crit = ref.loss.SegmentationLosses(aux=True, aux_num=2, aux_weight=0.1)
+            segloss = crit(seg[0], seg[1], seg[2], mask)
+        else:
+            crit = ref.loss.SegmentationLosses()
+            segloss = crit(seg, mask)
+        total = loss * 0.6 + segloss * 2 * 0.35         # train.py:366-391 gains (detgain .6, seggain .35, *batch)
+        total.backward()
+        out['loss_det'] = loss.detach().numpy()
+        out['loss_items'] = items.numpy()
+        out['loss_seg'] = segloss.detach().numpy().reshape(1)
+        for k, p in m.named_parameters():
+            g = p.grad.reshape(-1)
+            out['grad/' + k] = np.concatenate(([g.norm().item()], g[:5].numpy(), g[-3:].numpy())).astype(np.float32)
+
+    # ---- eval forward, fused (detect.py path: attempt_load -> fuse().eval()) ----
+    m2, _ = build_ref(ref, cfg_name)
+    m2.fuse().eval()
+    with torch.no_grad():
+        (pred, raw), seg = m2(x[:1])
+    out['eval_pred'] = pred.numpy()
+    out['eval_seg_sub'] = seg[:, :, ::4, ::4].numpy()
+    out['eval_seg_argmax'] = seg.argmax(1).numpy().astype(np.uint8)
+    np.savez_compressed(os.path.join(GOLD, f'model_{tag}.npz'), **out)
+    print('wrote', tag, len(out), 'arrays')
+
+
+def loss_case(ref):
+    out = {}
+    rs = np.random.RandomState(7)
+    B, nc = 2, 10
+    p = [torch.from_numpy(rs.normal(0, 1.5, (B, 3, ny, nx, 5 + nc)).astype(np.float32)).requires_grad_()
+         for ny, nx in ((16, 32), (8, 16), (4, 8))]
+    targets = synth.synth_det_targets(B, 24, nc, seed=5)      # dense: duplicates in tobj scatter do occur
+    targets[:4, 2:4] = torch.tensor([[0.003, 0.5], [0.997, 0.5], [0.5, 0.004], [0.5, 0.996]])  # border clamps
+
+    class FakeDet:
+        pass
+    for ls in (0.0, 0.1):
+        m, _ = build_ref(ref, 'yolov5s_city_seg.yaml') if ls == 0.0 else (m, None)
+        m.nc, m.gr = nc, 1.0
+        m.hyp = loss_ref.scaled_hyp(1024, nc, 3, label_smoothing=ls)
+        cl = ref.loss.ComputeLoss(m)
+        for q in p:
+            q.grad = None
+        loss, items = cl(p, targets)
+        loss.backward()
+        tag = f'ls{int(ls * 10)}'
+        out[f'det_{tag}_loss'] = loss.detach().numpy()
+        out[f'det_{tag}_items'] = items.numpy()
+        for i, q in enumerate(p):
+            out[f'det_{tag}_grad{i}'] = q.grad.numpy().copy()
+    out['anchors'] = m.model[-1].anchors.numpy()
+    for i, q in enumerate(p):
+        out[f'det_p{i}'] = q.detach().numpy()
+    out['det_targets'] = targets.numpy()
+    # empty-target edge case
+    loss, items = cl([q.detach() for q in p], torch.zeros(0, 6))
+    out['det_empty_loss'] = loss.numpy()
+    out['det_empty_items'] = items.numpy()
+
+    # segmentation CE + OHEM on [2,19,32,64]
+    logits = torch.from_numpy(rs.normal(0, 2.0, (2, 19, 32, 64)).astype(np.float32)).requires_grad_()
+    mask = synth.synth_seg_targets(2, 32, 64, 19, seed=3, blocky=4)
+    # make a blocky region "easy" so OHEM's threshold actually splits the pixels
+    with torch.no_grad():
+        easy = torch.zeros_like(mask, dtype=torch.bool)
+        easy[:, :, :40] = True
+        idx = mask.clamp(0)
+        boost = torch.zeros_like(logits).scatter_(1, idx[:, None], 8.0)
+        logits += boost * easy[:, None]
+    ce = ref.loss.SegmentationLosses()(logits, mask)
+    ce.backward()
+    out['seg_logits'], out['seg_mask'] = logits.detach().numpy(), mask.numpy().astype(np.int16)
+    out['ce_loss'], out['ce_grad'] = ce.detach().numpy().reshape(1), logits.grad.numpy().copy()
+    for th in (0.7, 0.999999):     # 0.7: thresholded branch; ~1.0: thresh ~ 0 -> all kept; see below for topk branch
+        logits.grad = None
+        oh = ref.loss.OhemCELoss.__new__(ref.loss.OhemCELoss)       # ctor calls .cuda() (loss.py:306): bypass
+        torch.nn.Module.__init__(oh)
+        oh.thresh = -torch.log(torch.tensor(th, dtype=torch.float))
+        oh.ignore_index, oh.aux = -1, False
+        oh.criteria = torch.nn.CrossEntropyLoss(ignore_index=-1, reduction='none')
+        v = oh(logits, mask)
+        v.backward()
+        out[f'ohem_{th}_loss'], out[f'ohem_{th}_grad'] = v.detach().numpy().reshape(1), logits.grad.numpy().copy()
+    # top-k fallback branch: all pixels easy except few -> fewer than n_min above threshold
+    logits2 = (logits.detach() + boost * 1.0).requires_grad_()
+    oh.thresh = -torch.log(torch.tensor(0.7))
+    v = oh(logits2, mask)
+    v.backward()
+    out['ohem_topk_logits'] = logits2.detach().numpy()
+    out['ohem_topk_loss'], out['ohem_topk_grad'] = v.detach().numpy().reshape(1), logits2.grad.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, 'losses.npz'), **out)
+    print('wrote losses', len(out))
+
+
+def nms_case(ref):
+    out = {}
+    pred = synth.synth_nms_pred(2, 3000, 10, seed=3)
+    for name, kw in (('single', dict(conf_thres=0.25, iou_thres=0.45)),
+                     ('multi', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True))):
+        res = ref.general.non_max_suppression(pred.clone(), **kw)
+        for i, r in enumerate(res):
+            out[f'{name}_{i}'] = r.numpy()
+    np.savez_compressed(os.path.join(GOLD, 'nms.npz'), **out)
+    print('wrote nms', {k: v.shape for k, v in out.items()})
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref = ref_shim.install()
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ['models', 'losses', 'nms']
+    if 'models' in which:
+        model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
+        model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
+        model_case(ref, 'yolov5s_city_seg_lab.yaml', 's_lab', True)
+        model_case(ref, 'yolov5s_city_seg_bise.yaml', 's_bise', True)
+        model_case(ref, 'yolov5m_city_seg_lab.yaml', 'm_lab', False)
+    if 'losses' in which:
+        loss_case(ref)
+    if 'nms' in which:
+        nms_case(ref)
+
+
+if __name__ == '__main__':
+    main()

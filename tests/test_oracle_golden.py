@@ -1,0 +1,139 @@
+"""The oracle restatement (oracle/*.py) against golden vectors produced by the real reference
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, model_ref, nms_ref, synth
+from tests.util import golden, load_cfg, synth_sd, tap
+
+H, W = 64, 128
+
+
+@pytest.mark.parametrize('tag', ['s_psp', 's_base', 's_lab', 's_bise', 'm_lab'])
+def test_state_dict_keys_match_reference(tag):
+    g = golden('model_' + tag)
+    sd = synth_sd(tag)
+    ref_keys = {k[len('train_rs/'):] for k in g.files if k.startswith('train_rs/')}
+    mine = {k for k in sd if k.endswith('running_mean') or k.endswith('running_var')}
+    assert ref_keys == mine
+    if any(k.startswith('grad/') for k in g.files):
+        ref_params = {k[len('grad/'):] for k in g.files if k.startswith('grad/')}
+        mine_p = {k for k in sd if not (k.endswith('running_mean') or k.endswith('running_var') or
+                                        k.endswith('num_batches_tracked') or 'anchor' in k)}
+        assert ref_params == mine_p
+    assert int(g['n_params']) == sum(v.numel() for k, v in sd.items() if k in
+                                     {k for k in sd if not ('running' in k or 'num_batches' in k or 'anchor' in k)})
+
+
+@pytest.mark.parametrize('tag', ['s_psp', 's_base', 's_lab', 's_bise', 'm_lab'])
+def test_forward_train_and_eval(tag):
+    g = golden('model_' + tag)
+    cfg = load_cfg(tag)
+    sd = synth_sd(tag)
+    x = synth.synth_images(2, H, W, seed=1)
+    rec = {}
+    sdt = {k: v.clone() for k, v in sd.items()}
+    det, seg = model_ref.forward(cfg, sdt, x, training=True, dropout_p=0.0, record=rec)
+    for i, d in enumerate(det):
+        np.testing.assert_allclose(d.numpy(), g[f'train_det{i}'], rtol=1e-4, atol=2e-5)
+    segs = seg if isinstance(seg, list) else [seg]
+    for j, s in enumerate(segs):
+        np.testing.assert_allclose(s[:, :, ::4, ::4].numpy(), g[f'train_seg{j}_sub'], rtol=1e-4, atol=2e-5)
+        assert (s.argmax(1).numpy() != g[f'train_seg{j}_argmax']).mean() < 1e-4
+    for k in g.files:
+        if k.startswith('train_layer'):
+            np.testing.assert_allclose(tap(rec[k[len('train_'):]]), g[k], rtol=1e-4, atol=2e-5)
+        if k.startswith('train_rs/'):
+            np.testing.assert_allclose(tap(sdt[k[len('train_rs/'):]], 4), g[k], rtol=1e-4, atol=1e-5)
+    # eval, fused
+    sde = model_ref.fuse_state_dict({k: v.clone() for k, v in sd.items()})
+    with torch.no_grad():
+        (pred, raw), seg = model_ref.forward(cfg, sde, x[:1], training=False)
+    np.testing.assert_allclose(pred.numpy(), g['eval_pred'], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(seg[:, :, ::4, ::4].numpy(), g['eval_seg_sub'], rtol=1e-4, atol=2e-5)
+    assert (seg.argmax(1).numpy() != g['eval_seg_argmax']).mean() < 1e-4
+
+
+@pytest.mark.parametrize('tag', ['s_psp', 's_bise'])
+def test_backward_matches_reference(tag):
+    g = golden('model_' + tag)
+    cfg = load_cfg(tag)
+    sd = synth_sd(tag)
+    params = {k: v.clone().requires_grad_() for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running' not in k and 'anchor' not in k}
+    sdt = {k: (params[k] if k in params else v.clone()) for k, v in sd.items()}
+    x = synth.synth_images(2, H, W, seed=1)
+    det, seg = model_ref.forward(cfg, sdt, x, training=True, dropout_p=0.0)
+    hyp = loss_ref.scaled_hyp(1024, 10, 3)
+    anchors = [v for k, v in sd.items() if k.endswith('.anchors')][0]
+    loss, items = loss_ref.compute_loss(det, synth.synth_det_targets(2, 8, 10, seed=1), anchors, hyp)
+    mask = synth.synth_seg_targets(2, H, W, 19, seed=1)
+    segloss = loss_ref.seg_ce_aux(seg, mask) if isinstance(seg, list) else loss_ref.seg_ce(seg, mask)
+    np.testing.assert_allclose(loss.detach().numpy(), g['loss_det'], rtol=1e-4)
+    np.testing.assert_allclose(items.numpy(), g['loss_items'], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(segloss.detach().numpy().reshape(1), g['loss_seg'], rtol=1e-4)
+    (loss * 0.6 + segloss * 2 * 0.35).backward()
+    for k, p in params.items():
+        gr = p.grad.reshape(-1)
+        mine = np.concatenate(([gr.norm().item()], gr[:5].numpy(), gr[-3:].numpy()))
+        ref = g['grad/' + k]
+        np.testing.assert_allclose(mine, ref, rtol=2e-3, atol=1e-5 + 1e-3 * ref[0], err_msg=k)
+
+
+def test_compute_loss_and_grads():
+    g = golden('losses')
+    anchors = torch.from_numpy(g['anchors'])
+    targets = torch.from_numpy(g['det_targets'])
+    for ls, tag in ((0.0, 'ls0'), (0.1, 'ls1')):
+        p = [torch.from_numpy(g[f'det_p{i}']).requires_grad_() for i in range(3)]
+        hyp = loss_ref.scaled_hyp(1024, 10, 3, label_smoothing=ls)
+        loss, items = loss_ref.compute_loss(p, targets, anchors, hyp)
+        loss.backward()
+        np.testing.assert_allclose(loss.detach().numpy(), g[f'det_{tag}_loss'], rtol=1e-5)
+        np.testing.assert_allclose(items.numpy(), g[f'det_{tag}_items'], rtol=1e-5)
+        for i in range(3):
+            np.testing.assert_allclose(p[i].grad.numpy(), g[f'det_{tag}_grad{i}'], rtol=1e-4, atol=1e-7)
+    loss, items = loss_ref.compute_loss([torch.from_numpy(g[f'det_p{i}']) for i in range(3)], torch.zeros(0, 6),
+                                        anchors, hyp)
+    np.testing.assert_allclose(loss.numpy(), g['det_empty_loss'], rtol=1e-5)
+
+
+def test_seg_losses():
+    g = golden('losses')
+    mask = torch.from_numpy(g['seg_mask'].astype(np.int64))
+    lg = torch.from_numpy(g['seg_logits']).requires_grad_()
+    v = loss_ref.seg_ce(lg, mask)
+    v.backward()
+    np.testing.assert_allclose(v.item(), g['ce_loss'][0], rtol=1e-5)
+    np.testing.assert_allclose(lg.grad.numpy(), g['ce_grad'], rtol=1e-4, atol=1e-9)
+    for th in (0.7, 0.999999):
+        lg.grad = None
+        v = loss_ref.ohem_ce(lg, mask, th)
+        v.backward()
+        np.testing.assert_allclose(v.item(), g[f'ohem_{th}_loss'][0], rtol=1e-5)
+        np.testing.assert_allclose(lg.grad.numpy(), g[f'ohem_{th}_grad'], rtol=1e-4, atol=1e-9)
+    lg2 = torch.from_numpy(g['ohem_topk_logits']).requires_grad_()
+    v = loss_ref.ohem_ce(lg2, mask, 0.7)
+    v.backward()
+    np.testing.assert_allclose(v.item(), g['ohem_topk_loss'][0], rtol=1e-5)
+    np.testing.assert_allclose(lg2.grad.numpy(), g['ohem_topk_grad'], rtol=1e-4, atol=1e-9)
+
+
+def test_nms_restatement():
+    g = golden('nms')
+    pred = synth.synth_nms_pred(2, 3000, 10, seed=3).numpy()
+    for name, kw in (('single', dict(conf_thres=0.25, iou_thres=0.45)),
+                     ('multi', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True))):
+        res = nms_ref.non_max_suppression(pred, **kw)
+        for i, r in enumerate(res):
+            ref = g[f'{name}_{i}']
+            assert r.shape == ref.shape
+            np.testing.assert_allclose(r, ref, rtol=1e-6, atol=1e-6)
+            assert (r[:, 5] == ref[:, 5]).all()
+
+
+def test_bilinear_restatement_matches_aten():
+    x = torch.randn(5, 8, 16)
+    ref = torch.nn.functional.interpolate(x[None], size=(64, 128), mode='bilinear', align_corners=True)[0]
+    np.testing.assert_allclose(nms_ref.bilinear_ac(x.numpy(), 64, 128), ref.numpy(), rtol=1e-5, atol=1e-6)
