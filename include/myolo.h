@@ -1,0 +1,182 @@
+/* libmyolo -- C ABI of the MI355X (gfx950) kernels behind the multiyolov5 hot path.
+ *
+ * The reference (TomMao23/multiyolov5) is pure Python/PyTorch and has NO plugin/FFI/operator registry
+ * (SURVEY.md §8b): its "operators" are the ATen calls made by models/common.py, models/yolo.py,
+ * utils/loss.py and utils/general.py.  Each entry point below replaces the ATen call(s) cited next to it.
+ * The host-side mirror of the reference's module API (multiyolov5_amd/models, multiyolov5_amd/utils)
+ * binds these symbols through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions (all entry points):
+ *   - plain device pointers + sizes; the caller owns every buffer; nothing is allocated, freed or
+ *     synchronised inside; work is enqueued on `stream` (a hipStream_t) and is hipGraph-capturable;
+ *   - return value is a hipError_t as int (0 = ok); MYOLO_EINVAL (-22) for a rejected argument;
+ *   - activations are NHWC *views*: element (n,y,x,c) lives at ptr + n*sn + y*sh + x*sw + c
+ *     (strides in elements).  A channel slice of a wider buffer (concat-free writes) is just a view
+ *     with sw > c.  16-byte alignment of ptr/strides is required wherever a tensor is a conv input;
+ *   - dtype is the storage type of activations / packed weights (MYOLO_F16 or MYOLO_F32);
+ *     accumulation, BN statistics, losses and gradients of parameters are always fp32.
+ */
+#ifndef MYOLO_H_
+#define MYOLO_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MYOLO_F32 0
+#define MYOLO_F16 1
+#define MYOLO_U8  2
+#define MYOLO_I64 3
+
+#define MYOLO_ACT_NONE    0
+#define MYOLO_ACT_SILU    1
+#define MYOLO_ACT_SIGMOID 2
+
+#define MYOLO_EINVAL (-22)
+#define MYOLO_MAX_TAPS 25
+
+typedef struct myolo_tensor {
+  void*   ptr;
+  int32_t n, h, w, c;
+  int64_t sn, sh, sw;      /* strides in elements; channel stride is 1 */
+  int32_t dtype;
+  int32_t reserved;
+} myolo_tensor;
+
+/* ---- version / capability ------------------------------------------------------------------ */
+int myolo_version(void);                 /* ABI version of this header */
+const char* myolo_arch(void);            /* "gfx950" */
+
+/* ---- weights ------------------------------------------------------------------------------- */
+/* OIHW master weights (nn.Conv2d.weight, common.py:38) -> MFMA-friendly packed layout
+ *   transpose=0: dst[rows=cout_pad][ntaps][cols=cin_pad]   (forward operand, K = tap*cin contiguous)
+ *   transpose=1: dst[rows=cin_pad ][ntaps][cols=cout_pad]  (dgrad operand)
+ * zero padded.  `row_scale` (optional, fp32[cout]) multiplies output-channel rows: folds a BN
+ * scale into the weights exactly like fuse_conv_and_bn (utils/torch_utils.py:193-195). */
+int myolo_pack_weight(const void* w_oihw, int src_dtype, int cout, int cin, int kh, int kw,
+                      void* dst, int dst_dtype, int rows_pad, int cols_pad, int transpose,
+                      const float* row_scale, void* stream);
+
+/* Focus slicing + cat (common.py:550) fused with the image cast: NCHW [n,3,h,w] (f32|f16|u8, value*mul)
+ * -> NHWC [n,h/2,w/2,16]: channel 3*q+c, q=(row parity, col parity) in order (0,0),(1,0),(0,1),(1,1);
+ * channels 12..15 are zero. */
+int myolo_focus_pack(const void* img_nchw, int src_dtype, int n, int h, int w, float mul,
+                     const myolo_tensor* out, void* stream);
+
+/* ---- convolution (implicit GEMM on MFMA) ------------------------------------------------------
+ * Replaces nn.Conv2d (+ BatchNorm2d + SiLU) of `Conv` (common.py:34-46), the bare dilated
+ * Conv2d+BN+SiLU triples (common.py:481-490), Detect.m[i] (yolo.py:211-214) and, with transposed
+ * weights / flipped taps, the autograd dgrad of all of them.
+ *   y[n,oy,ox,:] (+)= epilogue( sum_t  x[n, (oy*stride+tap_dy[t])>>up, (ox*stride+tap_dx[t])>>up, :] . W[:,tap_w[t],:] )
+ *   epilogue(v) = act(v*scale[c] + shift[c]) + res      (each part optional)
+ *   stats != NULL: atomically accumulates per-channel sum / sum of squares of the raw fp32 accumulators
+ *                  into stats[0..cout) / stats[cout..2cout)   (training-mode BatchNorm statistics)
+ *   det_no  > 0 : y is written in Detect's permuted layout [n, na, h, w, det_no] (yolo.py:214)           */
+typedef struct myolo_conv_desc {
+  myolo_tensor x;            /* [N,Hi,Wi,Cin] (source dims; logical dims are <<up_shift) */
+  myolo_tensor y;            /* [N,Ho,Wo,Cout] */
+  const void*  w;            /* packed weights [cout_pad][wtaps][cin_pad], dtype == x.dtype */
+  int32_t cin_pad, cout_pad, wtaps;
+  int32_t ntaps, stride, up_shift;
+  int32_t tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS], tap_w[MYOLO_MAX_TAPS];
+  const float* scale;        /* fp32[cout] or NULL */
+  const float* shift;        /* fp32[cout] or NULL */
+  int32_t act;
+  int32_t accumulate;        /* 1: y += result */
+  myolo_tensor res;          /* res.ptr == NULL: none */
+  float*  stats;             /* fp32[2*cout] or NULL */
+  int32_t det_no;
+  int32_t reserved;
+} myolo_conv_desc;
+int myolo_conv(const myolo_conv_desc* d, void* stream);
+
+/* wgrad: dw_oihw[co][ci][t] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, (oy*stride+tap_dy[t])>>up, (ox*stride+tap_dx[t])>>up, ci]
+ * (fp32 atomics into an OIHW fp32 gradient buffer = Parameter.grad layout).  db (optional, fp32[cout]) += sum dy. */
+typedef struct myolo_wgrad_desc {
+  myolo_tensor x, dy;
+  float*  dw;
+  float*  db;
+  int32_t ntaps, stride, up_shift;
+  int32_t tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
+  int32_t ksplit;            /* 0 = auto */
+  int32_t cout, cin;         /* real weight dims when dy.c / x.c are channel-padded views (0: use dy.c / x.c) */
+  int32_t reserved;
+} myolo_wgrad_desc;
+int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream);
+
+/* ---- BatchNorm(+SiLU)(+residual) around a raw conv output (training mode) ----------------------
+ * fwd: nn.BatchNorm2d batch-stat path + nn.SiLU + Bottleneck add (common.py:43,105), eps/momentum from
+ * initialize_weights (torch_utils.py:150-151).  `stats` are the sums produced by myolo_conv.
+ *   mean = s/M, var = q/M - mean^2;  out = act((y-mean)*rsqrt(var+eps)*gamma + beta) + res
+ *   block 0 also: saved[0..c)=mean, saved[c..2c)=invstd; running_mean/var (unbiased) momentum update,
+ *   num_batches_tracked += 1 (int64).
+ * gamma == NULL: no normalisation (plain activation of a BN-less conv, e.g. FFM's SE convs). */
+int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                     float* saved, float eps, float momentum, int act,
+                     const myolo_tensor* res, const myolo_tensor* out, void* stream);
+/* bwd pass 1: dsum[0..c) += sum dz, dsum[c..2c) += sum dz*xhat   with dz = gout * act'(z) */
+int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                            const float* gamma, const float* beta, int act, float* dsum, void* stream);
+/* bwd pass 2: dy = gamma*invstd*(dz - dsum0/M - xhat*dsum1/M); dgamma += dsum1, dbeta += dsum0 (block 0);
+ * gres (optional) (+)= gout  (residual branch of Bottleneck) */
+int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                           const float* gamma, const float* beta, int act, const float* dsum,
+                           float* dgamma, float* dbeta, const myolo_tensor* dy,
+                           const myolo_tensor* gres, int gres_accumulate, void* stream);
+
+/* ---- pooling / resampling / glue -------------------------------------------------------------- */
+/* SPP: three stride-1 max pools k=5,9,13, -inf padding (common.py:170).  idx (optional, u8 [3][n,h,w,c])
+ * records the first-max window offset for backward. */
+int myolo_spp_pool_fwd(const myolo_tensor* x, const myolo_tensor* o5, const myolo_tensor* o9,
+                       const myolo_tensor* o13, uint8_t* idx, void* stream);
+int myolo_spp_pool_bwd(const myolo_tensor* g5, const myolo_tensor* g9, const myolo_tensor* g13,
+                       const uint8_t* idx, const myolo_tensor* gx, int accumulate, void* stream);
+/* nn.Upsample(None, 2, 'nearest') (yaml:31,36) or plain copy (scale=1) into a (slice) view */
+int myolo_copy_up_fwd(const myolo_tensor* x, const myolo_tensor* out, int scale, void* stream);
+int myolo_copy_up_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int scale, int accumulate, void* stream);
+/* bilinear, align_corners=True (yolo.py:57..174, common.py:534-537, detect.py:191) */
+int myolo_bilinear_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream);
+int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
+/* nn.AdaptiveAvgPool2d(k) (common.py:521-524, 214): out [n,k,k,c] */
+int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream);
+int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
+/* FFM gate: out = feat*att + feat, att [n,1,1,c] (common.py:228-229) */
+int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream);
+int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
+                   const myolo_tensor* gfeat, int accumulate, float* gatt_f32 /* [n*c] zeroed by caller */,
+                   void* stream);
+/* out (+)= a  (elementwise on views; BiSe `m16 + feat3`, gradient fan-in) */
+int myolo_add(const myolo_tensor* a, const myolo_tensor* out, int accumulate, void* stream);
+int myolo_fill_zero(const myolo_tensor* t, void* stream);
+/* fp32 [n*c] -> view (cast), used for small fp32 side results */
+int myolo_cast_from_f32(const float* src, const myolo_tensor* out, void* stream);
+
+/* train-mode nn.Dropout (yolo.py:65,140): keep-mask u8 per element (dense [n,h,w,c]); `counter` is a 64-bit draw
+ * counter in device memory, advanced by the call itself (graph-replay safe). */
+int myolo_dropout_fwd(const myolo_tensor* x, const myolo_tensor* out, uint8_t* mask, float p, uint64_t* counter,
+                      void* stream);
+int myolo_dropout_bwd(const myolo_tensor* gout, const uint8_t* mask, const myolo_tensor* gx, float p, int accumulate,
+                      void* stream);
+
+/* ---- head outputs ------------------------------------------------------------------------------ */
+/* final nn.Upsample(x8, bilinear, align_corners=True) of the class logits (yolo.py:67,118,143,163) into a
+ * [N,C,H,W]-logical tensor with arbitrary element strides (sn,sc,sh,sw); bwd is its transpose. */
+int myolo_seg_upsample_fwd(const myolo_tensor* low, void* out, int out_dtype, int H, int W,
+                           int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* stream);
+int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
+                           const myolo_tensor* glow, int accumulate, void* stream);
+/* detect.py:191-193 fused: bilinear resize of the logits to (H,W) + argmax over classes -> labels [N,H,W] (u8|i64) */
+int myolo_seg_argmax(const myolo_tensor* low, void* labels, int label_dtype, int H, int W, void* stream);
+/* gradient of Detect's view/permute (yolo.py:214): dense [N,na,ny,nx,no] -> NHWC view [N,ny,nx,>=na*no] */
+int myolo_detect_unpermute(const void* g, int g_dtype, int na, int no, const myolo_tensor* out, void* stream);
+/* Detect eval decode (yolo.py:216-223) of one level: raw dense [N,na,ny,nx,no] -> rows [row0, row0+na*ny*nx) of
+ * z dense [N,a_total,no]; anchor_wh_px = anchor_grid[i] (pixels), host pointer, na*2 floats */
+int myolo_detect_decode(const void* raw, int dtype, int n, int na, int ny, int nx, int no, float stride,
+                        const float* anchor_wh_px, void* z, int64_t a_total, int64_t row0, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYOLO_H_ */

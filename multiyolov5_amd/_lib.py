@@ -1,0 +1,110 @@
+"""ctypes binding of libmyolo.so (include/myolo.h).  The library is the product: there is NO fallback --
+if it cannot be loaded, or a kernel launch fails, the caller gets an exception."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libmyolo.so')
+
+F32, F16, U8, I64 = 0, 1, 2, 3
+ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
+MAX_TAPS = 25
+DT = {torch.float32: F32, torch.float16: F16, torch.uint8: U8, torch.int64: I64}
+TORCH_DT = {F32: torch.float32, F16: torch.float16}
+
+
+class Tensor(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('c', C.c_int32),
+                ('sn', C.c_int64), ('sh', C.c_int64), ('sw', C.c_int64), ('dtype', C.c_int32), ('reserved', C.c_int32)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('x', Tensor), ('y', Tensor), ('w', C.c_void_p),
+                ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('wtaps', C.c_int32),
+                ('ntaps', C.c_int32), ('stride', C.c_int32), ('up_shift', C.c_int32),
+                ('tap_dy', C.c_int32 * MAX_TAPS), ('tap_dx', C.c_int32 * MAX_TAPS), ('tap_w', C.c_int32 * MAX_TAPS),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('act', C.c_int32), ('accumulate', C.c_int32),
+                ('res', Tensor), ('stats', C.c_void_p), ('det_no', C.c_int32), ('reserved', C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [('x', Tensor), ('dy', Tensor), ('dw', C.c_void_p), ('db', C.c_void_p),
+                ('ntaps', C.c_int32), ('stride', C.c_int32), ('up_shift', C.c_int32),
+                ('tap_dy', C.c_int32 * MAX_TAPS), ('tap_dx', C.c_int32 * MAX_TAPS),
+                ('ksplit', C.c_int32), ('cout', C.c_int32), ('cin', C.c_int32), ('reserved', C.c_int32)]
+
+
+class MyoloError(RuntimeError):
+    pass
+
+
+_lib = None
+P = C.c_void_p
+TP = C.POINTER(Tensor)
+_PROTOS = {
+    'myolo_version': (C.c_int, []),
+    'myolo_arch': (C.c_char_p, []),
+    'myolo_pack_weight': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    'myolo_focus_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, TP, P]),
+    'myolo_conv': (C.c_int, [C.POINTER(ConvDesc), P]),
+    'myolo_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), P]),
+    'myolo_bn_act_fwd': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, P]),
+    'myolo_bn_act_bwd_reduce': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P]),
+    'myolo_bn_act_bwd_apply': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P, P, TP, TP, C.c_int, P]),
+    'myolo_spp_pool_fwd': (C.c_int, [TP, TP, TP, TP, P, P]),
+    'myolo_spp_pool_bwd': (C.c_int, [TP, TP, TP, P, TP, C.c_int, P]),
+    'myolo_copy_up_fwd': (C.c_int, [TP, TP, C.c_int, P]),
+    'myolo_copy_up_bwd': (C.c_int, [TP, TP, C.c_int, C.c_int, P]),
+    'myolo_bilinear_fwd': (C.c_int, [TP, TP, P]),
+    'myolo_bilinear_bwd': (C.c_int, [TP, TP, C.c_int, P]),
+    'myolo_adaptive_avgpool_fwd': (C.c_int, [TP, TP, P]),
+    'myolo_adaptive_avgpool_bwd': (C.c_int, [TP, TP, C.c_int, P]),
+    'myolo_gate_fwd': (C.c_int, [TP, TP, TP, P]),
+    'myolo_gate_bwd': (C.c_int, [TP, TP, TP, TP, C.c_int, P, P]),
+    'myolo_add': (C.c_int, [TP, TP, C.c_int, P]),
+    'myolo_fill_zero': (C.c_int, [TP, P]),
+    'myolo_cast_from_f32': (C.c_int, [P, TP, P]),
+    'myolo_dropout_fwd': (C.c_int, [TP, TP, P, C.c_float, P, P]),
+    'myolo_dropout_bwd': (C.c_int, [TP, P, TP, C.c_float, C.c_int, P]),
+    'myolo_seg_upsample_fwd': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, P]),
+    'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P]),
+    'myolo_seg_argmax': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, P]),
+    'myolo_detect_unpermute': (C.c_int, [P, C.c_int, C.c_int, C.c_int, TP, P]),
+    'myolo_detect_decode': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                      C.POINTER(C.c_float), P, C.c_int64, C.c_int64, P]),
+}
+
+
+def lib():
+    """Load libmyolo.so (once).  Raises MyoloError if it is missing -- build it with `python -m multiyolov5_amd.build`."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MyoloError(f'{LIB_PATH} not found: run `python -m multiyolov5_amd.build` (hipcc --offload-arch=gfx950). '
+                             'There is no CPU/PyTorch fallback for the multiyolov5_amd hot path.')
+        l = C.CDLL(LIB_PATH)   # torch is imported above: libamdhip64.so.7 resolves to the runtime torch already loaded
+        for name, (res, args) in _PROTOS.items():
+            f = getattr(l, name)
+            f.restype, f.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(err, what=''):
+    if err != 0:
+        raise MyoloError(f'libmyolo {what} failed with error {err}' + (' (invalid argument)' if err == -22 else ''))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t):
+    if not t.is_cuda:
+        raise MyoloError('multiyolov5_amd runs on MI355X (gfx950) only: tensor is on %s; there is no CPU path' % t.device)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)

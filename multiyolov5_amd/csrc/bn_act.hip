@@ -1,0 +1,263 @@
+// Training-mode BatchNorm2d (+SiLU) (+Bottleneck residual) around a raw conv output, forward and backward.
+// HBM-bound elementwise / reduction kernels: 16-byte NHWC vectors, fp32 math, per-block scale/shift table in LDS.
+// The batch statistics themselves come for free from the conv kernel's epilogue (myolo_conv `stats`).
+// Replaces nn.BatchNorm2d (batch-stat path) + nn.SiLU + `x + cv2(cv1(x))` (reference models/common.py:43,105;
+// eps 1e-3 / momentum 0.03 from utils/torch_utils.py:150-151) and their autograd backward.
+#include "myolo_dev.h"
+
+namespace {
+
+struct PixDec {  // linear pixel -> (n,y,x) of a view
+  int hw, w;
+  __device__ PixDec(const myolo_tensor& t) : hw(t.h * t.w), w(t.w) {}
+  __device__ void get(int64_t pix, int& n, int& y, int& x) const {
+    n = (int)(pix / hw);
+    const int r = (int)(pix - (int64_t)n * hw);
+    y = r / w;
+    x = r - y * w;
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const float* __restrict__ stats,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* rm, float* rv, int64_t* nbt, float* saved, float eps,
+                                                         float mom, int act, myolo_tensor res, myolo_tensor out) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float tab[];  // [2*C]: scale, shift
+  const int C = y.c;
+  const int64_t M = (int64_t)y.n * y.h * y.w;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float sc = 1.f, sh = 0.f;
+    if (gamma) {
+      const float mean = stats[c] / (float)M;
+      float var = stats[C + c] / (float)M - mean * mean;
+      var = var > 0.f ? var : 0.f;
+      const float invstd = rsqrtf(var + eps);
+      sc = gamma[c] * invstd;
+      sh = beta[c] - mean * sc;
+      if (blockIdx.x == 0) {
+        if (saved) { saved[c] = mean; saved[C + c] = invstd; }
+        if (rm) {
+          rm[c] = (1.f - mom) * rm[c] + mom * mean;
+          const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+          rv[c] = (1.f - mom) * rv[c] + mom * unb;
+        }
+      }
+    }
+    tab[c] = sc;
+    tab[C + c] = sh;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && gamma) *nbt += 1;
+  __syncthreads();
+  const int G = C / SEG;
+  const int64_t total = M * G;
+  const PixDec pd(y);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = v / G;
+    const int cg = (int)(v - pix * G);
+    int n, yy, xx;
+    pd.get(pix, n, yy, xx);
+    float f[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(y, n, yy, xx) + cg * SEG), f);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) f[i] = act_f(f[i] * tab[cg * SEG + i] + tab[C + cg * SEG + i], act);
+    if (res.ptr) {
+      float g[SEG];
+      Vec<T>::unpack(ldg16(vptr<T>(res, n, yy, xx) + cg * SEG), g);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) f[i] += g[i];
+    }
+    stg16(vptr<T>(out, n, yy, xx) + cg * SEG, Vec<T>::pack(f));
+  }
+}
+
+// z and xhat of one element from the saved (mean, invstd)
+struct BnCoef { float sc, sh, mean, invstd; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gout, myolo_tensor y,
+                                                                const float* __restrict__ saved,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int act, float* dsum,
+                                                                int G, int PPB) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float red[];  // [PPB][G*SEG*2]
+  const int C = y.c;
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  const int64_t M = (int64_t)y.n * y.h * y.w;
+  float sc[SEG], sh[SEG], mean[SEG], istd[SEG], s0[SEG], s1[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) {
+    const int c = cg * SEG + i;
+    mean[i] = saved[c]; istd[i] = saved[C + c];
+    sc[i] = gamma[c] * istd[i]; sh[i] = beta[c] - mean[i] * sc[i];
+    s0[i] = 0.f; s1[i] = 0.f;
+  }
+  const PixDec pd(y);
+  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += (int64_t)gridDim.x * PPB) {
+    int n, yy, xx;
+    pd.get(pix, n, yy, xx);
+    float fy[SEG], fg[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(y, n, yy, xx) + cg * SEG), fy);
+    Vec<T>::unpack(ldg16(vptr<T>(gout, n, yy, xx) + cg * SEG), fg);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+      const float dz = fg[i] * act_grad_f(fy[i] * sc[i] + sh[i], act);
+      s0[i] += dz;
+      s1[i] += dz * (fy[i] - mean[i]) * istd[i];
+    }
+  }
+  float* mine = red + (size_t)pl * (G * SEG * 2) + cg * SEG * 2;
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) { mine[2 * i] = s0[i]; mine[2 * i + 1] = s1[i]; }
+  __syncthreads();
+  for (int j = threadIdx.x; j < G * SEG * 2; j += blockDim.x) {
+    float a = 0.f;
+    for (int q = 0; q < PPB; ++q) a += red[(size_t)q * (G * SEG * 2) + j];
+    const int c = j >> 1;
+    atomicAdd(dsum + ((j & 1) ? C + c : c), a);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout, myolo_tensor y,
+                                                               const float* __restrict__ saved,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int act,
+                                                               const float* __restrict__ dsum, float* dgamma,
+                                                               float* dbeta, myolo_tensor dy, myolo_tensor gres,
+                                                               int gres_acc) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float tab[];  // [6*C]: sc, sh, mean, invstd, k0 = dsum0/M, k1 = dsum1/M
+  const int C = y.c;
+  const int64_t M = (int64_t)y.n * y.h * y.w;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    if (gamma) {
+      const float mean = saved[c], istd = saved[C + c];
+      const float sc = gamma[c] * istd;
+      tab[c] = sc; tab[C + c] = beta[c] - mean * sc; tab[2 * C + c] = mean; tab[3 * C + c] = istd;
+      tab[4 * C + c] = dsum[c] / (float)M; tab[5 * C + c] = dsum[C + c] / (float)M;
+      if (blockIdx.x == 0) {
+        if (dgamma) dgamma[c] += dsum[C + c];
+        if (dbeta) dbeta[c] += dsum[c];
+      }
+    } else {
+      tab[c] = 1.f; tab[C + c] = 0.f; tab[2 * C + c] = 0.f; tab[3 * C + c] = 1.f; tab[4 * C + c] = 0.f; tab[5 * C + c] = 0.f;
+    }
+  }
+  __syncthreads();
+  const int G = C / SEG;
+  const int64_t total = M * G;
+  const PixDec pd(y);
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t pix = v / G;
+    const int cg = (int)(v - pix * G);
+    int n, yy, xx;
+    pd.get(pix, n, yy, xx);
+    float fy[SEG], fg[SEG], o[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(y, n, yy, xx) + cg * SEG), fy);
+    Vec<T>::unpack(ldg16(vptr<T>(gout, n, yy, xx) + cg * SEG), fg);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+      const int c = cg * SEG + i;
+      const float sc = tab[c];
+      const float dz = fg[i] * act_grad_f(fy[i] * sc + tab[C + c], act);
+      const float xh = (fy[i] - tab[2 * C + c]) * tab[3 * C + c];
+      o[i] = gamma ? sc * (dz - tab[4 * C + c] - xh * tab[5 * C + c]) : dz;
+    }
+    stg16(vptr<T>(dy, n, yy, xx) + cg * SEG, Vec<T>::pack(o));
+    if (gres.ptr) {
+      T* gp = vptr<T>(gres, n, yy, xx) + cg * SEG;
+      if (gres_acc) {
+        float a[SEG];
+        Vec<T>::unpack(ldg16(gp), a);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) fg[i] += a[i];
+      }
+      stg16(gp, Vec<T>::pack(fg));
+    }
+  }
+}
+
+inline bool same_shape(const myolo_tensor* a, const myolo_tensor* b) {
+  return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c && a->dtype == b->dtype;
+}
+inline bool vec_ok(const myolo_tensor* t) {
+  const int seg = t->dtype == MYOLO_F16 ? 8 : 4;
+  return t->ptr && (t->dtype == MYOLO_F16 || t->dtype == MYOLO_F32) && t->c % seg == 0 && t->sw % seg == 0 &&
+         t->sh % seg == 0 && t->sn % seg == 0 && ((uintptr_t)t->ptr & 15) == 0;
+}
+
+}  // namespace
+
+extern "C" int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* nbt, float* saved, float eps,
+                                float momentum, int act, const myolo_tensor* res, const myolo_tensor* out,
+                                void* stream) {
+  if (!y || !out || !vec_ok(y) || !vec_ok(out) || !same_shape(y, out)) return MYOLO_EINVAL;
+  if (gamma && (!stats || !beta)) return MYOLO_EINVAL;
+  myolo_tensor r{};
+  if (res && res->ptr) { if (!vec_ok(res) || !same_shape(res, y)) return MYOLO_EINVAL; r = *res; }
+  const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
+  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / seg);
+  const int grid = grid_for(total, 256);
+  const size_t smem = (size_t)2 * y->c * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (y->dtype == MYOLO_F16)
+    hipLaunchKernelGGL(bn_act_fwd_kernel<half_t>, dim3(grid), dim3(256), smem, st, *y, stats, gamma, beta, running_mean,
+                       running_var, nbt, saved, eps, momentum, act, r, *out);
+  else
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), smem, st, *y, stats, gamma, beta, running_mean,
+                       running_var, nbt, saved, eps, momentum, act, r, *out);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                       const float* gamma, const float* beta, int act, float* dsum, void* stream) {
+  if (!gout || !y || !vec_ok(gout) || !vec_ok(y) || !same_shape(gout, y) || !saved || !gamma || !beta || !dsum)
+    return MYOLO_EINVAL;
+  const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
+  const int G = y->c / seg;
+  if (G > 256) return MYOLO_EINVAL;
+  const int PPB = 256 / G;
+  const int64_t M = (int64_t)y->n * y->h * y->w;
+  int grid = (int)((M + PPB * 8 - 1) / (PPB * 8));   // >= 8 pixels per thread
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  const size_t smem = (size_t)PPB * G * seg * 2 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (y->dtype == MYOLO_F16)
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
+                       beta, act, dsum, G, PPB);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
+                       beta, act, dsum, G, PPB);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                      const float* gamma, const float* beta, int act, const float* dsum,
+                                      float* dgamma, float* dbeta, const myolo_tensor* dy, const myolo_tensor* gres,
+                                      int gres_accumulate, void* stream) {
+  if (!gout || !y || !dy || !vec_ok(gout) || !vec_ok(y) || !vec_ok(dy) || !same_shape(gout, y) || !same_shape(dy, y))
+    return MYOLO_EINVAL;
+  if (gamma && (!saved || !beta || !dsum)) return MYOLO_EINVAL;
+  myolo_tensor r{};
+  if (gres && gres->ptr) { if (!vec_ok(gres) || !same_shape(gres, y)) return MYOLO_EINVAL; r = *gres; }
+  const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
+  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / seg);
+  const int grid = grid_for(total, 256);
+  const size_t smem = (size_t)6 * y->c * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (y->dtype == MYOLO_F16)
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), smem, st, *gout, *y, saved, gamma, beta,
+                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate);
+  else
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(256), smem, st, *gout, *y, saved, gamma, beta,
+                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,341 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4): NHWC activations, packed [cout][tap][cin] weights,
+// MFMA 16x16x32 f16 (or 16x16x4 f32 in parity mode), fp32 accumulate, fused epilogue.
+//
+//   GEMM view: M = N*Ho*Wo pixels, N = Cout, K = ntaps*Cin.   One workgroup = 256 threads = 4 waves
+//   computes a BM(128) x BN(32|64|128) output tile; wave w owns rows [32w,32w+32) x all BN columns
+//   (2 x BN/16 accumulator fragments).  The K loop walks (tap, 64-byte channel chunk); each step the
+//   A tile (128 pixel rows x 64 B, gathered at the tap's shifted pixel) and the B tile (BN weight rows
+//   x 64 B) are staged global -> registers -> LDS (double buffered, one barrier per step; the global
+//   loads of step s+1 are in flight while step s computes).  LDS rows are 64 B with the 16-byte
+//   segment index XOR-ed by H[(row>>2)&3] = {0,2,3,1}: conflict-free for the ds_read_b128 lane groups
+//   of the MFMA fragment pattern (row = lane&15, segment = lane>>4) and for the staging writes.
+//
+//   Workgroups are persistent over M tiles (grid.x, XCD-contiguous ranges so that vertically adjacent
+//   tiles of a 3x3 conv share one XCD's L2) with a fixed N tile (grid.y): the training-mode BatchNorm
+//   statistics (sum, sum of squares of the raw fp32 accumulators) are kept in registers across the
+//   tiles and flushed once per workgroup with 2*BN atomics.
+//
+//   Epilogue: v = acc*scale[c]+shift[c] -> act -> staged through LDS so that global stores are
+//   16-byte row-contiguous (NHWC) -> (+ residual / += y) -> store, or Detect's permuted layout.
+//
+// Replaces: nn.Conv2d+BatchNorm2d+SiLU (reference models/common.py:34-46, 481-490), Detect.m (yolo.py:211-214),
+// and their dgrad (transposed weights, flipped taps, stride-2 by output parity).
+#include "myolo_dev.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int THREADS = 256;
+
+struct ConvK {
+  const char* x; int64_t x_sn, x_sh, x_sw; int Hi, Wi, Cin;
+  char* y; int64_t y_sn, y_sh, y_sw; int Ho, Wo, Cout, N;
+  const char* w; int cin_pad, cout_pad, wtaps, ntaps, stride, up;
+  int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS], tap_w[MYOLO_MAX_TAPS];
+  const float* scale; const float* shift; int act; int accumulate;
+  const char* res; int64_t r_sn, r_sh, r_sw;
+  float* stats; int det_no; int M; int ntile_m; int tiles_per_xcd;
+};
+
+}  // namespace
+
+// H = {0,2,3,1} packed two bits per entry: 0b01'11'10'00 = 0x78
+namespace {
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
+__device__ __forceinline__ int lds_off2(int row, int seg) { return row * 64 + ((seg ^ swz(row)) << 4); }
+
+template <typename T> struct Mma;
+template <> struct Mma<half_t> {
+  __device__ static void run(const uint4& a, const uint4& b, f4_t& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8_t*>(&a),
+                                                 *reinterpret_cast<const h8_t*>(&b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  __device__ static void run(const uint4& a, const uint4& b, f4_t& acc) {
+    const float* fa = reinterpret_cast<const float*>(&a);
+    const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j], fb[j], acc, 0, 0, 0);
+  }
+};
+
+template <typename T, int BN>
+__global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
+  constexpr int SEG = ET<T>::SEG;   // elements per 16 B
+  constexpr int KC = ET<T>::KC;     // elements per 64 B K-chunk
+  constexpr int NF = BN / 16;
+  constexpr int ES = (int)sizeof(T);
+  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  constexpr int CROW = BN * ES + 16;            // C staging row pitch (bytes)
+  constexpr int BROWS = (BN + 63) / 64;         // B rows per thread (64 rows per pass)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;                 // [2][A_BYTES]
+  char* sB = smem + 2 * A_BYTES;   // [2][B_BYTES]
+  char* sC = smem;                 // epilogue staging (aliases A/B)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tn = blockIdx.y;
+  const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3, bstride = gridDim.x >> 3;
+  const int kchunks = p.cin_pad / KC;
+  const int nsteps = p.ntaps * kchunks;
+  const int HWo = p.Ho * p.Wo;
+  const int Hlog = p.Hi << p.up, Wlog = p.Wi << p.up;
+
+  // staging roles
+  const int lrow = tid >> 2, lseg = tid & 3;   // A rows lrow, lrow+64 ; B rows lrow (+64)
+
+  // per-lane BN statistics partials (persist across this workgroup's tiles)
+  float st_s[NF], st_q[NF];
+#pragma unroll
+  for (int i = 0; i < NF; ++i) { st_s[i] = 0.f; st_q[i] = 0.f; }
+
+  // per-lane epilogue constants: channel = tn*BN + nf*16 + (lane&15)
+  float e_scale[NF], e_shift[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int c = tn * BN + nf * 16 + (lane & 15);
+    e_scale[nf] = (p.scale && c < p.Cout) ? p.scale[c] : 1.0f;
+    e_shift[nf] = (p.shift && c < p.Cout) ? p.shift[c] : 0.0f;
+  }
+
+  const char* wbase = p.w + (int64_t)(tn * BN) * p.wtaps * p.cin_pad * ES;
+
+  for (int tslot = bslot; tslot < p.tiles_per_xcd; tslot += bstride) {
+    const int tm = xcd * p.tiles_per_xcd + tslot;
+    if (tm >= p.ntile_m) break;
+    const int m0 = tm * BM;
+
+    // decode this thread's two A rows
+    int rn[2], roy[2], rox[2]; bool rvalid[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int m = m0 + lrow + r * 64;
+      rvalid[r] = m < p.M;
+      const int mm = rvalid[r] ? m : 0;
+      rn[r] = mm / HWo;
+      const int rem = mm - rn[r] * HWo;
+      roy[r] = rem / p.Wo;
+      rox[r] = rem - roy[r] * p.Wo;
+    }
+
+    f4_t acc[2][NF];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NF; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[2], rb[BROWS];
+    const char* arow[2] = {nullptr, nullptr};
+    int cur_tap = -1;
+
+    auto issue_loads = [&](int s) {
+      const int tap = s / kchunks, kc = s - tap * kchunks;
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        const int dy = p.tap_dy[tap], dx = p.tap_dx[tap];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          int iy = roy[r] * p.stride + dy, ix = rox[r] * p.stride + dx;
+          const bool ok = rvalid[r] && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
+          iy >>= p.up; ix >>= p.up;
+          arow[r] = ok ? p.x + ((int64_t)rn[r] * p.x_sn + (int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * ES : nullptr;
+        }
+      }
+      const int c0 = kc * KC + lseg * SEG;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        if (arow[r] != nullptr && c0 < p.Cin) ra[r] = ldg16(arow[r] + (int64_t)c0 * ES);
+        else ra[r] = uint4{0u, 0u, 0u, 0u};
+      }
+      const int wt = p.tap_w[tap];
+#pragma unroll
+      for (int r = 0; r < BROWS; ++r) {
+        const int brow = lrow + r * 64;
+        if (BN >= 64 || brow < BN)
+          rb[r] = ldg16(wbase + ((int64_t)(brow * p.wtaps + wt) * p.cin_pad + c0) * ES);
+      }
+    };
+    auto store_lds = [&](int buf) {
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+        *reinterpret_cast<uint4*>(sA + buf * A_BYTES + lds_off2(lrow + r * 64, lseg)) = ra[r];
+#pragma unroll
+      for (int r = 0; r < BROWS; ++r) {
+        const int brow = lrow + r * 64;
+        if (BN >= 64 || brow < BN)
+          *reinterpret_cast<uint4*>(sB + buf * B_BYTES + lds_off2(brow, lseg)) = rb[r];
+      }
+    };
+
+    issue_loads(0);
+    store_lds(0);
+    __syncthreads();
+
+    for (int s = 0; s < nsteps; ++s) {
+      const int buf = s & 1;
+      if (s + 1 < nsteps) issue_loads(s + 1);
+      // fragments
+      uint4 fa[2], fb[NF];
+      const int frow = lane & 15, fseg = lane >> 4;
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+        fa[mf] = *reinterpret_cast<const uint4*>(sA + buf * A_BYTES + lds_off2(wave * 32 + mf * 16 + frow, fseg));
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        fb[nf] = *reinterpret_cast<const uint4*>(sB + buf * B_BYTES + lds_off2(nf * 16 + frow, fseg));
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[mf], fb[nf], acc[mf][nf]);
+      if (s + 1 < nsteps) store_lds(buf ^ 1);
+      __syncthreads();
+    }
+
+    // ---- epilogue ----
+    // acc[mf][nf][r] = D[row = wave*32+mf*16+4*(lane>>4)+r][col = nf*16+(lane&15)]
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = acc[mf][nf][r];
+          st_s[nf] += v0;
+          st_q[nf] += v0 * v0;
+          float v = v0 * e_scale[nf] + e_shift[nf];
+          v = act_f(v, p.act);
+          const int row = wave * 32 + mf * 16 + 4 * (lane >> 4) + r;
+          const int col = nf * 16 + (lane & 15);
+          *reinterpret_cast<T*>(sC + row * CROW + col * ES) = (T)v;
+        }
+      }
+    __syncthreads();
+    constexpr int VPR = BN / SEG;   // 16-byte vectors per row
+    for (int v = tid; v < BM * VPR; v += THREADS) {
+      const int row = v / VPR, cs = v - row * VPR;
+      const int m = m0 + row;
+      const int c0 = tn * BN + cs * SEG;
+      if (m >= p.M || c0 >= p.Cout) continue;
+      const int n = m / HWo; const int rem = m - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+      uint4 cv = *reinterpret_cast<const uint4*>(sC + row * CROW + cs * 16);
+      float f[SEG];
+      Vec<T>::unpack(cv, f);
+      const int nvalid = (p.Cout - c0) < SEG ? (p.Cout - c0) : SEG;
+      if (p.det_no > 0) {
+        // Detect layout: [n, a, oy, ox, o] with conv channel = a*no + o
+        T* yb = reinterpret_cast<T*>(p.y);
+        const int na = p.Cout / p.det_no;
+        for (int i = 0; i < nvalid; ++i) {
+          const int c = c0 + i; const int a = c / p.det_no, o = c - a * p.det_no;
+          yb[(((int64_t)(n * na + a) * p.Ho + oy) * p.Wo + ox) * p.det_no + o] = (T)f[i];
+        }
+        continue;
+      }
+      char* yp = p.y + ((int64_t)n * p.y_sn + (int64_t)oy * p.y_sh + (int64_t)ox * p.y_sw + c0) * ES;
+      if (nvalid == SEG) {
+        if (p.res) {
+          float g[SEG];
+          Vec<T>::unpack(ldg16(p.res + ((int64_t)n * p.r_sn + (int64_t)oy * p.r_sh + (int64_t)ox * p.r_sw + c0) * ES), g);
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) f[i] += g[i];
+        }
+        if (p.accumulate) {
+          float g[SEG];
+          Vec<T>::unpack(ldg16(yp), g);
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) f[i] += g[i];
+        }
+        stg16(yp, Vec<T>::pack(f));
+      } else {
+        T* ys = reinterpret_cast<T*>(yp);
+        const T* rs = p.res ? reinterpret_cast<const T*>(p.res + ((int64_t)n * p.r_sn + (int64_t)oy * p.r_sh + (int64_t)ox * p.r_sw + c0) * ES) : nullptr;
+        for (int i = 0; i < nvalid; ++i) {
+          float v2 = f[i];
+          if (rs) v2 += (float)rs[i];
+          if (p.accumulate) v2 += (float)ys[i];
+          ys[i] = (T)v2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (p.stats) {
+    // reduce partials over the 4 lane groups (rows), then one atomic per channel per wave
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      float s = st_s[nf], q = st_q[nf];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      const int c = tn * BN + nf * 16 + (lane & 15);
+      if (lane < 16 && c < p.Cout) {
+        atomicAdd(p.stats + c, s);
+        atomicAdd(p.stats + p.Cout + c, q);
+      }
+    }
+  }
+}
+
+template <typename T, int BN>
+int launch_conv(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int AB = 2 * (BM * 64 + BN * 64);
+  constexpr int CB = BM * (BN * ES + 16);
+  const int smem = AB > CB ? AB : CB;
+  auto kern = conv_igemm_kernel<T, BN>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
+  if (!d || !d->x.ptr || !d->y.ptr || !d->w) return MYOLO_EINVAL;
+  const int dt = d->x.dtype;
+  if (dt != d->y.dtype || (dt != MYOLO_F16 && dt != MYOLO_F32)) return MYOLO_EINVAL;
+  const int es = dt == MYOLO_F16 ? 2 : 4, seg = 16 / es, kc = 64 / es;
+  if (d->ntaps < 1 || d->ntaps > MYOLO_MAX_TAPS) return MYOLO_EINVAL;
+  if (d->cin_pad % kc || d->cout_pad % 32 || d->x.c > d->cin_pad || d->y.c > d->cout_pad) return MYOLO_EINVAL;
+  if (d->x.c % seg || d->x.sw % seg || d->x.sh % seg || d->x.sn % seg || ((uintptr_t)d->x.ptr & 15)) return MYOLO_EINVAL;
+  if (d->det_no > 0 && (d->y.c % d->det_no)) return MYOLO_EINVAL;
+  if (d->res.ptr && d->res.dtype != dt) return MYOLO_EINVAL;
+  ConvK k;
+  k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw;
+  k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;
+  k.y = (char*)d->y.ptr; k.y_sn = d->y.sn; k.y_sh = d->y.sh; k.y_sw = d->y.sw;
+  k.Ho = d->y.h; k.Wo = d->y.w; k.Cout = d->y.c; k.N = d->y.n;
+  k.w = (const char*)d->w; k.cin_pad = d->cin_pad; k.cout_pad = d->cout_pad; k.wtaps = d->wtaps;
+  k.ntaps = d->ntaps; k.stride = d->stride; k.up = d->up_shift;
+  for (int i = 0; i < MYOLO_MAX_TAPS; ++i) { k.tap_dy[i] = d->tap_dy[i]; k.tap_dx[i] = d->tap_dx[i]; k.tap_w[i] = d->tap_w[i]; }
+  k.scale = d->scale; k.shift = d->shift; k.act = d->act; k.accumulate = d->accumulate;
+  k.res = (const char*)d->res.ptr; k.r_sn = d->res.sn; k.r_sh = d->res.sh; k.r_sw = d->res.sw;
+  k.stats = d->stats; k.det_no = d->det_no;
+  const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
+  if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
+  k.M = (int)M;
+  k.ntile_m = (int)((M + BM - 1) / BM);
+  k.tiles_per_xcd = (k.ntile_m + 7) / 8;
+  const int bn = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
+  const int ntile_n = d->cout_pad / bn;
+  // persistent grid: ~3 workgroups per CU in total, multiple of 8 (one slot range per XCD)
+  int per_xcd = (768 / ntile_n + 7) / 8;
+  if (per_xcd < 1) per_xcd = 1;
+  if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
+  const int grid_x = per_xcd * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == MYOLO_F16) {
+    if (bn == 128) return launch_conv<half_t, 128>(k, grid_x, ntile_n, st);
+    if (bn == 64) return launch_conv<half_t, 64>(k, grid_x, ntile_n, st);
+    return launch_conv<half_t, 32>(k, grid_x, ntile_n, st);
+  } else {
+    if (bn == 128) return launch_conv<float, 128>(k, grid_x, ntile_n, st);
+    if (bn == 64) return launch_conv<float, 64>(k, grid_x, ntile_n, st);
+    return launch_conv<float, 32>(k, grid_x, ntile_n, st);
+  }
+}

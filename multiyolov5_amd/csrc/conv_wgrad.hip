@@ -1,0 +1,217 @@
+// Weight gradient of the NHWC convolution on gfx950 MFMA.
+//
+//   dW[co][ci][t] += sum_{pixels m} dy[m][co] * x[m shifted by tap t][ci]        (fp32, OIHW = Parameter.grad layout)
+//
+// GEMM view per tap: out [Cout x Cin], contraction K = pixels.  Both operands are pixel-major in HBM
+// (NHWC), i.e. K is the *slow* index of both -- the MFMA wants K-contiguous fragments.  The tile
+// [32 pixels][64 channels] is therefore staged row-major in LDS exactly as it lies in HBM (16-byte
+// coalesced loads, no transposition pass) and fragments are read with the gfx950 LDS transpose read
+// `ds_read_b64_tr_b16` (fp16), which hands each lane 4 consecutive K values of its own column; the fp32
+// parity path reads one dword per lane per 16x16x4 MFMA, which needs no transposition at all.
+//
+// One workgroup (256 threads, 4 waves as 2x2) owns a 64(co) x 64(ci) tile of one tap and a contiguous
+// range of pixels (split-K); partial tiles are combined with fp32 atomics.  Replaces the autograd wgrad of
+// nn.Conv2d (reference models/common.py:38,42; invoked by loss.backward() at train.py:371,392).
+#include "myolo_dev.h"
+
+namespace {
+
+constexpr int WT = 64;        // tile edge (channels)
+constexpr int KP = 32;        // pixels per K step
+constexpr int THREADS = 256;
+
+struct WgradK {
+  const char* x; int64_t x_sn, x_sh, x_sw; int Hi, Wi, Cin;
+  const char* dy; int64_t d_sn, d_sh, d_sw; int Ho, Wo, Cout, N;
+  float* dw; float* db;
+  int ntaps, stride, up;
+  int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
+  int M, ksplit, pix_per_split, tiles_co, tiles_ci;
+  int cout_w, cin_w;   // real (unpadded) weight dims: bounds of dw
+};
+
+template <typename T> struct Pitch;                       // LDS row pitch in bytes for a [KP][64] tile
+template <> struct Pitch<half_t> { static constexpr int V = 64 * 2 + 16; };
+template <> struct Pitch<float> { static constexpr int V = 64 * 4 + 16; };
+
+template <typename T>
+__global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradK p) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int SEG = ET<T>::SEG;
+  constexpr int PITCH = Pitch<T>::V;
+  constexpr int SEGS_PER_ROW = WT / SEG;                  // 8 (f16) / 16 (f32)
+  constexpr int LOADS = KP * SEGS_PER_ROW / THREADS;      // 1 (f16) / 2 (f32) 16-byte loads per thread per tile
+  __shared__ __attribute__((aligned(16))) char sD[2][KP * PITCH];   // dy tile  [pixel][co]
+  __shared__ __attribute__((aligned(16))) char sX[2][KP * PITCH];   // x tile   [pixel][ci]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;               // wave tile: co rows [32wr,+32), ci cols [32wc,+32)
+  int b = blockIdx.x;
+  const int tci = b % p.tiles_ci; b /= p.tiles_ci;
+  const int tco = b % p.tiles_co; b /= p.tiles_co;
+  const int tap = b;
+  const int split = blockIdx.y;
+  const int co0 = tco * WT, ci0 = tci * WT;
+  const int HWo = p.Ho * p.Wo;
+  const int Hlog = p.Hi << p.up, Wlog = p.Wi << p.up;
+  const int tdy = p.tap_dy[tap], tdx = p.tap_dx[tap];
+  const int m_begin = split * p.pix_per_split;
+  int m_end = m_begin + p.pix_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int nsteps = (m_end - m_begin + KP - 1) / KP;
+
+  f4_t acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  float bias_part = 0.f;   // db partial: thread (tid<64) sums dy column co0+tid ; only for tci==0 && tap==0
+
+  uint4 rd[LOADS], rx[LOADS];
+  auto issue = [&](int s) {
+#pragma unroll
+    for (int l = 0; l < LOADS; ++l) {
+      const int v = tid + l * THREADS;
+      const int prow = v / SEGS_PER_ROW, cs = v - prow * SEGS_PER_ROW;
+      const int m = m_begin + s * KP + prow;
+      rd[l] = uint4{0u, 0u, 0u, 0u};
+      rx[l] = uint4{0u, 0u, 0u, 0u};
+      if (m < m_end) {
+        const int n = m / HWo; const int rem = m - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+        const int cd = co0 + cs * SEG;
+        if (cd < p.Cout)
+          rd[l] = ldg16(p.dy + ((int64_t)n * p.d_sn + (int64_t)oy * p.d_sh + (int64_t)ox * p.d_sw + cd) * ES);
+        int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
+        const int cx = ci0 + cs * SEG;
+        if (iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog && cx < p.Cin) {
+          iy >>= p.up; ix >>= p.up;
+          rx[l] = ldg16(p.x + ((int64_t)n * p.x_sn + (int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw + cx) * ES);
+        }
+      }
+    }
+  };
+  auto stage = [&](int buf) {
+#pragma unroll
+    for (int l = 0; l < LOADS; ++l) {
+      const int v = tid + l * THREADS;
+      const int prow = v / SEGS_PER_ROW, cs = v - prow * SEGS_PER_ROW;
+      *reinterpret_cast<uint4*>(&sD[buf][prow * PITCH + cs * 16]) = rd[l];
+      *reinterpret_cast<uint4*>(&sX[buf][prow * PITCH + cs * 16]) = rx[l];
+    }
+  };
+
+  if (nsteps > 0) {
+    issue(0);
+    stage(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) issue(s + 1);
+    if constexpr (sizeof(T) == 2) {
+      // A fragment (co): lane (i = lane&15, g = lane>>4) needs dy[pixel 8g..8g+7][co = base + i]:
+      // two transpose reads of a [4 pixel][16 co] block; within the 16-lane group lane (4*k'+q) supplies
+      // the address of pixel row (8g + k') (+4), channels base+4q..4q+3, and receives column (lane&15).
+      const int g = lane >> 4, kq = (lane & 15) >> 2, q = lane & 3;
+      h8_t fa[2], fb[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int ca = (wr * 32 + f * 16 + q * 4) * 2;
+        const int cb = (wc * 32 + f * 16 + q * 4) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int prow = 8 * g + 4 * h + kq;
+          fp16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) fp16x4_t*)(&sD[buf][prow * PITCH + ca]));
+          fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) fp16x4_t*)(&sX[buf][prow * PITCH + cb]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { fa[f][4 * h + e] = (half_t)va[e]; fb[f][4 * h + e] = (half_t)vb[e]; }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    } else {
+      const int i16 = lane & 15, g = lane >> 4;
+#pragma unroll
+      for (int kk = 0; kk < KP / 4; ++kk) {
+        const int prow = kk * 4 + g;
+        float a[2], bb[2];
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          a[f] = *reinterpret_cast<const float*>(&sD[buf][prow * PITCH + (wr * 32 + f * 16 + i16) * 4]);
+          bb[f] = *reinterpret_cast<const float*>(&sX[buf][prow * PITCH + (wc * 32 + f * 16 + i16) * 4]);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (p.db && tci == 0 && tap == 0 && tid < WT) {
+      for (int r = 0; r < KP; ++r) bias_part += (float)*reinterpret_cast<const T*>(&sD[buf][r * PITCH + tid * ES]);
+    }
+    if (s + 1 < nsteps) stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // acc[i][j][r] = D[row(co) = wr*32+i*16+4*(lane>>4)+r][col(ci) = wc*32+j*16+(lane&15)]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wr * 32 + i * 16 + 4 * (lane >> 4) + r;
+        const int ci = ci0 + wc * 32 + j * 16 + (lane & 15);
+        if (co < p.cout_w && ci < p.cin_w) atomicAdd(p.dw + ((int64_t)co * p.cin_w + ci) * p.ntaps + tap, acc[i][j][r]);
+      }
+  if (p.db && tci == 0 && tap == 0 && tid < WT && co0 + tid < p.cout_w) atomicAdd(p.db + co0 + tid, bias_part);
+}
+
+}  // namespace
+
+extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
+  if (!d || !d->x.ptr || !d->dy.ptr || !d->dw) return MYOLO_EINVAL;
+  const int dt = d->x.dtype;
+  if (dt != d->dy.dtype || (dt != MYOLO_F16 && dt != MYOLO_F32)) return MYOLO_EINVAL;
+  const int seg = dt == MYOLO_F16 ? 8 : 4;
+  if (d->ntaps < 1 || d->ntaps > MYOLO_MAX_TAPS) return MYOLO_EINVAL;
+  if (d->x.c % seg || d->x.sw % seg || d->x.sh % seg || d->x.sn % seg || ((uintptr_t)d->x.ptr & 15)) return MYOLO_EINVAL;
+  if (d->dy.sw % seg || d->dy.sh % seg || d->dy.sn % seg || ((uintptr_t)d->dy.ptr & 15)) return MYOLO_EINVAL;
+  WgradK k;
+  k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw; k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;
+  k.dy = (const char*)d->dy.ptr; k.d_sn = d->dy.sn; k.d_sh = d->dy.sh; k.d_sw = d->dy.sw;
+  k.Ho = d->dy.h; k.Wo = d->dy.w; k.Cout = d->dy.c; k.N = d->dy.n;
+  k.dw = d->dw; k.db = d->db; k.ntaps = d->ntaps; k.stride = d->stride; k.up = d->up_shift;
+  for (int i = 0; i < MYOLO_MAX_TAPS; ++i) { k.tap_dy[i] = d->tap_dy[i]; k.tap_dx[i] = d->tap_dx[i]; }
+  const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
+  if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
+  k.M = (int)M;
+  k.cout_w = d->cout > 0 ? d->cout : k.Cout;
+  k.cin_w = d->cin > 0 ? d->cin : k.Cin;
+  if (k.cout_w > k.Cout || k.cin_w > k.Cin) return MYOLO_EINVAL;
+  k.tiles_co = (k.cout_w + WT - 1) / WT;
+  k.tiles_ci = (k.cin_w + WT - 1) / WT;
+  const int out_tiles = k.tiles_co * k.tiles_ci * k.ntaps;
+  int ks = d->ksplit;
+  if (ks <= 0) {
+    ks = (1024 + out_tiles - 1) / out_tiles;                  // aim at ~1024 workgroups
+    const int max_ks = (int)((M + 8 * KP - 1) / (8 * KP));    // but at least 8 K-steps each
+    if (ks > max_ks) ks = max_ks;
+    if (ks < 1) ks = 1;
+  }
+  int pps = (int)((M + ks - 1) / ks);
+  pps = (pps + KP - 1) / KP * KP;
+  ks = (int)((M + pps - 1) / pps);
+  k.ksplit = ks; k.pix_per_split = pps;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == MYOLO_F16) hipLaunchKernelGGL(wgrad_kernel<half_t>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
+  else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,93 @@
+// Device-side helpers shared by the gfx950 kernels of libmyolo (CDNA4 only: wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/myolo.h"
+
+typedef _Float16 half_t;
+typedef _Float16 h8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+#define MYOLO_CHECK_LAUNCH()                                  \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) return (int)e__;                   \
+  } while (0)
+
+// element traits: a "segment" is one 16-byte vector (8 halves / 4 floats)
+template <typename T> struct ET;
+template <> struct ET<half_t> { static constexpr int SEG = 8; static constexpr int KC = 32; };
+template <> struct ET<float>  { static constexpr int SEG = 4; static constexpr int KC = 16; };
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + __expf(-z)); }
+__device__ __forceinline__ float sigmoid_f(float z) { return 1.0f / (1.0f + __expf(-z)); }
+// d silu(z)/dz = s(z) * (1 + z * (1 - s(z)))
+__device__ __forceinline__ float silu_grad_f(float z) {
+  float s = sigmoid_f(z);
+  return s * (1.0f + z * (1.0f - s));
+}
+__device__ __forceinline__ float act_f(float z, int act) {
+  return act == MYOLO_ACT_SILU ? silu_f(z) : (act == MYOLO_ACT_SIGMOID ? sigmoid_f(z) : z);
+}
+__device__ __forceinline__ float act_grad_f(float z, int act) {
+  if (act == MYOLO_ACT_SILU) return silu_grad_f(z);
+  if (act == MYOLO_ACT_SIGMOID) { float s = sigmoid_f(z); return s * (1.0f - s); }
+  return 1.0f;
+}
+
+// 16-byte vector <-> float[SEG]
+template <typename T> struct Vec;
+template <> struct Vec<half_t> {
+  static constexpr int N = 8;
+  __device__ static void unpack(const uint4& v, float* f) {
+    const half_t* h = reinterpret_cast<const half_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)h[i];
+  }
+  __device__ static uint4 pack(const float* f) {
+    uint4 v;
+    half_t* h = reinterpret_cast<half_t*>(&v);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) h[i] = (half_t)f[i];
+    return v;
+  }
+};
+template <> struct Vec<float> {
+  static constexpr int N = 4;
+  __device__ static void unpack(const uint4& v, float* f) {
+    const float* h = reinterpret_cast<const float*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = h[i];
+  }
+  __device__ static uint4 pack(const float* f) {
+    uint4 v;
+    float* h = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h[i] = f[i];
+    return v;
+  }
+};
+
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+// view addressing (strides in elements)
+template <typename T>
+__device__ __forceinline__ T* vptr(const myolo_tensor& t, int n, int y, int x) {
+  return reinterpret_cast<T*>(t.ptr) + (int64_t)n * t.sn + (int64_t)y * t.sh + (int64_t)x * t.sw;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+static inline int grid_for(int64_t work_items, int threads, int max_blocks = 2048) {
+  int64_t b = (work_items + threads - 1) / threads;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (int)b;
+}

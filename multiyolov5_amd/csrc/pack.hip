@@ -1,0 +1,98 @@
+// Layout transforms at the edge of the hot path (HBM-bound, one pass each):
+//   * OIHW master weights -> packed [row][tap][col] MFMA operand (forward or transposed for dgrad),
+//     optional per-output-channel scale (BN folding, reference utils/torch_utils.py:193-195);
+//   * Focus space-to-depth + image cast (reference models/common.py:550, train.py:342 `/255`).
+#include "myolo_dev.h"
+
+namespace {
+
+template <typename S, typename D>
+__global__ void pack_weight_kernel(const S* __restrict__ src, D* __restrict__ dst, int cout, int cin, int ntaps,
+                                   int rows_pad, int cols_pad, int transpose, const float* __restrict__ row_scale) {
+  const int64_t total = (int64_t)rows_pad * ntaps * cols_pad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % cols_pad);
+    const int t = (int)((i / cols_pad) % ntaps);
+    const int row = (int)(i / ((int64_t)cols_pad * ntaps));
+    const int co = transpose ? col : row, ci = transpose ? row : col;
+    float v = 0.f;
+    if (co < cout && ci < cin) {
+      v = (float)src[((int64_t)co * cin + ci) * ntaps + t];
+      if (row_scale) v *= row_scale[co];
+    }
+    dst[i] = (D)v;
+  }
+}
+
+template <typename S, typename D>
+__global__ void focus_pack_kernel(const S* __restrict__ img, int n, int h, int w, float mul, myolo_tensor out) {
+  const int ho = h >> 1, wo = w >> 1;
+  const int64_t total = (int64_t)n * ho * wo;
+  const int64_t plane = (int64_t)h * w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % wo);
+    const int oy = (int)((i / wo) % ho);
+    const int b = (int)(i / ((int64_t)wo * ho));
+    D* o = vptr<D>(out, b, oy, ox);
+    const S* base = img + (int64_t)b * 3 * plane + (int64_t)(2 * oy) * w + 2 * ox;
+    D vals[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int dy = q & 1, dx = q >> 1;          // q: (0,0),(1,0),(0,1),(1,1) as (row parity, col parity)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) vals[3 * q + c] = (D)((float)base[c * plane + (int64_t)dy * w + dx] * mul);
+    }
+#pragma unroll
+    for (int c = 12; c < 16; ++c) vals[c] = (D)0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) o[c] = vals[c];
+  }
+}
+
+}  // namespace
+
+extern "C" int myolo_version(void) { return 1; }
+extern "C" const char* myolo_arch(void) { return "gfx950"; }
+
+extern "C" int myolo_pack_weight(const void* w, int src_dtype, int cout, int cin, int kh, int kw, void* dst,
+                                 int dst_dtype, int rows_pad, int cols_pad, int transpose, const float* row_scale,
+                                 void* stream) {
+  if (!w || !dst || cout <= 0 || cin <= 0) return MYOLO_EINVAL;
+  const int ntaps = kh * kw;
+  if ((transpose ? cin : cout) > rows_pad || (transpose ? cout : cin) > cols_pad) return MYOLO_EINVAL;
+  const int64_t total = (int64_t)rows_pad * ntaps * cols_pad;
+  const int grid = grid_for(total, 256);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(S, D)                                                                                           \
+  hipLaunchKernelGGL((pack_weight_kernel<S, D>), dim3(grid), dim3(256), 0, st, (const S*)w, (D*)dst, cout, cin, \
+                     ntaps, rows_pad, cols_pad, transpose, row_scale)
+  if (src_dtype == MYOLO_F32 && dst_dtype == MYOLO_F16) LAUNCH(float, half_t);
+  else if (src_dtype == MYOLO_F32 && dst_dtype == MYOLO_F32) LAUNCH(float, float);
+  else if (src_dtype == MYOLO_F16 && dst_dtype == MYOLO_F16) LAUNCH(half_t, half_t);
+  else if (src_dtype == MYOLO_F16 && dst_dtype == MYOLO_F32) LAUNCH(half_t, float);
+  else return MYOLO_EINVAL;
+#undef LAUNCH
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_focus_pack(const void* img, int src_dtype, int n, int h, int w, float mul,
+                                const myolo_tensor* out, void* stream) {
+  if (!img || !out || !out->ptr || (h & 1) || (w & 1) || out->c != 16 || out->h != h / 2 || out->w != w / 2 ||
+      out->n != n)
+    return MYOLO_EINVAL;
+  const int grid = grid_for((int64_t)n * (h / 2) * (w / 2), 256, 4096);
+  hipStream_t st = (hipStream_t)stream;
+#define LAUNCH(S, D) hipLaunchKernelGGL((focus_pack_kernel<S, D>), dim3(grid), dim3(256), 0, st, (const S*)img, n, h, w, mul, *out)
+  const int dd = out->dtype;
+  if (src_dtype == MYOLO_F32 && dd == MYOLO_F16) LAUNCH(float, half_t);
+  else if (src_dtype == MYOLO_F32 && dd == MYOLO_F32) LAUNCH(float, float);
+  else if (src_dtype == MYOLO_F16 && dd == MYOLO_F16) LAUNCH(half_t, half_t);
+  else if (src_dtype == MYOLO_F16 && dd == MYOLO_F32) LAUNCH(half_t, float);
+  else if (src_dtype == MYOLO_U8 && dd == MYOLO_F16) LAUNCH(uint8_t, half_t);
+  else if (src_dtype == MYOLO_U8 && dd == MYOLO_F32) LAUNCH(uint8_t, float);
+  else return MYOLO_EINVAL;
+#undef LAUNCH
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,580 @@
+// Pooling / resampling / glue kernels of the hot path (all HBM- or L2-bound, NHWC 16-byte vectors, fp32 math).
+//   SPP max pools k=5,9,13 stride 1 (reference models/common.py:170)        fwd (+first-max index) / bwd (gather)
+//   nearest 2x upsample or plain copy into a concat slice (yaml:31,36; common.py:589)
+//   bilinear align_corners=True resize (models/yolo.py:57..174, common.py:534-537)  fwd / bwd (gather form, no atomics)
+//   AdaptiveAvgPool2d(k) (common.py:521-524,214)                               fwd / bwd
+//   FFM gate feat*att+feat (common.py:228-229)                                 fwd / bwd
+#include "myolo_dev.h"
+
+namespace {
+
+inline bool vec_ok(const myolo_tensor* t) {
+  const int seg = t->dtype == MYOLO_F16 ? 8 : 4;
+  return t && t->ptr && (t->dtype == MYOLO_F16 || t->dtype == MYOLO_F32) && t->c % seg == 0 && t->sw % seg == 0 &&
+         t->sh % seg == 0 && t->sn % seg == 0 && ((uintptr_t)t->ptr & 15) == 0;
+}
+
+// decode vector index -> (n, y, x, cg) for a tensor with G channel groups
+__device__ __forceinline__ void dec(int64_t v, int G, int W, int H, int& n, int& y, int& x, int& cg) {
+  cg = (int)(v % G); v /= G;
+  x = (int)(v % W); v /= W;
+  y = (int)(v % H);
+  n = (int)(v / H);
+}
+
+#define GRID_STRIDE(v, total) \
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < (total); v += (int64_t)gridDim.x * blockDim.x)
+
+// ---------------------------------------------------------------- SPP max pools
+template <typename T, bool IDX>
+__global__ __launch_bounds__(256) void spp_fwd_kernel(myolo_tensor x, myolo_tensor o5, myolo_tensor o9, myolo_tensor o13,
+                                                      uint8_t* idx) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = x.c / SEG;
+  const int64_t total = (int64_t)x.n * x.h * x.w * G;
+  const int64_t plane = (int64_t)x.n * x.h * x.w * x.c;   // idx plane size per pool
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, x.w, x.h, n, y, xx, cg);
+    float m5[SEG], m9[SEG], m13[SEG];
+    int i5[SEG], i9[SEG], i13[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { m5[i] = m9[i] = m13[i] = -INFINITY; i5[i] = i9[i] = i13[i] = 0; }
+    // row-major scan of the 13x13 window; strict '>' keeps the first maximum (ATen max_pool2d semantics)
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int iy = y + dy;
+      if (iy < 0 || iy >= x.h) continue;
+      for (int dx = -6; dx <= 6; ++dx) {
+        const int ix = xx + dx;
+        if (ix < 0 || ix >= x.w) continue;
+        float f[SEG];
+        Vec<T>::unpack(ldg16(vptr<T>(x, n, iy, ix) + cg * SEG), f);
+        const bool in9 = dy >= -4 && dy <= 4 && dx >= -4 && dx <= 4;
+        const bool in5 = dy >= -2 && dy <= 2 && dx >= -2 && dx <= 2;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          if (f[i] > m13[i]) { m13[i] = f[i]; i13[i] = (dy + 6) * 13 + dx + 6; }
+          if (in9 && f[i] > m9[i]) { m9[i] = f[i]; i9[i] = (dy + 4) * 9 + dx + 4; }
+          if (in5 && f[i] > m5[i]) { m5[i] = f[i]; i5[i] = (dy + 2) * 5 + dx + 2; }
+        }
+      }
+    }
+    stg16(vptr<T>(o5, n, y, xx) + cg * SEG, Vec<T>::pack(m5));
+    stg16(vptr<T>(o9, n, y, xx) + cg * SEG, Vec<T>::pack(m9));
+    stg16(vptr<T>(o13, n, y, xx) + cg * SEG, Vec<T>::pack(m13));
+    if (IDX) {
+      const int64_t e = (((int64_t)n * x.h + y) * x.w + xx) * x.c + cg * SEG;
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        idx[e + i] = (uint8_t)i5[i];
+        idx[plane + e + i] = (uint8_t)i9[i];
+        idx[2 * plane + e + i] = (uint8_t)i13[i];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void spp_bwd_kernel(myolo_tensor g5, myolo_tensor g9, myolo_tensor g13,
+                                                      const uint8_t* __restrict__ idx, myolo_tensor gx, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = gx.c / SEG;
+  const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+  const int64_t plane = (int64_t)gx.n * gx.h * gx.w * gx.c;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+    // output (oy,ox) selected input (y,xx) iff its recorded window offset equals (y-oy+r, xx-ox+r)
+    for (int dy = -6; dy <= 6; ++dy) {
+      const int oy = y + dy;
+      if (oy < 0 || oy >= gx.h) continue;
+      for (int dx = -6; dx <= 6; ++dx) {
+        const int ox = xx + dx;
+        if (ox < 0 || ox >= gx.w) continue;
+        const int64_t e = (((int64_t)n * gx.h + oy) * gx.w + ox) * gx.c + cg * SEG;
+        {
+          float f[SEG];
+          Vec<T>::unpack(ldg16(vptr<T>(g13, n, oy, ox) + cg * SEG), f);
+          const int want = (6 - dy) * 13 + (6 - dx);
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) if (idx[2 * plane + e + i] == want) a[i] += f[i];
+        }
+        if (dy >= -4 && dy <= 4 && dx >= -4 && dx <= 4) {
+          float f[SEG];
+          Vec<T>::unpack(ldg16(vptr<T>(g9, n, oy, ox) + cg * SEG), f);
+          const int want = (4 - dy) * 9 + (4 - dx);
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) if (idx[plane + e + i] == want) a[i] += f[i];
+        }
+        if (dy >= -2 && dy <= 2 && dx >= -2 && dx <= 2) {
+          float f[SEG];
+          Vec<T>::unpack(ldg16(vptr<T>(g5, n, oy, ox) + cg * SEG), f);
+          const int want = (2 - dy) * 5 + (2 - dx);
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) if (idx[e + i] == want) a[i] += f[i];
+        }
+      }
+    }
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
+// ---------------------------------------------------------------- copy / nearest upsample
+template <typename T>
+__global__ __launch_bounds__(256) void copy_up_fwd_kernel(myolo_tensor x, myolo_tensor out, int shift) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = out.c / SEG;
+  const int64_t total = (int64_t)out.n * out.h * out.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, out.w, out.h, n, y, xx, cg);
+    stg16(vptr<T>(out, n, y, xx) + cg * SEG, ldg16(vptr<T>(x, n, y >> shift, xx >> shift) + cg * SEG));
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void copy_up_bwd_kernel(myolo_tensor gout, myolo_tensor gx, int shift, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = gx.c / SEG;
+  const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+  const int r = 1 << shift;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+    for (int dy = 0; dy < r; ++dy)
+      for (int dx = 0; dx < r; ++dx) {
+        float f[SEG];
+        Vec<T>::unpack(ldg16(vptr<T>(gout, n, y * r + dy, xx * r + dx) + cg * SEG), f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += f[i];
+      }
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
+// ---------------------------------------------------------------- bilinear (align_corners=True)
+// ATen upsample_bilinear2d: scale = (in-1)/(out-1) (0 if out==1); src = scale*dst; i0 = floor(src); i1 = min(i0+1,in-1);
+// lambda1 = src - i0.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(myolo_tensor x, myolo_tensor out, float sy, float sx) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = out.c / SEG;
+  const int64_t total = (int64_t)out.n * out.h * out.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, out.w, out.h, n, y, xx, cg);
+    const float fy = sy * (float)y, fx = sx * (float)xx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < x.h ? y0 + 1 : x.h - 1, x1 = x0 + 1 < x.w ? x0 + 1 : x.w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    float a[SEG], b[SEG], c[SEG], d[SEG], o[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y0, x0) + cg * SEG), a);
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y0, x1) + cg * SEG), b);
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y1, x0) + cg * SEG), c);
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y1, x1) + cg * SEG), d);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i)
+      o[i] = (1.f - ly) * ((1.f - lx) * a[i] + lx * b[i]) + ly * ((1.f - lx) * c[i] + lx * d[i]);
+    stg16(vptr<T>(out, n, y, xx) + cg * SEG, Vec<T>::pack(o));
+  }
+}
+
+// gather form of the transpose: input pixel (iy,ix) collects every output whose 2x2 footprint touches it
+__device__ __forceinline__ void out_range(int i, int in, int out, float s, int& lo, int& hi) {
+  // outputs o with floor(s*o) in {i-1, i}  (i1 = i0+1 may equal i);  conservative bounds, exact test inside
+  if (out == 1 || in == 1 || s <= 0.f) { lo = 0; hi = out - 1; return; }
+  float a = ((float)i - 1.f) / s, b = ((float)i + 1.f) / s;
+  lo = (int)floorf(a) - 1; hi = (int)ceilf(b) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(myolo_tensor gout, myolo_tensor gx, float sy, float sx, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = gx.c / SEG;
+  const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    int ylo, yhi, xlo, xhi;
+    out_range(y, gx.h, gout.h, sy, ylo, yhi);
+    out_range(xx, gx.w, gout.w, sx, xlo, xhi);
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float fy = sy * (float)oy;
+      const int y0 = (int)fy;
+      const int y1 = y0 + 1 < gx.h ? y0 + 1 : gx.h - 1;
+      const float ly = fy - (float)y0;
+      float wy = 0.f;
+      if (y0 == y) wy += 1.f - ly;
+      if (y1 == y) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float fx = sx * (float)ox;
+        const int x0 = (int)fx;
+        const int x1 = x0 + 1 < gx.w ? x0 + 1 : gx.w - 1;
+        const float lx = fx - (float)x0;
+        float wx = 0.f;
+        if (x0 == xx) wx += 1.f - lx;
+        if (x1 == xx) wx += lx;
+        if (wx == 0.f) continue;
+        float f[SEG];
+        Vec<T>::unpack(ldg16(vptr<T>(gout, n, oy, ox) + cg * SEG), f);
+        const float wgt = wy * wx;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += wgt * f[i];
+      }
+    }
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
+// ---------------------------------------------------------------- adaptive average pool
+// bin i of k over H: [floor(i*H/k), ceil((i+1)*H/k))
+template <typename T>
+__global__ __launch_bounds__(256) void aap_fwd_kernel(myolo_tensor x, myolo_tensor out) {
+  constexpr int SEG = ET<T>::SEG;
+  // one workgroup per (n, by, bx); threads = channel groups x pixel lanes
+  __shared__ float red[256 * 8];
+  const int G = x.c / SEG;
+  const int kb = out.h, kw = out.w;
+  int b = blockIdx.x;
+  const int bx = b % kw; b /= kw;
+  const int by = b % kb; const int n = b / kb;
+  const int y0 = (by * x.h) / kb, y1 = ((by + 1) * x.h + kb - 1) / kb;
+  const int x0 = (bx * x.w) / kw, x1 = ((bx + 1) * x.w + kw - 1) / kw;
+  const int bw = x1 - x0, npix = (y1 - y0) * bw;
+  for (int cg0 = 0; cg0 < G; cg0 += 256) {
+    const int gcount = (G - cg0) < 256 ? (G - cg0) : 256;
+    const int lanes = 256 / gcount;                    // pixel lanes per channel group
+    const int cg = cg0 + threadIdx.x % gcount, pl = threadIdx.x / gcount;
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+    if (pl < lanes)
+      for (int p = pl; p < npix; p += lanes) {
+        const int yy = y0 + p / bw, xx = x0 + p % bw;
+        float f[SEG];
+        Vec<T>::unpack(ldg16(vptr<T>(x, n, yy, xx) + cg * SEG), f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += f[i];
+      }
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) red[threadIdx.x * 8 + i] = a[i];
+    __syncthreads();
+    if (threadIdx.x < gcount) {
+      float s[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) s[i] = 0.f;
+      for (int q = 0; q < lanes; ++q)
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) s[i] += red[(q * gcount + threadIdx.x) * 8 + i];
+      const float inv = 1.f / (float)npix;
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) s[i] *= inv;
+      stg16(vptr<T>(out, n, by, bx) + (cg0 + threadIdx.x) * SEG, Vec<T>::pack(s));
+    }
+    __syncthreads();
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_tensor gx, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = gx.c / SEG;
+  const int kb = gout.h, kw = gout.w;
+  const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+    for (int by = 0; by < kb; ++by) {
+      const int y0 = (by * gx.h) / kb, y1 = ((by + 1) * gx.h + kb - 1) / kb;
+      if (y < y0 || y >= y1) continue;
+      for (int bx = 0; bx < kw; ++bx) {
+        const int x0 = (bx * gx.w) / kw, x1 = ((bx + 1) * gx.w + kw - 1) / kw;
+        if (xx < x0 || xx >= x1) continue;
+        float f[SEG];
+        Vec<T>::unpack(ldg16(vptr<T>(gout, n, by, bx) + cg * SEG), f);
+        const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += f[i] * inv;
+      }
+    }
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
+// ---------------------------------------------------------------- FFM gate
+template <typename T>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(myolo_tensor feat, myolo_tensor att, myolo_tensor out) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = feat.c / SEG;
+  const int64_t total = (int64_t)feat.n * feat.h * feat.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, feat.w, feat.h, n, y, xx, cg);
+    float f[SEG], a[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(feat, n, y, xx) + cg * SEG), f);
+    Vec<T>::unpack(ldg16(vptr<T>(att, n, 0, 0) + cg * SEG), a);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) f[i] = f[i] * a[i] + f[i];
+    stg16(vptr<T>(out, n, y, xx) + cg * SEG, Vec<T>::pack(f));
+  }
+}
+// gfeat (+)= g*(1+att);  gatt[n][c] += sum_pixels g*feat   (block-level partial sums, fp32 atomics)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(myolo_tensor gout, myolo_tensor feat, myolo_tensor att,
+                                                       myolo_tensor gfeat, int acc, float* gatt, int G, int PPB,
+                                                       int blocks_per_img) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float red[];  // [PPB][G*SEG]
+  const int n = blockIdx.x / blocks_per_img, bi = blockIdx.x % blocks_per_img;
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  const int HW = feat.h * feat.w;
+  float a[SEG], s[SEG];
+  Vec<T>::unpack(ldg16(vptr<T>(att, n, 0, 0) + cg * SEG), a);
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) s[i] = 0.f;
+  for (int p = bi * PPB + pl; p < HW; p += blocks_per_img * PPB) {
+    const int y = p / feat.w, xx = p - y * feat.w;
+    float g[SEG], f[SEG], o[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(gout, n, y, xx) + cg * SEG), g);
+    Vec<T>::unpack(ldg16(vptr<T>(feat, n, y, xx) + cg * SEG), f);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { s[i] += g[i] * f[i]; o[i] = g[i] * (1.f + a[i]); }
+    T* gp = vptr<T>(gfeat, n, y, xx) + cg * SEG;
+    if (acc) {
+      float q[SEG];
+      Vec<T>::unpack(ldg16(gp), q);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) o[i] += q[i];
+    }
+    stg16(gp, Vec<T>::pack(o));
+  }
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) red[(size_t)pl * G * SEG + cg * SEG + i] = s[i];
+  __syncthreads();
+  for (int j = threadIdx.x; j < G * SEG; j += blockDim.x) {
+    float t = 0.f;
+    for (int q = 0; q < PPB; ++q) t += red[(size_t)q * G * SEG + j];
+    atomicAdd(gatt + (size_t)n * G * SEG + j, t);
+  }
+}
+
+// ---------------------------------------------------------------- add / zero / cast
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(myolo_tensor a, myolo_tensor out, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = out.c / SEG;
+  const int64_t total = (int64_t)out.n * out.h * out.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, out.w, out.h, n, y, xx, cg);
+    uint4 va = ldg16(vptr<T>(a, n, y, xx) + cg * SEG);
+    T* op = vptr<T>(out, n, y, xx) + cg * SEG;
+    if (acc) {
+      float f[SEG], g[SEG];
+      Vec<T>::unpack(va, f);
+      Vec<T>::unpack(ldg16(op), g);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) f[i] += g[i];
+      va = Vec<T>::pack(f);
+    }
+    stg16(op, va);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void zero_kernel(myolo_tensor t) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = t.c / SEG;
+  const int64_t total = (int64_t)t.n * t.h * t.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, t.w, t.h, n, y, xx, cg);
+    stg16(vptr<T>(t, n, y, xx) + cg * SEG, uint4{0u, 0u, 0u, 0u});
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src, myolo_tensor out) {
+  const int64_t total = (int64_t)out.n * out.h * out.w * out.c;
+  GRID_STRIDE(v, total) {
+    int64_t r = v;
+    const int c = (int)(r % out.c); r /= out.c;
+    const int x = (int)(r % out.w); r /= out.w;
+    const int y = (int)(r % out.h);
+    const int n = (int)(r / out.h);
+    vptr<T>(out, n, y, x)[c] = (T)src[v];
+  }
+}
+
+inline int64_t nvec(const myolo_tensor* t) {
+  return (int64_t)t->n * t->h * t->w * (t->c / (t->dtype == MYOLO_F16 ? 8 : 4));
+}
+inline bool same_nc(const myolo_tensor* a, const myolo_tensor* b) {
+  return a->n == b->n && a->c == b->c && a->dtype == b->dtype;
+}
+inline bool same_shape(const myolo_tensor* a, const myolo_tensor* b) {
+  return same_nc(a, b) && a->h == b->h && a->w == b->w;
+}
+
+#define DISPATCH(dtype, KERN, grid, block, smem, st, ...)                                        \
+  do {                                                                                            \
+    if ((dtype) == MYOLO_F16) hipLaunchKernelGGL(KERN<half_t>, dim3(grid), dim3(block), smem, st, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERN<float>, dim3(grid), dim3(block), smem, st, __VA_ARGS__);        \
+    MYOLO_CHECK_LAUNCH();                                                                         \
+  } while (0)
+
+}  // namespace
+
+extern "C" int myolo_spp_pool_fwd(const myolo_tensor* x, const myolo_tensor* o5, const myolo_tensor* o9,
+                                  const myolo_tensor* o13, uint8_t* idx, void* stream) {
+  if (!vec_ok(x) || !vec_ok(o5) || !vec_ok(o9) || !vec_ok(o13) || !same_shape(x, o5) || !same_shape(x, o9) ||
+      !same_shape(x, o13))
+    return MYOLO_EINVAL;
+  const int grid = grid_for(nvec(x), 256, 8192);
+  hipStream_t st = (hipStream_t)stream;
+  if (x->dtype == MYOLO_F16) {
+    if (idx) hipLaunchKernelGGL((spp_fwd_kernel<half_t, true>), dim3(grid), dim3(256), 0, st, *x, *o5, *o9, *o13, idx);
+    else hipLaunchKernelGGL((spp_fwd_kernel<half_t, false>), dim3(grid), dim3(256), 0, st, *x, *o5, *o9, *o13, idx);
+  } else {
+    if (idx) hipLaunchKernelGGL((spp_fwd_kernel<float, true>), dim3(grid), dim3(256), 0, st, *x, *o5, *o9, *o13, idx);
+    else hipLaunchKernelGGL((spp_fwd_kernel<float, false>), dim3(grid), dim3(256), 0, st, *x, *o5, *o9, *o13, idx);
+  }
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_spp_pool_bwd(const myolo_tensor* g5, const myolo_tensor* g9, const myolo_tensor* g13,
+                                  const uint8_t* idx, const myolo_tensor* gx, int accumulate, void* stream) {
+  if (!vec_ok(gx) || !vec_ok(g5) || !vec_ok(g9) || !vec_ok(g13) || !idx || !same_shape(gx, g5) ||
+      !same_shape(gx, g9) || !same_shape(gx, g13))
+    return MYOLO_EINVAL;
+  DISPATCH(gx->dtype, spp_bwd_kernel, grid_for(nvec(gx), 256, 8192), 256, 0, (hipStream_t)stream, *g5, *g9, *g13, idx,
+           *gx, accumulate);
+  return 0;
+}
+extern "C" int myolo_copy_up_fwd(const myolo_tensor* x, const myolo_tensor* out, int scale, void* stream) {
+  if (!vec_ok(x) || !vec_ok(out) || !same_nc(x, out) || (scale != 1 && scale != 2) || out->h != x->h * scale ||
+      out->w != x->w * scale)
+    return MYOLO_EINVAL;
+  DISPATCH(out->dtype, copy_up_fwd_kernel, grid_for(nvec(out), 256), 256, 0, (hipStream_t)stream, *x, *out,
+           scale == 2 ? 1 : 0);
+  return 0;
+}
+extern "C" int myolo_copy_up_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int scale, int accumulate,
+                                 void* stream) {
+  if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout) || (scale != 1 && scale != 2) || gout->h != gx->h * scale ||
+      gout->w != gx->w * scale)
+    return MYOLO_EINVAL;
+  DISPATCH(gx->dtype, copy_up_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx,
+           scale == 2 ? 1 : 0, accumulate);
+  return 0;
+}
+static inline float ac_scale(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
+extern "C" int myolo_bilinear_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream) {
+  if (!vec_ok(x) || !vec_ok(out) || !same_nc(x, out)) return MYOLO_EINVAL;
+  DISPATCH(out->dtype, bilinear_fwd_kernel, grid_for(nvec(out), 256), 256, 0, (hipStream_t)stream, *x, *out,
+           ac_scale(x->h, out->h), ac_scale(x->w, out->w));
+  return 0;
+}
+extern "C" int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream) {
+  if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
+  DISPATCH(gx->dtype, bilinear_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx,
+           ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), accumulate);
+  return 0;
+}
+extern "C" int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream) {
+  if (!vec_ok(x) || !vec_ok(out) || !same_nc(x, out) || out->h > x->h || out->w > x->w) return MYOLO_EINVAL;
+  DISPATCH(x->dtype, aap_fwd_kernel, out->n * out->h * out->w, 256, 0, (hipStream_t)stream, *x, *out);
+  return 0;
+}
+extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate,
+                                          void* stream) {
+  if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
+  DISPATCH(gx->dtype, aap_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx, accumulate);
+  return 0;
+}
+extern "C" int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out,
+                              void* stream) {
+  if (!vec_ok(feat) || !vec_ok(att) || !vec_ok(out) || !same_shape(feat, out) || !same_nc(feat, att) || att->h != 1 ||
+      att->w != 1)
+    return MYOLO_EINVAL;
+  DISPATCH(feat->dtype, gate_fwd_kernel, grid_for(nvec(feat), 256), 256, 0, (hipStream_t)stream, *feat, *att, *out);
+  return 0;
+}
+extern "C" int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
+                              const myolo_tensor* gfeat, int accumulate, float* gatt, void* stream) {
+  if (!vec_ok(gout) || !vec_ok(feat) || !vec_ok(att) || !vec_ok(gfeat) || !gatt || !same_shape(gout, feat) ||
+      !same_shape(gfeat, feat) || !same_nc(feat, att))
+    return MYOLO_EINVAL;
+  const int seg = feat->dtype == MYOLO_F16 ? 8 : 4;
+  const int G = feat->c / seg;
+  if (G > 256) return MYOLO_EINVAL;
+  const int PPB = 256 / G;
+  const int HW = feat->h * feat->w;
+  int bpi = (HW + PPB * 16 - 1) / (PPB * 16);
+  if (bpi > 128) bpi = 128;
+  if (bpi < 1) bpi = 1;
+  const size_t smem = (size_t)PPB * G * seg * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (feat->dtype == MYOLO_F16)
+    hipLaunchKernelGGL(gate_bwd_kernel<half_t>, dim3(feat->n * bpi), dim3(G * PPB), smem, st, *gout, *feat, *att, *gfeat,
+                       accumulate, gatt, G, PPB, bpi);
+  else
+    hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(feat->n * bpi), dim3(G * PPB), smem, st, *gout, *feat, *att, *gfeat,
+                       accumulate, gatt, G, PPB, bpi);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_add(const myolo_tensor* a, const myolo_tensor* out, int accumulate, void* stream) {
+  if (!vec_ok(a) || !vec_ok(out) || !same_shape(a, out)) return MYOLO_EINVAL;
+  DISPATCH(out->dtype, add_kernel, grid_for(nvec(out), 256), 256, 0, (hipStream_t)stream, *a, *out, accumulate);
+  return 0;
+}
+extern "C" int myolo_fill_zero(const myolo_tensor* t, void* stream) {
+  if (!vec_ok(t)) return MYOLO_EINVAL;
+  DISPATCH(t->dtype, zero_kernel, grid_for(nvec(t), 256), 256, 0, (hipStream_t)stream, *t);
+  return 0;
+}
+extern "C" int myolo_cast_from_f32(const float* src, const myolo_tensor* out, void* stream) {
+  if (!src || !out || !out->ptr) return MYOLO_EINVAL;
+  DISPATCH(out->dtype, cast_from_f32_kernel, grid_for((int64_t)out->n * out->h * out->w * out->c, 256), 256, 0,
+           (hipStream_t)stream, src, *out);
+  return 0;
+}

@@ -1,0 +1,210 @@
+// Output-side kernels of the segmentation / detection heads.
+//   seg_upsample fwd : low-res class logits [N,h,w,C] (NHWC view, C arbitrary) -> bilinear(align_corners=True)
+//                      -> strided [N,C,H,W]-logical tensor (reference models/yolo.py:163 nn.Upsample x8, detect.py:191)
+//   seg_upsample bwd : transpose of the above (gather form) into the (channel-padded) low-res gradient
+//   seg_argmax       : fused bilinear resize + per-pixel argmax over classes, writes only the label map
+//                      (detect.py:191-193 `F.interpolate(...)` then `seg.max(axis=0)[1]`; never materialises
+//                      the [19,H0,W0] logits)
+//   detect_unpermute : gradient of Detect's [N,na,ny,nx,no] output back to NHWC [N,ny,nx,na*no (padded)]
+//                      (autograd of yolo.py:214 view/permute)
+//   detect_decode    : eval-mode box decode of the three levels into [N, sum(na*ny*nx), no] (yolo.py:216-225)
+#include "myolo_dev.h"
+
+namespace {
+
+struct Strided4 {  // generic [N,C,H,W]-logical tensor, strides in elements
+  void* ptr; int64_t sn, sc, sh, sw; int dtype;
+};
+
+template <typename T> __device__ __forceinline__ float ld(const void* p, int64_t i) { return (float)((const T*)p)[i]; }
+__device__ __forceinline__ float ld_any(const void* p, int64_t i, int dt) {
+  return dt == MYOLO_F16 ? (float)((const half_t*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int64_t i, int dt, float v) {
+  if (dt == MYOLO_F16) ((half_t*)p)[i] = (half_t)v; else ((float*)p)[i] = v;
+}
+
+constexpr int MAXC = 32;   // classes handled per pixel in registers (n_segcls = 19)
+
+__global__ __launch_bounds__(256) void seg_up_fwd_kernel(myolo_tensor low, Strided4 out, int H, int W, float sy, float sx) {
+  const int C = low.c;
+  const int64_t total = (int64_t)low.n * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); const int y = (int)((i / W) % H); const int n = (int)(i / ((int64_t)W * H));
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < low.h ? y0 + 1 : low.h - 1, x1 = x0 + 1 < low.w ? x0 + 1 : low.w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const int64_t b00 = (int64_t)n * low.sn + (int64_t)y0 * low.sh + (int64_t)x0 * low.sw;
+    const int64_t b01 = (int64_t)n * low.sn + (int64_t)y0 * low.sh + (int64_t)x1 * low.sw;
+    const int64_t b10 = (int64_t)n * low.sn + (int64_t)y1 * low.sh + (int64_t)x0 * low.sw;
+    const int64_t b11 = (int64_t)n * low.sn + (int64_t)y1 * low.sh + (int64_t)x1 * low.sw;
+    const int64_t ob = (int64_t)n * out.sn + (int64_t)y * out.sh + (int64_t)x * out.sw;
+    for (int c = 0; c < C; ++c) {
+      const float a = ld_any(low.ptr, b00 + c, low.dtype), b = ld_any(low.ptr, b01 + c, low.dtype);
+      const float cc = ld_any(low.ptr, b10 + c, low.dtype), d = ld_any(low.ptr, b11 + c, low.dtype);
+      const float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+      st_any(out.ptr, ob + (int64_t)c * out.sc, out.dtype, v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void seg_argmax_kernel(myolo_tensor low, void* labels, int label_dtype, int H, int W,
+                                                         float sy, float sx) {
+  const int C = low.c;
+  const int64_t total = (int64_t)low.n * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % W); const int y = (int)((i / W) % H); const int n = (int)(i / ((int64_t)W * H));
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < low.h ? y0 + 1 : low.h - 1, x1 = x0 + 1 < low.w ? x0 + 1 : low.w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const int64_t b00 = (int64_t)n * low.sn + (int64_t)y0 * low.sh + (int64_t)x0 * low.sw;
+    const int64_t b01 = (int64_t)n * low.sn + (int64_t)y0 * low.sh + (int64_t)x1 * low.sw;
+    const int64_t b10 = (int64_t)n * low.sn + (int64_t)y1 * low.sh + (int64_t)x0 * low.sw;
+    const int64_t b11 = (int64_t)n * low.sn + (int64_t)y1 * low.sh + (int64_t)x1 * low.sw;
+    float best = -INFINITY; int arg = 0;
+    for (int c = 0; c < C; ++c) {
+      const float a = ld_any(low.ptr, b00 + c, low.dtype), b = ld_any(low.ptr, b01 + c, low.dtype);
+      const float cc = ld_any(low.ptr, b10 + c, low.dtype), d = ld_any(low.ptr, b11 + c, low.dtype);
+      float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+      if (low.dtype == MYOLO_F16) v = (float)(half_t)v;     // the reference materialises fp16 logits before max
+      if (v > best) { best = v; arg = c; }                   // first maximum wins (torch.max)
+    }
+    if (label_dtype == MYOLO_I64) ((int64_t*)labels)[i] = arg; else ((uint8_t*)labels)[i] = (uint8_t)arg;
+  }
+}
+
+__device__ __forceinline__ void out_range(int i, int in, int out, float s, int& lo, int& hi) {
+  if (out == 1 || in == 1 || s <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf(((float)i - 1.f) / s) - 1; hi = (int)ceilf(((float)i + 1.f) / s) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+// one thread per (n, iy, ix, c) of the low-res gradient
+__global__ __launch_bounds__(256) void seg_up_bwd_kernel(Strided4 g, int H, int W, myolo_tensor glow, float sy, float sx,
+                                                         int acc) {
+  const int C = glow.c;
+  const int64_t total = (int64_t)glow.n * glow.h * glow.w * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int c = (int)(r % C); r /= C;
+    const int ix = (int)(r % glow.w); r /= glow.w;
+    const int iy = (int)(r % glow.h); const int n = (int)(r / glow.h);
+    int ylo, yhi, xlo, xhi;
+    out_range(iy, glow.h, H, sy, ylo, yhi);
+    out_range(ix, glow.w, W, sx, xlo, xhi);
+    float a = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float fy = sy * (float)oy; const int y0 = (int)fy; const int y1 = y0 + 1 < glow.h ? y0 + 1 : glow.h - 1;
+      const float ly = fy - (float)y0;
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float fx = sx * (float)ox; const int x0 = (int)fx; const int x1 = x0 + 1 < glow.w ? x0 + 1 : glow.w - 1;
+        const float lx = fx - (float)x0;
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx == 0.f) continue;
+        a += wy * wx * ld_any(g.ptr, (int64_t)n * g.sn + (int64_t)c * g.sc + (int64_t)oy * g.sh + (int64_t)ox * g.sw, g.dtype);
+      }
+    }
+    const int64_t o = (int64_t)n * glow.sn + (int64_t)iy * glow.sh + (int64_t)ix * glow.sw + c;
+    if (acc) a += ld_any(glow.ptr, o, glow.dtype);
+    st_any(glow.ptr, o, glow.dtype, a);
+  }
+}
+
+// g: dense [N,na,ny,nx,no] (dtype gdt) -> out NHWC view [N,ny,nx,na*no] (padded channels untouched)
+__global__ __launch_bounds__(256) void detect_unpermute_kernel(const void* g, int gdt, int na, int no, myolo_tensor out) {
+  const int C = na * no;
+  const int64_t total = (int64_t)out.n * out.h * out.w * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int c = (int)(r % C); r /= C;
+    const int x = (int)(r % out.w); r /= out.w;
+    const int y = (int)(r % out.h); const int n = (int)(r / out.h);
+    const int a = c / no, o = c - a * no;
+    const float v = ld_any(g, ((((int64_t)n * na + a) * out.h + y) * out.w + x) * no + o, gdt);
+    st_any(out.ptr, (int64_t)n * out.sn + (int64_t)y * out.sh + (int64_t)x * out.sw + c, out.dtype, v);
+  }
+}
+
+// raw: dense [N,na,ny,nx,no]; z: dense [N, A_total, no], rows [row0, row0+na*ny*nx) of each image, order (a,y,x)
+__global__ __launch_bounds__(256) void detect_decode_kernel(const void* raw, int dt, int N, int na, int ny, int nx, int no,
+                                                            float stride, float aw0, float ah0, float aw1, float ah1,
+                                                            float aw2, float ah2, void* z, int64_t a_total, int64_t row0) {
+  const int64_t per_img = (int64_t)na * ny * nx;
+  const int64_t total = (int64_t)N * per_img;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / per_img); const int64_t r = i - (int64_t)n * per_img;
+    const int a = (int)(r / ((int64_t)ny * nx)); const int rem = (int)(r - (int64_t)a * ny * nx);
+    const int y = rem / nx, x = rem - y * nx;
+    const float aw = a == 0 ? aw0 : (a == 1 ? aw1 : aw2), ah = a == 0 ? ah0 : (a == 1 ? ah1 : ah2);
+    const int64_t src = i * no;
+    const int64_t dst = ((int64_t)n * a_total + row0 + r) * no;
+    for (int o = 0; o < no; ++o) {
+      float s = sigmoid_f(ld_any(raw, src + o, dt));
+      if (dt == MYOLO_F16) s = (float)(half_t)s;          // reference: y = x.sigmoid() materialised in fp16
+      float v;
+      if (o == 0) v = (s * 2.f - 0.5f + (float)x) * stride;
+      else if (o == 1) v = (s * 2.f - 0.5f + (float)y) * stride;
+      else if (o == 2) v = (s * 2.f) * (s * 2.f) * aw;
+      else if (o == 3) v = (s * 2.f) * (s * 2.f) * ah;
+      else v = s;
+      st_any(z, dst + o, dt, v);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int myolo_seg_upsample_fwd(const myolo_tensor* low, void* out, int out_dtype, int H, int W, int64_t sn,
+                                      int64_t sc, int64_t sh, int64_t sw, void* stream) {
+  if (!low || !low->ptr || !out || H < 1 || W < 1) return MYOLO_EINVAL;
+  Strided4 o{out, sn, sc, sh, sw, out_dtype};
+  const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
+  hipLaunchKernelGGL(seg_up_fwd_kernel, dim3(grid_for((int64_t)low->n * H * W, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, *low, o, H, W, sy, sx);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, int64_t sn, int64_t sc, int64_t sh,
+                                      int64_t sw, const myolo_tensor* glow, int accumulate, void* stream) {
+  if (!glow || !glow->ptr || !g) return MYOLO_EINVAL;
+  Strided4 gg{const_cast<void*>(g), sn, sc, sh, sw, g_dtype};
+  const float sy = H > 1 ? (float)(glow->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(glow->w - 1) / (float)(W - 1) : 0.f;
+  hipLaunchKernelGGL(seg_up_bwd_kernel, dim3(grid_for((int64_t)glow->n * glow->h * glow->w * glow->c, 256, 8192)), dim3(256),
+                     0, (hipStream_t)stream, gg, H, W, *glow, sy, sx, accumulate);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_seg_argmax(const myolo_tensor* low, void* labels, int label_dtype, int H, int W, void* stream) {
+  if (!low || !low->ptr || !labels || (label_dtype != MYOLO_U8 && label_dtype != MYOLO_I64)) return MYOLO_EINVAL;
+  const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
+  hipLaunchKernelGGL(seg_argmax_kernel, dim3(grid_for((int64_t)low->n * H * W, 256, 8192)), dim3(256), 0,
+                     (hipStream_t)stream, *low, labels, label_dtype, H, W, sy, sx);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_detect_unpermute(const void* g, int g_dtype, int na, int no, const myolo_tensor* out, void* stream) {
+  if (!g || !out || !out->ptr || out->c < na * no) return MYOLO_EINVAL;
+  hipLaunchKernelGGL(detect_unpermute_kernel, dim3(grid_for((int64_t)out->n * out->h * out->w * na * no, 256)), dim3(256),
+                     0, (hipStream_t)stream, g, g_dtype, na, no, *out);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_detect_decode(const void* raw, int dtype, int n, int na, int ny, int nx, int no, float stride,
+                                   const float* anchor_wh_px /* host, na*2 */, void* z, int64_t a_total, int64_t row0,
+                                   void* stream) {
+  if (!raw || !z || !anchor_wh_px || na != 3) return MYOLO_EINVAL;
+  hipLaunchKernelGGL(detect_decode_kernel, dim3(grid_for((int64_t)n * na * ny * nx, 256)), dim3(256), 0,
+                     (hipStream_t)stream, raw, dtype, n, na, ny, nx, no, stride, anchor_wh_px[0], anchor_wh_px[1],
+                     anchor_wh_px[2], anchor_wh_px[3], anchor_wh_px[4], anchor_wh_px[5], z, a_total, row0);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -1,0 +1,806 @@
+"""Static launch plans over libmyolo (the host side of the MI355X hot path).
+
+A reference module (`Conv`, `C3`, `SegMaskPSP`, ... `Model`) does not call ATen: its `emit()` appends kernel
+launches to a `Plan` -- NHWC buffers laid out once (concat-free: producers write channel slices of the
+consumer's buffer), weights pre-packed for MFMA, forward and backward launch lists fixed at build time.
+Running a plan is a flat loop of C-ABI calls on the current HIP stream, so a whole training step is
+hipGraph-capturable (torch.cuda.graph == hipGraph on ROCm).  There is no CPU path.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import Tensor as CT
+
+SEG = {torch.float16: 8, torch.float32: 4}
+KC = {torch.float16: 32, torch.float32: 16}
+
+
+def rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Buf:
+    """One NHWC allocation [n,h,w,c] (+ an optional gradient twin with the same geometry)."""
+
+    def __init__(self, n, h, w, c, dtype):
+        self.n, self.h, self.w, self.c, self.dtype = n, h, w, c, dtype
+        self.t = None
+        self.g = None
+        self.gwritten = []      # list of (c0, c1) ranges of the gradient twin already written this backward
+
+    def alloc(self, device, with_grad):
+        if self.t is None:
+            self.t = torch.zeros(self.n, self.h, self.w, self.c, dtype=self.dtype, device=device)
+        if with_grad and self.g is None:
+            self.g = torch.zeros(self.n, self.h, self.w, self.c, dtype=self.dtype, device=device)
+
+
+class TV:
+    """Tensor view: channel slice [coff, coff+c) of a Buf.  `buf` may be unset until a concat claims it."""
+
+    def __init__(self, plan, n, h, w, c, requires_grad=True):
+        self.plan, self.n, self.h, self.w, self.c = plan, n, h, w, c
+        self.buf, self.coff = None, 0
+        self.requires_grad = requires_grad
+
+    @property
+    def shape(self):
+        return (self.n, self.h, self.w, self.c)
+
+    def place(self, buf, coff):
+        assert self.buf is None
+        self.buf, self.coff = buf, coff
+
+    def desc(self, grad=False, c=None, pad_to=None):
+        b = self.buf
+        t = b.g if grad else b.t
+        cc = self.c if c is None else c
+        if pad_to:
+            cc = min(rup(cc, pad_to), b.c - self.coff)
+        es = t.element_size()
+        return CT(t.data_ptr() + self.coff * es, b.n, b.h, b.w, cc, b.h * b.w * b.c, b.w * b.c, b.c,
+                  L.DT[b.dtype], 0)
+
+    def torch_view(self, grad=False):
+        t = self.buf.g if grad else self.buf.t
+        return t[..., self.coff:self.coff + self.c]
+
+
+def null_tensor():
+    return CT(None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
+
+
+class Call:
+    """One C-ABI launch: function + argument tuple (stream appended at run time)."""
+    __slots__ = ('fn', 'args', 'name', 'keep')
+
+    def __init__(self, name, args, keep=None):
+        self.fn = getattr(L.lib(), name)
+        self.name, self.args, self.keep = name, args, keep
+
+    def __call__(self, st):
+        e = self.fn(*self.args, st)
+        if e:
+            L.check(e, self.name)
+
+
+class Op:
+    def build(self, plan):      # create Calls (buffers are allocated)
+        self.fwd_calls, self.bwd_calls, self.prep_calls = [], [], []
+
+    def plan_bwd(self, plan):   # decide accumulate flags; called in reverse op order before build()
+        pass
+
+
+def claim(tv):
+    """Gradient write planning for tv: returns (accumulate_flag, [zero-fill TV ranges needed first])."""
+    b = tv.buf
+    lo, hi = tv.coff, tv.coff + tv.c
+    covered = [(a, z) for a, z in b.gwritten if a < hi and z > lo]
+    if not covered:
+        b.gwritten.append((lo, hi))
+        return 0, []
+    # fully covered?
+    pts = sorted(covered)
+    cur, gaps = lo, []
+    for a, z in pts:
+        if a > cur:
+            gaps.append((cur, min(a, hi)))
+        cur = max(cur, z)
+    if cur < hi:
+        gaps.append((cur, hi))
+    b.gwritten.append((lo, hi))
+    return 1, gaps
+
+
+def taps_fwd(k, d, pad):
+    dy, dx, tw = [], [], []
+    for kh in range(k):
+        for kw in range(k):
+            dy.append(kh * d - pad)
+            dx.append(kw * d - pad)
+            tw.append(kh * k + kw)
+    return dy, dx, tw
+
+
+def taps_dgrad(k, d, pad, s, py, px):
+    """taps of dx[(s*oy'+py),(s*ox'+px)] = sum dy[oy'+off] W^T ; only taps with (p + pad - k*d) % s == 0."""
+    dy, dx, tw = [], [], []
+    for kh in range(k):
+        ny = py + pad - kh * d
+        if ny % s:
+            continue
+        for kw in range(k):
+            nx = px + pad - kw * d
+            if nx % s:
+                continue
+            dy.append(ny // s)
+            dx.append(nx // s)
+            tw.append(kh * k + kw)
+    return dy, dx, tw
+
+
+def fill_taps(desc, dy, dx, tw=None):
+    for i in range(len(dy)):
+        desc.tap_dy[i] = dy[i]
+        desc.tap_dx[i] = dx[i]
+        if tw is not None:
+            desc.tap_w[i] = tw[i]
+
+
+class FocusPackOp(Op):
+    """common.py:550 -- space-to-depth of the NCHW image into NHWC16 (+cast)."""
+
+    def __init__(self, plan, img_slot, out, mul=1.0):
+        self.slot, self.out, self.mul = img_slot, out, mul
+
+    def build(self, plan):
+        super().build(plan)
+        meta = plan.in_meta[self.slot]
+        n, _, h, w = meta['shape']
+        self.d = self.out.desc()
+        self.fwd_calls.append(Call('myolo_focus_pack', (plan.in_ptr[self.slot], L.DT[meta['dtype']], n, h, w,
+                                                        C.c_float(self.mul), C.byref(self.d))))
+
+
+class ImportOp(Op):
+    """NCHW-logical torch tensor (any strides) -> NHWC TV (module-level boundary); bwd exports the gradient."""
+
+    def __init__(self, plan, slot, out):
+        self.slot, self.out = slot, out
+
+    def build(self, plan):
+        super().build(plan)
+        meta = plan.in_meta[self.slot]
+        n, c, h, w = meta['shape']
+        sn, sc, sh, sw = meta['stride']
+        self.d = self.out.desc()
+        self.fwd_calls.append(Call('myolo_seg_upsample_bwd', (plan.in_ptr[self.slot], L.DT[meta['dtype']], h, w, sn, sc, sh, sw,
+                                                              C.byref(self.d), 0)))
+        if plan.training and self.out.requires_grad:
+            g = torch.empty(n, c, h, w, dtype=meta['dtype'], device=plan.device)
+            plan.input_grads[self.slot] = g
+            self.gd = self.out.desc(grad=True)
+            gsn, gsc, gsh, gsw = g.stride()
+            self.bwd_calls.append(Call('myolo_seg_upsample_fwd', (C.byref(self.gd), L.ptr(g), L.DT[g.dtype], h, w,
+                                                                  gsn, gsc, gsh, gsw), keep=g))
+
+
+class ConvOp(Op):
+    """Conv2d (+BN) (+act) (+residual) / Detect conv; see include/myolo.h myolo_conv."""
+
+    def __init__(self, plan, x, out, weight, bn=None, bias=None, k=1, s=1, d=1, act=L.ACT_NONE, res=None, det=None):
+        self.x, self.out, self.weight, self.bn, self.bias = x, out, weight, bn, bias
+        self.k, self.s, self.d, self.act, self.res, self.det = k, s, d, act, res, det
+        self.pad = d * (k // 2)
+        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.acc_x = 0
+        self.zero_first = []
+        self.res_acc = 0
+
+    def plan_bwd(self, plan):
+        if self.res is not None and self.res.requires_grad:
+            self.res_acc, z = claim(self.res)
+            self.zero_first += [(self.res, a, b) for a, b in z]
+        if self.x.requires_grad:
+            self.acc_x, z = claim(self.x)
+            self.zero_first += [(self.x, a, b) for a, b in z]
+
+    def build(self, plan):
+        super().build(plan)
+        dt = plan.dtype
+        seg, kc = SEG[dt], KC[dt]
+        dev = plan.device
+        training = plan.training
+        has_bn = self.bn is not None
+        two_pass = training and (has_bn or self.act != L.ACT_NONE)
+        ntaps = self.k * self.k
+        cin_pad, cout_pad = rup(self.x.c, kc), rup(self.cout, 32)
+        self.wpack = torch.zeros(cout_pad, ntaps, cin_pad, dtype=dt, device=dev)
+        w = self.weight
+        pack = Call('myolo_pack_weight', (L.ptr(w), L.DT[w.dtype], self.cout, self.cin, self.k, self.k, L.ptr(self.wpack),
+                                          L.DT[dt], cout_pad, cin_pad, 0, None), keep=w)
+        (self.fwd_calls if training else self.prep_calls).append(pack)
+        d = L.ConvDesc()
+        d.x = self.x.desc()
+        d.w = self.wpack.data_ptr()
+        d.cin_pad, d.cout_pad, d.wtaps, d.ntaps, d.stride, d.up_shift = cin_pad, cout_pad, ntaps, ntaps, self.s, 0
+        fill_taps(d, *taps_fwd(self.k, self.d, self.pad))
+        d.res = null_tensor()
+        if two_pass:
+            self.yraw = Buf(self.out.n, self.out.h, self.out.w, self.cout, dt)
+            self.yraw.alloc(dev, False)
+            yv = TV(plan, *self.yraw.t.shape)
+            yv.place(self.yraw, 0)
+            self.yv = yv
+            d.y = yv.desc()
+            d.act = L.ACT_NONE
+            if has_bn:
+                self.stats = plan.f32_fwd_zero(2 * self.cout)
+                self.saved = torch.zeros(2 * self.cout, dtype=torch.float32, device=dev)
+                d.stats = self.stats.data_ptr()
+            self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
+            self.yd, self.od = yv.desc(), self.out.desc()
+            self.rd = self.res.desc() if self.res is not None else null_tensor()
+            bn = self.bn
+            if has_bn:
+                self.fwd_calls.append(Call('myolo_bn_act_fwd', (
+                    C.byref(self.yd), L.ptr(self.stats), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+                    L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), L.ptr(self.saved), C.c_float(bn.eps),
+                    C.c_float(bn.momentum), self.act, C.byref(self.rd), C.byref(self.od)), keep=bn))
+            else:
+                self.fwd_calls.append(Call('myolo_bn_act_fwd', (
+                    C.byref(self.yd), None, None, None, None, None, None, None, C.c_float(0), C.c_float(0), self.act,
+                    C.byref(self.rd), C.byref(self.od))))
+        else:
+            d.y = self.out.desc()
+            d.act = self.act
+            if self.det:   # Detect: the forward result goes to a dense [N,na,ny,nx,no] tensor (yolo.py:214)
+                o = self.out
+                self.det_out = torch.zeros(o.n, self.det[0], o.h, o.w, self.det[1], dtype=dt, device=dev)
+                d.y = CT(self.det_out.data_ptr(), o.n, o.h, o.w, self.cout, 0, 0, 0, L.DT[dt], 0)
+                d.det_no = self.det[1]
+            if self.res is not None:
+                d.res = self.res.desc()
+            if has_bn:       # eval: y = act(conv*scale + shift), scale/shift folded from running stats at prepare time
+                self.scale = torch.empty(self.cout, dtype=torch.float32, device=dev)
+                self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
+                d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
+            elif self.bias is not None:
+                if self.bias.dtype == torch.float32:
+                    d.shift = self.bias.data_ptr()        # read the live parameter: no stale copy under training
+                else:
+                    self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
+                    d.shift = self.shift.data_ptr()
+            self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
+        self.d = d
+        if training:
+            self._build_bwd(plan, two_pass, has_bn)
+
+    def prepare(self):
+        """(re)derive eval-mode epilogue constants from the parameters (host-side, once per weight version)."""
+        with torch.no_grad():
+            if hasattr(self, 'scale'):
+                bn = self.bn
+                sc = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                self.scale.copy_(sc)
+                self.shift.copy_(bn.bias.float() - bn.running_mean.float() * sc)
+            elif hasattr(self, 'shift'):
+                self.shift.copy_(self.bias.float())
+
+    def _build_bwd(self, plan, two_pass, has_bn):
+        dt, dev = plan.dtype, plan.device
+        seg, kc = SEG[dt], KC[dt]
+        calls = self.bwd_calls
+        for tv, a, b in self.zero_first:
+            z = TV(plan, tv.n, tv.h, tv.w, b - a)
+            z.place(tv.buf, a)
+            zd = z.desc(grad=True)
+            calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+        if two_pass:
+            self.dy = Buf(self.out.n, self.out.h, self.out.w, self.cout, dt)
+            self.dy.alloc(dev, False)
+            dyv = TV(plan, *self.dy.t.shape)
+            dyv.place(self.dy, 0)
+            self.god = self.out.desc(grad=True)
+            self.dyd = dyv.desc()
+            grd = self.res.desc(grad=True) if (self.res is not None and self.res.requires_grad) else null_tensor()
+            self.grd = grd
+            if has_bn:
+                bn = self.bn
+                self.dsum = plan.f32_bwd_zero(2 * self.cout)
+                calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
+                                                              L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
+                calls.append(Call('myolo_bn_act_bwd_apply', (
+                    C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
+                    L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
+                    C.byref(grd), self.res_acc)))
+            else:
+                calls.append(Call('myolo_bn_act_bwd_apply', (
+                    C.byref(self.god), C.byref(self.yd), None, None, None, self.act, None, None, None,
+                    C.byref(self.dyd), C.byref(grd), self.res_acc)))
+            dy_desc = dyv.desc()
+        else:
+            dy_desc = self.out.desc(grad=True, pad_to=seg)       # no BN, no act: dy is the output gradient itself
+            if self.det:
+                # the Detect output gradient arrives permuted [N,na,ny,nx,no]; un-permute into the NHWC twin first
+                self.gdet = torch.zeros(self.out.n, self.det[0], self.out.h, self.out.w, self.det[1], dtype=dt, device=dev)
+                plan.det_grads.append(self.gdet)
+                self.gdd = self.out.desc(grad=True)
+                calls.append(Call('myolo_detect_unpermute', (L.ptr(self.gdet), L.DT[dt], self.det[0], self.det[1],
+                                                             C.byref(self.gdd))))
+        self.dy_desc = dy_desc
+        # dgrad
+        if self.x.requires_grad:
+            cin_pad_t, cout_pad_t = rup(dy_desc.c, kc), rup(self.x.c, 32)
+            ntaps = self.k * self.k
+            self.wpack_t = torch.zeros(cout_pad_t, ntaps, cin_pad_t, dtype=dt, device=dev)
+            w = self.weight
+            self.fwd_calls.append(Call('myolo_pack_weight', (
+                L.ptr(w), L.DT[w.dtype], self.cout, self.cin, self.k, self.k, L.ptr(self.wpack_t), L.DT[dt], cout_pad_t,
+                cin_pad_t, 1, None), keep=w))
+            self.dg = []
+            s = self.s
+            gx_full = self.x.desc(grad=True)
+            es = 2 if dt == torch.float16 else 4
+            for py in range(s):
+                for px in range(s):
+                    tdy, tdx, tw = taps_dgrad(self.k, self.d, self.pad, s, py, px)
+                    hh, ww = (self.x.h - py + s - 1) // s, (self.x.w - px + s - 1) // s
+                    if hh <= 0 or ww <= 0:
+                        continue
+                    sub = CT(gx_full.ptr + (py * gx_full.sh + px * gx_full.sw) * es, gx_full.n, hh, ww, gx_full.c,
+                             gx_full.sn, gx_full.sh * s, gx_full.sw * s, gx_full.dtype, 0)
+                    if not tdy:
+                        if not self.acc_x:
+                            self.dg.append(sub)
+                            calls.append(Call('myolo_fill_zero', (C.byref(sub),)))
+                        continue
+                    g = L.ConvDesc()
+                    g.x, g.y, g.w = dy_desc, sub, self.wpack_t.data_ptr()
+                    g.cin_pad, g.cout_pad, g.wtaps, g.ntaps, g.stride, g.up_shift = cin_pad_t, cout_pad_t, ntaps, len(tdy), 1, 0
+                    fill_taps(g, tdy, tdx, tw)
+                    g.act, g.accumulate, g.res = L.ACT_NONE, self.acc_x, null_tensor()
+                    self.dg.append(g)
+                    calls.append(Call('myolo_conv', (C.byref(g),)))
+        # wgrad
+        wd = L.WgradDesc()
+        wd.x, wd.dy = self.x.desc(), dy_desc
+        wd.dw = plan.pgrad(self.weight).data_ptr()
+        wd.db = plan.pgrad(self.bias).data_ptr() if self.bias is not None else None
+        wd.ntaps, wd.stride, wd.up_shift, wd.ksplit, wd.cout, wd.cin = self.k * self.k, self.s, 0, 0, self.cout, self.cin
+        tdy, tdx, _ = taps_fwd(self.k, self.d, self.pad)
+        fill_taps(wd, tdy, tdx)
+        self.wd = wd
+        calls.append(Call('myolo_conv_wgrad', (C.byref(wd),)))
+
+
+class SimpleOp(Op):
+    """Ops with one fwd launch and one bwd launch that (accumulate-)writes the gradient of `src`."""
+
+    def __init__(self, plan, src, dst):
+        self.src, self.dst = src, dst
+        self.acc, self.zero_first = 0, []
+
+    def plan_bwd(self, plan):
+        if self.src.requires_grad:
+            self.acc, z = claim(self.src)
+            self.zero_first = [(self.src, a, b) for a, b in z]
+
+    def _zero_calls(self, plan):
+        out = []
+        for tv, a, b in self.zero_first:
+            z = TV(plan, tv.n, tv.h, tv.w, b - a)
+            z.place(tv.buf, a)
+            zd = z.desc(grad=True)
+            out.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+        return out
+
+    def build(self, plan):
+        super().build(plan)
+        self.sd, self.dd = self.src.desc(), self.dst.desc()
+        self.emit_fwd(plan)
+        if plan.training and self.src.requires_grad:
+            self.bwd_calls += self._zero_calls(plan)
+            self.gsd, self.gdd = self.src.desc(grad=True), self.dst.desc(grad=True)
+            self.emit_bwd(plan)
+
+
+class CopyUpOp(SimpleOp):
+    def __init__(self, plan, src, dst, scale):
+        super().__init__(plan, src, dst)
+        self.scale = scale
+
+    def emit_fwd(self, plan):
+        self.fwd_calls.append(Call('myolo_copy_up_fwd', (C.byref(self.sd), C.byref(self.dd), self.scale)))
+
+    def emit_bwd(self, plan):
+        self.bwd_calls.append(Call('myolo_copy_up_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.scale, self.acc)))
+
+
+class BilinearOp(SimpleOp):
+    def emit_fwd(self, plan):
+        self.fwd_calls.append(Call('myolo_bilinear_fwd', (C.byref(self.sd), C.byref(self.dd))))
+
+    def emit_bwd(self, plan):
+        self.bwd_calls.append(Call('myolo_bilinear_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc)))
+
+
+class AvgPoolOp(SimpleOp):
+    def emit_fwd(self, plan):
+        self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd', (C.byref(self.sd), C.byref(self.dd))))
+
+    def emit_bwd(self, plan):
+        self.bwd_calls.append(Call('myolo_adaptive_avgpool_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc)))
+
+
+class DropoutOp(SimpleOp):
+    """train-mode nn.Dropout(p) (yolo.py:65,140)."""
+
+    def __init__(self, plan, src, dst, p):
+        super().__init__(plan, src, dst)
+        self.p = p
+
+    def emit_fwd(self, plan):
+        s = self.src
+        self.mask = torch.zeros(s.n * s.h * s.w * s.c, dtype=torch.uint8, device=plan.device)
+        self.fwd_calls.append(Call('myolo_dropout_fwd', (C.byref(self.sd), C.byref(self.dd), L.ptr(self.mask), C.c_float(self.p),
+                                                         L.ptr(plan.rng_counter()))))
+
+    def emit_bwd(self, plan):
+        self.bwd_calls.append(Call('myolo_dropout_bwd', (C.byref(self.gdd), L.ptr(self.mask), C.byref(self.gsd), C.c_float(self.p),
+                                                         self.acc)))
+
+
+class AddOp(Op):
+    """out = a + b (BiSe `m16 + feat3`, yolo.py:84)."""
+
+    def __init__(self, plan, a, b, out):
+        self.a, self.b, self.out = a, b, out
+        self.acc = [0, 0]
+        self.zero_first = []
+
+    def plan_bwd(self, plan):
+        for i, tv in enumerate((self.a, self.b)):
+            if tv.requires_grad:
+                self.acc[i], z = claim(tv)
+                self.zero_first += [(tv, x, y) for x, y in z]
+
+    def build(self, plan):
+        super().build(plan)
+        self.ad, self.bd, self.od = self.a.desc(), self.b.desc(), self.out.desc()
+        self.fwd_calls.append(Call('myolo_add', (C.byref(self.ad), C.byref(self.od), 0)))
+        self.fwd_calls.append(Call('myolo_add', (C.byref(self.bd), C.byref(self.od), 1)))
+        if plan.training:
+            for tv, x, y in self.zero_first:
+                z = TV(plan, tv.n, tv.h, tv.w, y - x)
+                z.place(tv.buf, x)
+                zd = z.desc(grad=True)
+                self.bwd_calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+            self.god = self.out.desc(grad=True)
+            self.gds = []
+            for i, tv in enumerate((self.a, self.b)):
+                if tv.requires_grad:
+                    gd = tv.desc(grad=True)
+                    self.gds.append(gd)
+                    self.bwd_calls.append(Call('myolo_add', (C.byref(self.god), C.byref(gd), self.acc[i])))
+
+
+class SppPoolOp(Op):
+    """three stride-1 max pools of SPP (common.py:170); outputs are slices of the concat buffer."""
+
+    def __init__(self, plan, x, outs):
+        self.x, self.outs = x, outs
+        self.acc, self.zero_first = 0, []
+
+    def plan_bwd(self, plan):
+        if self.x.requires_grad:
+            self.acc, z = claim(self.x)
+            self.zero_first = [(self.x, a, b) for a, b in z]
+
+    def build(self, plan):
+        super().build(plan)
+        self.xd = self.x.desc()
+        self.ods = [o.desc() for o in self.outs]
+        idx = None
+        if plan.training:
+            self.idx = torch.zeros(3 * self.x.n * self.x.h * self.x.w * self.x.c, dtype=torch.uint8, device=plan.device)
+            idx = self.idx
+        self.fwd_calls.append(Call('myolo_spp_pool_fwd', (C.byref(self.xd), C.byref(self.ods[0]), C.byref(self.ods[1]),
+                                                          C.byref(self.ods[2]), L.ptr(idx))))
+        if plan.training and self.x.requires_grad:
+            for tv, a, b in self.zero_first:
+                z = TV(plan, tv.n, tv.h, tv.w, b - a)
+                z.place(tv.buf, a)
+                zd = z.desc(grad=True)
+                self.bwd_calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+            self.gds = [o.desc(grad=True) for o in self.outs]
+            self.gxd = self.x.desc(grad=True)
+            self.bwd_calls.append(Call('myolo_spp_pool_bwd', (C.byref(self.gds[0]), C.byref(self.gds[1]), C.byref(self.gds[2]),
+                                                              L.ptr(self.idx), C.byref(self.gxd), self.acc)))
+
+
+class GateOp(Op):
+    """FFM: out = feat*att + feat (common.py:228-229)."""
+
+    def __init__(self, plan, feat, att, out):
+        self.feat, self.att, self.out = feat, att, out
+        self.acc, self.zero_first, self.acc_att = 0, [], 0
+
+    def plan_bwd(self, plan):
+        self.acc, z = claim(self.feat)
+        self.zero_first = [(self.feat, a, b) for a, b in z]
+        self.acc_att, z2 = claim(self.att)
+        assert not z2 and not self.acc_att, 'attention vector has a single consumer'
+
+    def build(self, plan):
+        super().build(plan)
+        self.fd, self.ad, self.od = self.feat.desc(), self.att.desc(), self.out.desc()
+        self.fwd_calls.append(Call('myolo_gate_fwd', (C.byref(self.fd), C.byref(self.ad), C.byref(self.od))))
+        if plan.training:
+            for tv, a, b in self.zero_first:
+                z = TV(plan, tv.n, tv.h, tv.w, b - a)
+                z.place(tv.buf, a)
+                zd = z.desc(grad=True)
+                self.bwd_calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+            self.gatt = plan.f32_bwd_zero(self.att.n * self.att.c)
+            self.god, self.gfd, self.gad = self.out.desc(grad=True), self.feat.desc(grad=True), self.att.desc(grad=True)
+            self.bwd_calls.append(Call('myolo_gate_bwd', (C.byref(self.god), C.byref(self.fd), C.byref(self.ad),
+                                                          C.byref(self.gfd), self.acc, L.ptr(self.gatt))))
+            self.bwd_calls.append(Call('myolo_cast_from_f32', (L.ptr(self.gatt), C.byref(self.gad))))
+
+
+class SegOutOp(Op):
+    """final bilinear x`scale` of the class logits into a [N,C,H,W]-logical output tensor (yolo.py:163 etc.)."""
+
+    def __init__(self, plan, low, scale, slot):
+        self.low, self.scale, self.slot = low, scale, slot
+        self.acc = 0
+
+    def plan_bwd(self, plan):
+        self.acc, z = claim(self.low)
+        assert not z
+
+    def build(self, plan):
+        super().build(plan)
+        lw = self.low
+        H, W = lw.h * self.scale, lw.w * self.scale
+        store = torch.empty(lw.n, H, W, lw.c, dtype=plan.dtype, device=plan.device)
+        out = store.permute(0, 3, 1, 2)                 # [N,C,H,W] logical, NHWC memory
+        plan.outputs[self.slot] = out
+        self.ld = lw.desc()
+        sn, sc, sh, sw = out.stride()
+        self.fwd_calls.append(Call('myolo_seg_upsample_fwd', (C.byref(self.ld), L.ptr(out), L.DT[out.dtype], H, W, sn, sc, sh, sw),
+                                   keep=out))
+        if plan.training:
+            g = torch.zeros_like(store).permute(0, 3, 1, 2)
+            plan.output_grads[self.slot] = g
+            self.gld = lw.desc(grad=True)
+            self.bwd_calls.append(Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], H, W, *g.stride(), C.byref(self.gld),
+                                                                  self.acc), keep=g))
+
+
+class ExportOp(Op):
+    """NHWC TV -> NCHW-logical output tensor (module-level boundary)."""
+
+    def __init__(self, plan, src, slot):
+        self.src, self.slot, self.acc = src, slot, 0
+
+    def plan_bwd(self, plan):
+        self.acc, z = claim(self.src)
+        assert not z
+
+    def build(self, plan):
+        super().build(plan)
+        s = self.src
+        store = torch.empty(s.n, s.h, s.w, s.c, dtype=plan.dtype, device=plan.device)
+        out = store.permute(0, 3, 1, 2)
+        plan.outputs[self.slot] = out
+        self.sd = s.desc()
+        self.fwd_calls.append(Call('myolo_seg_upsample_fwd', (C.byref(self.sd), L.ptr(out), L.DT[out.dtype], s.h, s.w, *out.stride()),
+                                   keep=out))
+        if plan.training:
+            g = torch.zeros_like(store).permute(0, 3, 1, 2)
+            plan.output_grads[self.slot] = g
+            self.gsd = s.desc(grad=True)
+            self.bwd_calls.append(Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], s.h, s.w, *g.stride(), C.byref(self.gsd),
+                                                                  self.acc), keep=g))
+
+
+class Plan:
+    """A built forward (+backward) launch plan for one (module, input shapes, dtype, mode)."""
+
+    def __init__(self, device, dtype, training):
+        self.device, self.dtype, self.training = device, dtype, training
+        self.ops, self.bufs, self.tvs = [], [], []
+        self.in_meta, self.in_ptr = [], []          # per input slot: {'shape','stride','dtype'} / ctypes pointer cell
+        self.input_grads, self.outputs, self.output_grads = {}, {}, {}
+        self.det_grads = []
+        self.params, self._pgrad = [], {}
+        self.built = False
+
+    # ---- graph construction -------------------------------------------------------------------------
+    def new(self, n, h, w, c, requires_grad=True):
+        tv = TV(self, n, h, w, c, requires_grad)
+        self.tvs.append(tv)
+        return tv
+
+    def new_buf(self, n, h, w, c):
+        b = Buf(n, h, w, c, self.dtype)
+        self.bufs.append(b)
+        return b
+
+    def add(self, op):
+        self.ops.append(op)
+        return op
+
+    def add_input(self, t):
+        """declare an input tensor slot (shape/stride/dtype are part of the plan; the pointer is rebound per run)."""
+        self.in_meta.append({'shape': tuple(t.shape), 'stride': tuple(t.stride()), 'dtype': t.dtype})
+        self.in_ptr.append(C.c_void_p(0))
+        return len(self.in_meta) - 1
+
+    def cat(self, tvs):
+        """channel concat without a copy when the producer has not been placed yet (common.py:589)."""
+        n, h, w = tvs[0].n, tvs[0].h, tvs[0].w
+        ctot = sum(t.c for t in tvs)
+        b = self.new_buf(n, h, w, ctot)
+        off = 0
+        for t in tvs:
+            assert (t.n, t.h, t.w) == (n, h, w), 'concat of mismatched maps'
+            if t.buf is None:
+                t.place(b, off)
+            else:
+                dst = self.new(n, h, w, t.c, t.requires_grad)
+                dst.place(b, off)
+                self.add(CopyUpOp(self, t, dst, 1))
+            off += t.c
+        out = self.new(n, h, w, ctot, any(t.requires_grad for t in tvs))
+        out.place(b, 0)
+        return out
+
+    def _carve(self, which, n):
+        arena, used = self._arena[which], self._used[which]
+        n = rup(n, 64)
+        assert used + n <= arena.numel(), 'fp32 arena exhausted'
+        self._used[which] = used + n
+        return arena[used:used + n]
+
+    def f32_fwd_zero(self, n):
+        """fp32 scratch zeroed at the start of every forward (BN sum / sum-of-squares accumulators)."""
+        return self._carve(0, n)
+
+    def f32_bwd_zero(self, n):
+        """fp32 scratch zeroed at the start of every backward (BN backward sums, gate partials)."""
+        return self._carve(1, n)
+
+    def rng_counter(self):
+        if not hasattr(self, '_rng'):
+            self._rng = torch.randint(0, 2 ** 40, (1,), dtype=torch.int64, device=self.device)
+        return self._rng
+
+    def pgrad(self, p):
+        """fp32 gradient slot of a parameter inside the plan's flat gradient buffer."""
+        if p is None:
+            return None
+        return self._pgrad[id(p)]
+
+    # ---- build --------------------------------------------------------------------------------------
+    def register_params(self, params):
+        self.params = list(params)
+
+    def build(self):
+        dev = self.device
+        for tv in self.tvs:
+            if tv.buf is None:
+                b = self.new_buf(tv.n, tv.h, tv.w, rup(tv.c, SEG[self.dtype]))
+                tv.place(b, 0)
+        for b in self.bufs:
+            b.alloc(dev, self.training)
+        self._arena = [torch.zeros(1 << 18, dtype=torch.float32, device=dev) for _ in range(2)]
+        self._used = [0, 0]
+        if self.training:
+            tot = sum(p.numel() for p in self.params)
+            self.flat_grad = torch.zeros(tot, dtype=torch.float32, device=dev)
+            off = 0
+            for p in self.params:
+                self._pgrad[id(p)] = self.flat_grad[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            for b in self.bufs:
+                b.gwritten = []
+            for op in reversed(self.ops):
+                op.plan_bwd(self)
+        for op in self.ops:
+            op.build(self)
+        self.built = True
+        self.prepare()
+
+    def prepare(self):
+        st = L.stream_ptr()
+        for op in self.ops:
+            if hasattr(op, 'prepare'):
+                op.prepare()
+            for c in op.prep_calls:
+                c(st)
+
+    # ---- run ----------------------------------------------------------------------------------------
+    def run_fwd(self):
+        st = L.stream_ptr()
+        if self._used[0]:
+            self._arena[0][:self._used[0]].zero_()
+        for op in self.ops:
+            for c in op.fwd_calls:
+                c(st)
+
+    def run_bwd(self):
+        st = L.stream_ptr()
+        if self._used[1]:
+            self._arena[1][:self._used[1]].zero_()
+        if self.training:
+            self.flat_grad.zero_()
+        for op in reversed(self.ops):
+            for c in op.bwd_calls:
+                c(st)
+
+    def nbytes(self):
+        tot = 0
+        for b in self.bufs:
+            tot += b.t.numel() * b.t.element_size() * (2 if b.g is not None else 1)
+        return tot
+
+
+# ---------------------------------------------------------------------------------------------------------
+# output handles returned by module emit() functions besides plain TVs
+class ImageInput:
+    """the raw NCHW image fed to Focus (3 channels; consumed by FocusPackOp)."""
+
+    def __init__(self, slot, shape):
+        self.slot, self.shape = slot, shape
+
+
+class DetHandle:
+    """one Detect level in training layout [N,na,ny,nx,no] (yolo.py:214)."""
+
+    def __init__(self, conv_op):
+        self.op = conv_op
+
+
+class SegHandle:
+    """class logits (low-res TV) + the final bilinear scale (yolo.py:163): materialised by SegOutOp."""
+
+    def __init__(self, low, scale):
+        self.low, self.scale = low, scale
+
+
+class DecodeHandle:
+    """eval-mode Detect: (cat of decoded levels, [raw levels]) (yolo.py:225)."""
+
+    def __init__(self, det_handles, strides, anchor_grid):
+        self.dets, self.strides, self.anchor_grid = det_handles, strides, anchor_grid
+
+
+class DecodeOp(Op):
+    def __init__(self, plan, handle, slot):
+        self.h, self.slot = handle, slot
+
+    def build(self, plan):
+        super().build(plan)
+        convs = [d.op for d in self.h.dets]
+        n = convs[0].out.n
+        na, no = convs[0].det
+        rows = [na * c.out.h * c.out.w for c in convs]
+        a_total = sum(rows)
+        self.z = torch.zeros(n, a_total, no, dtype=plan.dtype, device=plan.device)
+        plan.outputs[self.slot] = self.z
+        row0 = 0
+        self.anch = []
+        for i, c in enumerate(convs):
+            wh = (C.c_float * (na * 2))(*[float(v) for v in self.h.anchor_grid[i].reshape(-1).tolist()])
+            self.anch.append(wh)
+            self.fwd_calls.append(Call('myolo_detect_decode', (L.ptr(c.det_out), L.DT[plan.dtype], n, na, c.out.h, c.out.w, no,
+                                                               C.c_float(float(self.h.strides[i])), wh, L.ptr(self.z),
+                                                               a_total, row0)))
+            row0 += rows[i]

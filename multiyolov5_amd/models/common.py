@@ -1,0 +1,394 @@
+"""Block library of the multiyolov5 hot path on MI355X -- host-side mirror of the reference's `models/common.py`.
+
+Same class names, constructor signatures, attribute names and `state_dict` keys as the reference
+(/root/reference/models/common.py; file:line cited per class), so `parse_model`'s `eval(name)` and pickled
+checkpoints resolve.  None of these modules calls ATen for compute: `forward()` builds (once per input
+signature) and runs a static plan of libmyolo kernel launches (multiyolov5_amd/engine.py); the nn.Conv2d /
+nn.BatchNorm2d members are parameter containers only.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from .. import engine as E
+from ..runtime import PlannedModule
+
+SILU = L.ACT_SILU
+
+
+def autopad(k, p=None):  # common.py:22-26
+    if p is None:
+        p = k // 2 if isinstance(k, int) else [x // 2 for x in k]
+    return p
+
+
+def _act_code(act):
+    if isinstance(act, nn.SiLU):
+        return L.ACT_SILU
+    if isinstance(act, nn.Sigmoid):
+        return L.ACT_SIGMOID
+    if isinstance(act, nn.Identity):
+        return L.ACT_NONE
+    raise NotImplementedError(f'activation {type(act).__name__} has no gfx950 epilogue (SiLU / Sigmoid / Identity only)')
+
+
+def conv_out_hw(h, w, k, s, p, d):
+    return (h + 2 * p - d * (k - 1) - 1) // s + 1, (w + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+def emit_conv(plan, x, conv, bn=None, act=L.ACT_NONE, res=None, out=None, det=None):
+    """append one Conv2d(+BN)(+act)(+res) to the plan; `conv` is an nn.Conv2d used as a parameter container."""
+    k, s, d = conv.kernel_size[0], conv.stride[0], conv.dilation[0]
+    if conv.groups != 1 or conv.kernel_size[0] != conv.kernel_size[1] or conv.padding[0] != d * (k // 2):
+        raise NotImplementedError('only groups=1, square, "same"-padded convolutions are on the hot path (SURVEY §2.2 K1)')
+    ho, wo = conv_out_hw(x.h, x.w, k, s, conv.padding[0], d)
+    if out is None:
+        out = plan.new(x.n, ho, wo, conv.out_channels)
+    op = plan.add(E.ConvOp(plan, x, out, conv.weight, bn=bn, bias=conv.bias, k=k, s=s, d=d, act=act, res=res, det=det))
+    return out, op
+
+
+class Conv(PlannedModule):
+    """Conv2d(bias=False) + BatchNorm2d + SiLU (common.py:34-46); `fuseforward` after Model.fuse() (45-46)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, c2, k, s, autopad(k, p), groups=g, bias=False)
+        self.bn = nn.BatchNorm2d(c2)
+        self.act = nn.SiLU() if act is True else (act if isinstance(act, nn.Module) else nn.Identity())
+
+    def emit(self, plan, x, res=None):
+        bn = self.bn if hasattr(self, 'bn') else None       # fused: bn deleted, conv carries the bias
+        return emit_conv(plan, x, self.conv, bn, _act_code(self.act), res)[0]
+
+    def fuseforward(self, x):
+        return self.forward(x)
+
+
+class Bottleneck(PlannedModule):
+    """x + cv2(cv1(x)) (common.py:95-105); the add rides in cv2's epilogue."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_, c2, 3, 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def emit(self, plan, x):
+        return self.cv2.emit(plan, self.cv1.emit(plan, x), res=x if self.add else None)
+
+
+class C3(PlannedModule):
+    """cv3(cat(m(cv1(x)), cv2(x))) (common.py:127-139); the cat is free (slice writes)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=True, g=1, e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(2 * c_, c2, 1)
+        self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
+
+    def emit(self, plan, x):
+        a = self.cv1.emit(plan, x)
+        for b in self.m:
+            a = b.emit(plan, a)
+        return self.cv3.emit(plan, plan.cat([a, self.cv2.emit(plan, x)]))
+
+
+class SPP(PlannedModule):
+    """cv1 -> [x, maxpool5, maxpool9, maxpool13] -> cv2 (common.py:163-174); one kernel does the three pools."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13)):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * (len(k) + 1), c2, 1, 1)
+        self.m = nn.ModuleList([nn.MaxPool2d(kernel_size=x, stride=1, padding=x // 2) for x in k])
+        self.k = tuple(k)
+
+    def emit(self, plan, x):
+        if tuple(getattr(self, 'k', (5, 9, 13))) != (5, 9, 13):
+            raise NotImplementedError('SPP kernel sizes other than (5,9,13)')
+        x = self.cv1.emit(plan, x)
+        outs = [plan.new(x.n, x.h, x.w, x.c) for _ in range(3)]
+        plan.add(E.SppPoolOp(plan, x, outs))
+        return self.cv2.emit(plan, plan.cat([x] + outs))
+
+
+class C3SPP(PlannedModule):
+    """C3 whose inner block is SPP (common.py:142-152)."""
+
+    def __init__(self, c1, c2, k=(5, 9, 13), g=1, e=0.5):
+        super().__init__()
+        c_ = int(c1 * e)
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c1, c_, 1, 1)
+        self.cv3 = Conv(c_ + int(c_ * 1.5), c2, 1)
+        self.m = SPP(c_, int(c_ * 1.5), k=k)
+
+    def emit(self, plan, x):
+        a = self.m.emit(plan, self.cv1.emit(plan, x))
+        return self.cv3.emit(plan, plan.cat([a, self.cv2.emit(plan, x)]))
+
+
+class Focus(PlannedModule):
+    """space-to-depth + Conv (common.py:542-551); the slicing/cat is fused with the image cast (focus_pack)."""
+
+    def __init__(self, c1, c2, k=1, s=1, p=None, g=1, act=True):
+        super().__init__()
+        self.conv = Conv(c1 * 4, c2, k, s, p, g, act)
+
+    def emit(self, plan, x):
+        if not isinstance(x, E.ImageInput):
+            raise NotImplementedError('Focus consumes the raw NCHW image (c1=3) on this path')
+        n, c, h, w = x.shape
+        if c != 3 or h % 2 or w % 2:
+            raise NotImplementedError('Focus: 3-channel image with even height/width expected')
+        t = plan.new(n, h // 2, w // 2, 16, requires_grad=False)
+        plan.add(E.FocusPackOp(plan, x.slot, t))
+        return self.conv.emit(plan, t)
+
+
+class Concat(PlannedModule):
+    """torch.cat along channels (common.py:582-589) -- producers write into slices, no copy kernel."""
+
+    def __init__(self, dimension=1):
+        super().__init__()
+        self.d = dimension
+
+    def emit(self, plan, xs):
+        if self.d != 1:
+            raise NotImplementedError('Concat along a non-channel dimension')
+        return plan.cat(list(xs))
+
+
+class Upsample(PlannedModule):
+    """nn.Upsample(None, 2, 'nearest') of the PANet (yaml:31,36) / bilinear align_corners=True elsewhere."""
+
+    def __init__(self, size=None, scale_factor=None, mode='nearest', align_corners=None):
+        super().__init__()
+        self.size, self.scale_factor, self.mode, self.align_corners = size, scale_factor, mode, align_corners
+
+    def emit(self, plan, x):
+        s = int(self.scale_factor)
+        out = plan.new(x.n, x.h * s, x.w * s, x.c)
+        if self.mode == 'nearest':
+            if s != 2:
+                raise NotImplementedError('nearest upsample other than x2')
+            plan.add(E.CopyUpOp(plan, x, out, 2))
+        elif self.mode == 'bilinear' and self.align_corners:
+            plan.add(E.BilinearOp(plan, x, out))
+        else:
+            raise NotImplementedError(f'Upsample mode {self.mode} align_corners={self.align_corners}')
+        return out
+
+
+def emit_bilinear(plan, x, h, w):
+    out = plan.new(x.n, h, w, x.c)
+    plan.add(E.BilinearOp(plan, x, out))
+    return out
+
+
+def emit_avgpool(plan, x, k):
+    out = plan.new(x.n, k, k, x.c)
+    plan.add(E.AvgPoolOp(plan, x, out))
+    return out
+
+
+def emit_broadcast(plan, g, h, w):
+    """F.interpolate(1x1 -> HxW, 'nearest') == broadcast (common.py:273,509)."""
+    out = plan.new(g.n, h, w, g.c)
+    plan.add(E.BilinearOp(plan, g, out))     # 1x1 source: bilinear align_corners degenerates to a broadcast
+    return out
+
+
+class _BareConvBNAct(nn.Sequential):
+    """nn.Sequential(Conv2d(k3,dilated,bias=False), BatchNorm2d, SiLU) as written inline in RFB/ASPP (common.py:481-490)."""
+
+    def __init__(self, c1, c2, d):
+        super().__init__(nn.Conv2d(c1, c2, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
+                         nn.BatchNorm2d(c2), nn.SiLU())
+
+    def emit(self, plan, x):
+        return emit_conv(plan, x, self[0], self[1], L.ACT_SILU)[0]
+
+
+def _emit_seq(plan, seq, x):
+    for m in seq:
+        x = m.emit(plan, x)
+    return x
+
+
+class _GlobalBranch(nn.Sequential):
+    def __init__(self, c1, c2):
+        super().__init__(nn.AdaptiveAvgPool2d(1), Conv(c1, c2, k=1))
+
+    def emit(self, plan, x):
+        return self[1].emit(plan, emit_avgpool(plan, x, 1))
+
+
+class RFB2(PlannedModule):
+    """cascaded dilated block (common.py:470-511)."""
+
+    def __init__(self, in_planes, out_planes, map_reduce=4, d=[2, 3], has_globel=False):
+        super().__init__()
+        self.out_channels = out_planes
+        self.has_globel = has_globel
+        ip = in_planes // map_reduce
+        self.branch0 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1))
+        self.branch1 = _BareConvBNAct(ip, ip, d[0])
+        self.branch2 = _BareConvBNAct(ip, ip, d[1])
+        self.branch3 = nn.Sequential(Conv(in_planes, ip, k=1, s=1))
+        if self.has_globel:
+            self.branch4 = _GlobalBranch(ip, ip)
+        self.ConvLinear = Conv(int(5 * ip) if has_globel else int(4 * ip), out_planes, k=1, s=1)
+
+    def emit(self, plan, x, res=None):
+        x3 = _emit_seq(plan, self.branch3, x)
+        x0 = _emit_seq(plan, self.branch0, x)
+        x1 = self.branch1.emit(plan, x0)
+        x2 = self.branch2.emit(plan, x1)
+        parts = [x0, x1, x2, x3]
+        if self.has_globel:
+            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x2), x.h, x.w))
+        return self.ConvLinear.emit(plan, plan.cat(parts))
+
+
+class RFB1(PlannedModule):
+    """parallel-branch variant (common.py:416-466); not instantiated by any shipped head, kept for the API."""
+
+    def __init__(self, in_planes, out_planes, map_reduce=4, d=[3, 5, 7], has_globel=False):
+        super().__init__()
+        self.out_channels = out_planes
+        self.has_globel = has_globel
+        ip = in_planes // map_reduce
+        self.branch0 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1))
+        self.branch1 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1), *_BareConvBNAct(ip, ip, d[0]))
+        self.branch2 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1), *_BareConvBNAct(ip, ip, d[1]))
+        self.branch3 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=5, s=1), *_BareConvBNAct(ip, ip, d[2]))
+        if self.has_globel:
+            self.branch4 = _GlobalBranch(in_planes, ip)
+        self.Fusion = Conv(int(5 * ip) if has_globel else int(4 * ip), out_planes, k=1, s=1)
+
+    @staticmethod
+    def _branch(plan, seq, x):
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Conv2d):       # inline Conv2d, BN, SiLU triple
+                x = emit_conv(plan, x, m, mods[i + 1], L.ACT_SILU)[0]
+                i += 3
+            else:
+                x = m.emit(plan, x)
+                i += 1
+        return x
+
+    def emit(self, plan, x):
+        parts = [self._branch(plan, b, x) for b in (self.branch0, self.branch1, self.branch2, self.branch3)]
+        if self.has_globel:
+            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x), x.h, x.w))
+        return self.Fusion.emit(plan, plan.cat(parts))
+
+
+class ASPP(PlannedModule):
+    """1x1 || three dilated 3x3 (|| global) -> 1x1 (common.py:233-275)."""
+
+    def __init__(self, in_planes, out_planes, d=[3, 6, 9], has_globel=True, map_reduce=4):
+        super().__init__()
+        self.has_globel = has_globel
+        self.hid = in_planes // map_reduce
+        self.branch0 = nn.Sequential(Conv(in_planes, self.hid, k=1, s=1))
+        self.branch1 = _BareConvBNAct(in_planes, self.hid, d[0])
+        self.branch2 = _BareConvBNAct(in_planes, self.hid, d[1])
+        self.branch3 = _BareConvBNAct(in_planes, self.hid, d[2])
+        if self.has_globel:
+            self.branch4 = _GlobalBranch(in_planes, self.hid)
+        self.ConvLinear = Conv(int(5 * self.hid) if has_globel else int(4 * self.hid), out_planes, k=1, s=1)
+
+    def emit(self, plan, x):
+        parts = [_emit_seq(plan, self.branch0, x), self.branch1.emit(plan, x), self.branch2.emit(plan, x),
+                 self.branch3.emit(plan, x)]
+        if self.has_globel:
+            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x), x.h, x.w))
+        return self.ConvLinear.emit(plan, plan.cat(parts))
+
+
+class PyramidPooling(PlannedModule):
+    """AdaptiveAvgPool(1,2,3,6) -> 1x1 -> bilinear up -> cat with x (common.py:514-539)."""
+
+    def __init__(self, in_channels, k=[1, 2, 3, 6]):
+        super().__init__()
+        self.pool1 = nn.AdaptiveAvgPool2d(k[0])
+        self.pool2 = nn.AdaptiveAvgPool2d(k[1])
+        self.pool3 = nn.AdaptiveAvgPool2d(k[2])
+        self.pool4 = nn.AdaptiveAvgPool2d(k[3])
+        oc = in_channels // 4
+        self.conv1 = Conv(in_channels, oc, k=1)
+        self.conv2 = Conv(in_channels, oc, k=1)
+        self.conv3 = Conv(in_channels, oc, k=1)
+        self.conv4 = Conv(in_channels, oc, k=1)
+        self.k = list(k)
+
+    def emit(self, plan, x):
+        feats = [x]
+        for k, conv in zip(self.k, (self.conv1, self.conv2, self.conv3, self.conv4)):
+            feats.append(emit_bilinear(plan, conv.emit(plan, emit_avgpool(plan, x, k)), x.h, x.w))
+        return plan.cat(feats)
+
+
+class FFM(PlannedModule):
+    """feature fusion: f = Conv_k(cat); out = f*sigmoid(W2 silu(W1 GAP(f))) + f (common.py:210-230)."""
+
+    def __init__(self, in_chan, out_chan, reduction=1, is_cat=True, k=1):
+        super().__init__()
+        self.convblk = Conv(in_chan, out_chan, k=k, s=1, p=None)
+        self.channel_attention = nn.Sequential(
+            nn.AdaptiveAvgPool2d(1),
+            nn.Conv2d(out_chan, out_chan // reduction, kernel_size=1, stride=1, padding=0, bias=False),
+            nn.SiLU(inplace=True),
+            nn.Conv2d(out_chan // reduction, out_chan, kernel_size=1, stride=1, padding=0, bias=False),
+            nn.Sigmoid())
+        self.is_cat = is_cat
+
+    def emit(self, plan, xs):
+        x = plan.cat(list(xs)) if self.is_cat else xs
+        feat = self.convblk.emit(plan, x)
+        a = emit_avgpool(plan, feat, 1)
+        ca = self.channel_attention
+        a = emit_conv(plan, a, ca[1], None, L.ACT_SILU)[0]
+        a = emit_conv(plan, a, ca[3], None, L.ACT_SIGMOID)[0]
+        out = plan.new(feat.n, feat.h, feat.w, feat.c)
+        plan.add(E.GateOp(plan, feat, a, out))
+        return out
+
+
+class Attention(PlannedModule):
+    """SE gate x * W(x) (common.py:177-192); not instantiated by the shipped heads."""
+
+    def __init__(self, chan, reduction=1):
+        super().__init__()
+        if reduction > 1:
+            self.W = nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv(chan, chan // reduction, k=1, s=1),
+                                   Conv(chan // reduction, chan, k=1, s=1, act=False), nn.Sigmoid())
+        else:
+            self.W = nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv(chan, chan, k=1, s=1, act=False), nn.Sigmoid())
+
+    def emit(self, plan, x):
+        raise NotImplementedError('Attention/ARM gates (x*att without the +x) are not wired on the gfx950 path yet; '
+                                  'no shipped head instantiates them (reference yolo.py:43-49 keeps them commented)')
+
+
+class ARM(PlannedModule):
+    """AttentionRefinementModule (common.py:195-207); not instantiated by the shipped heads."""
+
+    def __init__(self, in_chan, out_chan, *args, **kwargs):
+        super().__init__()
+        self.conv = Conv(in_chan, out_chan, k=3, s=1, p=None)
+        self.channel_attention = nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv(out_chan, out_chan, k=1, s=1, act=False),
+                                               nn.Sigmoid())
+
+    def emit(self, plan, x):
+        raise NotImplementedError('ARM is not wired on the gfx950 path yet; no shipped head instantiates it')

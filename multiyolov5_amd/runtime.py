@@ -1,0 +1,221 @@
+"""Module <-> plan glue: `PlannedModule.forward` builds (once per input signature) and runs a static launch plan.
+
+The torch side is plumbing only: tensors own device memory, `torch.autograd.Function` hands the plan's backward to
+`loss.backward()` (reference train.py:371,392) and to DDP's reducer hooks.  All arithmetic is in libmyolo.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import engine as E
+
+
+def compute_dtype(tensors):
+    """fp16 under autocast (train.py:364,380) or for .half() models/inputs (detect.py:103,136); fp32 otherwise."""
+    if torch.is_autocast_enabled():
+        return torch.float16
+    for t in tensors:
+        if t.dtype == torch.float16:
+            return torch.float16
+    return torch.float32
+
+
+def _flatten(x, out):
+    if torch.is_tensor(x):
+        out.append(x)
+        return ('t', len(out) - 1)
+    if isinstance(x, (list, tuple)):
+        return ('l', [_flatten(v, out) for v in x])
+    raise TypeError(f'unsupported module input {type(x)}')
+
+
+def _unflatten(spec, vals):
+    kind, v = spec
+    if kind == 't':
+        return vals[v]
+    return [_unflatten(s, vals) for s in v]
+
+
+class _OutSpec:
+    """walks the structure returned by emit(), registering plan outputs; rebuilds it from tensors at run time."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.nslots = 0
+        self.det_slots = {}      # slot -> ConvOp (Detect training outputs)
+
+    def register(self, y):
+        plan = self.plan
+        if isinstance(y, E.TV):
+            s = self._slot()
+            plan.add(E.ExportOp(plan, y, s))
+            return ('o', s)
+        if isinstance(y, E.SegHandle):
+            s = self._slot()
+            plan.add(E.SegOutOp(plan, y.low, y.scale, s))
+            return ('o', s)
+        if isinstance(y, E.DetHandle):
+            s = self._slot()
+            self.det_slots[s] = y.op
+            return ('o', s)
+        if isinstance(y, E.DecodeHandle):
+            s = self._slot()
+            plan.add(E.DecodeOp(plan, y, s))
+            return ('tuple', [('o', s), ('l', [self.register(d) for d in y.dets])])
+        if isinstance(y, (list, tuple)):
+            return ('l', [self.register(v) for v in y])
+        raise TypeError(f'unsupported module output {type(y)}')
+
+    def _slot(self):
+        self.nslots += 1
+        return self.nslots - 1
+
+    @staticmethod
+    def rebuild(spec, vals):
+        kind, v = spec
+        if kind == 'o':
+            return vals[v]
+        if kind == 'tuple':
+            return tuple(_OutSpec.rebuild(s, vals) for s in v)
+        return [_OutSpec.rebuild(s, vals) for s in v]
+
+
+class PlanFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, *tensors):
+        plan = holder.plan
+        ctx.holder = holder
+        ctx.set_materialize_grads(False)
+        holder.bind_inputs(tensors[:holder.n_in])
+        plan.run_fwd()
+        outs = tuple(o.detach() for o in holder.output_tensors())
+        holder.pending_bwd = True
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        holder = ctx.holder
+        plan = holder.plan
+        if not holder.pending_bwd:
+            raise L.MyoloError('backward through a plan whose activations were overwritten by a newer forward '
+                               '(one outstanding forward per module/shape; call backward before the next forward)')
+        for s, g in enumerate(grads):
+            dst = holder.output_grad_tensor(s)
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g)
+        plan.run_bwd()
+        holder.pending_bwd = False
+        in_grads = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]
+        flat = plan.flat_grad.clone()
+        pg, off = [], 0
+        for p in plan.params:
+            n = p.numel()
+            pg.append(flat[off:off + n].view(p.shape) if p.requires_grad else None)
+            off += n
+        return (None, *in_grads, *pg)
+
+
+class PlanHolder:
+    """a built plan + its input/output binding for one (module, signature)."""
+
+    def __init__(self, module, tensors, spec, dtype, training):
+        dev = tensors[0].device
+        self.plan = plan = E.Plan(dev, dtype, training)
+        self.n_in = len(tensors)
+        self.in_requires_grad = [bool(t.requires_grad) for t in tensors]
+        handles = []
+        for t in tensors:
+            slot = plan.add_input(t)
+            if t.dim() != 4:
+                raise L.MyoloError('module inputs are NCHW tensors')
+            n, c, h, w = t.shape
+            if c % E.SEG[dtype] != 0:
+                if not t.is_contiguous():
+                    raise L.MyoloError('image input must be contiguous NCHW')
+                handles.append(E.ImageInput(slot, tuple(t.shape)))
+            else:
+                tv = plan.new(n, h, w, c, requires_grad=training and t.requires_grad)
+                plan.add(E.ImportOp(plan, slot, tv))
+                handles.append(tv)
+        y = module.emit(plan, _unflatten(spec, handles))
+        self.ospec = _OutSpec(plan)
+        self.out_spec = self.ospec.register(y)
+        plan.register_params([p for p in module.parameters()])
+        plan.build()
+        self.pending_bwd = False
+        self.sig = self.param_sig(module)
+
+    @staticmethod
+    def param_sig(module):
+        return tuple((p.data_ptr(), p.dtype) for p in module.parameters()) + \
+            tuple((b.data_ptr(), b.dtype) for b in module.buffers())
+
+    def bind_inputs(self, tensors):
+        for i, t in enumerate(tensors):
+            self.plan.in_ptr[i].value = t.data_ptr()
+
+    def output_tensors(self):
+        outs = []
+        for s in range(self.ospec.nslots):
+            if s in self.ospec.det_slots:
+                outs.append(self.ospec.det_slots[s].det_out)
+            else:
+                outs.append(self.plan.outputs[s])
+        return outs
+
+    def output_grad_tensor(self, s):
+        if s in self.ospec.det_slots:
+            return self.ospec.det_slots[s].gdet
+        return self.plan.output_grads[s]
+
+
+class PlannedModule(nn.Module):
+    """nn.Module whose forward is a libmyolo launch plan.  Subclasses implement emit(plan, x)."""
+
+    def _holder(self, tensors, spec):
+        for t in tensors:
+            L.require_gpu(t)
+        dtype = compute_dtype(tensors)
+        grad = torch.is_grad_enabled() and self.training
+        key = (tuple((tuple(t.shape), tuple(t.stride()), t.dtype, bool(t.requires_grad and grad)) for t in tensors),
+               str(spec), dtype, bool(self.training), grad)
+        plans = self.__dict__.setdefault('_plans', {})
+        h = plans.get(key)
+        sig = PlanHolder.param_sig(self)
+        if h is None or h.sig != sig:
+            # module.training decides BatchNorm batch statistics (and builds the backward launch list);
+            # `grad` only decides whether autograd is wired through PlanFn
+            h = PlanHolder(self, tensors, spec, dtype, bool(self.training))
+            h.sig = sig
+            plans[key] = h
+        elif not self.training:
+            if self.__dict__.get('_prepared_version') != self._param_version():
+                h.plan.prepare()
+        self.__dict__['_prepared_version'] = self._param_version()
+        return h, grad
+
+    def _param_version(self):
+        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+
+    def forward(self, x):
+        tensors = []
+        spec = _flatten(x, tensors)
+        h, grad = self._holder(tensors, spec)
+        if grad:
+            outs = PlanFn.apply(h, *tensors, *h.plan.params)
+        else:
+            h.bind_inputs(tensors)
+            h.plan.run_fwd()
+            outs = h.output_tensors()
+        return _OutSpec.rebuild(h.out_spec, list(outs))
+
+    def invalidate_plans(self):
+        self.__dict__.pop('_plans', None)
+
+    def __getstate__(self):       # plans hold device pointers: never pickled (train.py:485 pickles whole modules)
+        d = dict(self.__dict__)
+        d.pop('_plans', None)
+        d.pop('_prepared_version', None)
+        return d

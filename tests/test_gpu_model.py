@@ -1,0 +1,87 @@
+"""-m gpu: whole-model parity (Model.forward / backward through the C ABI) against the CPU oracle and the committed
+golden vectors generated from the reference itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, model_ref, synth
+from tests.gpu_util import TOL, check
+from tests.util import CFG, TAGS, golden, load_cfg, synth_sd
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+H, W = 64, 128
+
+
+def build(tag):
+    from multiyolov5_amd.models.yolo import Model
+    m = Model(os.path.join(CFG, TAGS[tag]))
+    sd = synth_sd(tag)
+    m.load_state_dict(sd, strict=True)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    return m.to(DEV), sd
+
+
+@pytest.mark.parametrize('tag', ['s_psp', 's_base', 's_lab', 's_bise', 'm_lab'])
+def test_eval_fused_fp32_matches_reference_golden(tag):
+    """detect.py path: fuse().eval(); fp32 logits within 1e-3, seg argmax and decoded boxes vs the reference."""
+    m, _ = build(tag)
+    m.fuse().eval()
+    x = synth.synth_images(2, H, W, seed=1)[:1].to(DEV)
+    with torch.no_grad():
+        (pred, raw), seg = m(x)
+    g = golden('model_' + tag)
+    bad = []
+    check(f'{tag}/eval_pred', pred, g['eval_pred'], 1e-4, atol=2e-2, collect=bad)
+    check(f'{tag}/eval_seg_sub', seg[:, :, ::4, ::4], g['eval_seg_sub'], 2e-4, atol=1e-3, collect=bad)
+    mism = (seg.argmax(1).cpu().numpy() != g['eval_seg_argmax']).mean()
+    assert mism < 1e-3, f'seg argmax mismatch fraction {mism}'
+    assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+@pytest.mark.parametrize('tag', ['s_psp', 's_lab', 's_bise', 's_base'])
+def test_train_forward_backward_vs_oracle(tag, dtype):
+    m, sd = build(tag)
+    m.train()
+    cfg = load_cfg(tag)
+    x = synth.synth_images(2, H, W, seed=1)
+    # oracle (CPU fp32, autograd)
+    params = {k: v.clone().requires_grad_() for k, v in sd.items()
+              if v.dtype.is_floating_point and 'running' not in k and 'anchor' not in k}
+    sdt = {k: (params[k] if k in params else v.clone()) for k, v in sd.items()}
+    rdet, rseg = model_ref.forward(cfg, sdt, x, training=True, dropout_p=0.0)
+    rsegs = rseg if isinstance(rseg, list) else [rseg]
+    gen = torch.Generator().manual_seed(5)
+    rd = [torch.randn(d.shape, generator=gen) for d in rdet]
+    rs = [torch.randn(s.shape, generator=gen) * 0.1 for s in rsegs]
+    (sum((a * b).sum() for a, b in zip(rdet, rd)) + sum((a * b).sum() for a, b in zip(rsegs, rs))).backward()
+    # product
+    xin = x.to(DEV, dtype)
+    det, seg = m(xin)
+    segs = seg if isinstance(seg, list) else [seg]
+    tol = TOL[dtype]
+    bad = []
+    g = golden('model_' + tag)
+    for i, d in enumerate(det):
+        check(f'{tag}/det{i}', d, rdet[i], tol, collect=bad)
+        if dtype == torch.float32:
+            check(f'{tag}/det{i}_golden', d, g[f'train_det{i}'], 2e-4, collect=bad)
+    for j, s in enumerate(segs):
+        check(f'{tag}/seg{j}', s, rsegs[j], tol, collect=bad)
+        if dtype == torch.float32:
+            check(f'{tag}/seg{j}_golden', s[:, :, ::4, ::4], g[f'train_seg{j}_sub'], 2e-4, atol=1e-3, collect=bad)
+    (sum((a.float() * b.to(DEV)).sum() for a, b in zip(det, rd)) +
+     sum((a.float() * b.to(DEV)).sum() for a, b in zip(segs, rs))).backward()
+    worst = []
+    for k, p in m.named_parameters():
+        ok = check(f'{tag}/grad/{k}', p.grad, params[k].grad, tol * 5, collect=worst)
+    assert len(worst) <= 0, f'{len(worst)} parameter gradients off:\n' + '\n'.join(worst[:20])
+    for k, b in m.named_buffers():
+        if 'running' in k:
+            check(f'{tag}/{k}', b, sdt[k], tol, collect=bad)
+    assert not bad, '\n'.join(bad[:20])

@@ -1,0 +1,110 @@
+"""-m gpu: every block of the hot path through the module API (-> plan -> libmyolo C ABI), forward and backward,
+against the CPU oracle restatement on the same seeded inputs.  fp32 parity mode and fp16."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref
+from tests.gpu_util import TOL, check
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _randomize(mod, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in mod.named_parameters():
+            if p.dim() == 4:
+                fan = p.shape[1] * p.shape[2] * p.shape[3]
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * (3.0 / fan) ** 0.5 * 1.4)
+            elif n.endswith('bn.weight') or n.endswith('.1.weight'):
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+        for n, b in mod.named_buffers():
+            if n.endswith('running_mean'):
+                b.copy_(torch.randn(b.shape, generator=g) * 0.1)
+            elif n.endswith('running_var'):
+                b.copy_(torch.rand(b.shape, generator=g) + 0.5)
+
+
+def _oracle(fn, mod, xs, training):
+    """run an oracle block function on CPU with the module's parameters; returns (out, grads dict, input grads)."""
+    sd = {'m.' + k: v.detach().cpu().float().clone() for k, v in mod.state_dict().items()}
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k}
+    ctx = model_ref.Ctx(sd, training, dropout_p=0.0)
+    xin = [x.detach().cpu().float().clone().requires_grad_() for x in xs]
+    out = fn(ctx, 'm', xin[0] if len(xin) == 1 else xin)
+    return out, params, xin, sd
+
+
+CASES = {
+    # name: (ctor, oracle fn, input shapes)
+    'conv1x1': (lambda C: C.Conv(64, 128, 1, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 1), [(2, 64, 24, 40)]),
+    'conv3x3': (lambda C: C.Conv(32, 64, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(2, 32, 20, 36)]),
+    'conv3x3s2': (lambda C: C.Conv(64, 128, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), [(2, 64, 24, 40)]),
+    'conv3x3s2_odd': (lambda C: C.Conv(16, 32, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), [(1, 16, 13, 19)]),
+    'conv_wide': (lambda C: C.Conv(512, 256, 1, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 1), [(2, 512, 8, 16)]),
+    'conv_c48': (lambda C: C.Conv(48, 48, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(2, 48, 16, 16)]),
+    'bottleneck': (lambda C: C.Bottleneck(64, 64, True), lambda c, p, x: model_ref.bottleneck(c, p, x, True), [(2, 64, 16, 32)]),
+    'c3': (lambda C: C.C3(64, 64, 2, True), lambda c, p, x: model_ref.c3(c, p, x, 2, True), [(2, 64, 16, 32)]),
+    'c3_noshort': (lambda C: C.C3(128, 64, 1, False), lambda c, p, x: model_ref.c3(c, p, x, 1, False), [(2, 128, 8, 16)]),
+    'spp': (lambda C: C.SPP(64, 64), lambda c, p, x: model_ref.spp(c, p, x), [(2, 64, 10, 18)]),
+    'c3spp': (lambda C: C.C3SPP(64, 96), lambda c, p, x: model_ref.c3spp(c, p, x), [(2, 64, 8, 16)]),
+    'rfb2': (lambda C: C.RFB2(96, 64, map_reduce=6), lambda c, p, x: model_ref.rfb2(c, p, x, (2, 3), False), [(2, 96, 12, 20)]),
+    'rfb2_global': (lambda C: C.RFB2(128, 64, map_reduce=8, has_globel=True), lambda c, p, x: model_ref.rfb2(c, p, x, (2, 3), True), [(2, 128, 6, 10)]),
+    'aspp': (lambda C: C.ASPP(64, 64, d=[3, 6, 9], has_globel=False, map_reduce=4), lambda c, p, x: model_ref.aspp(c, p, x, (3, 6, 9), False), [(2, 64, 12, 20)]),
+    'pyramid': (lambda C: C.PyramidPooling(64), lambda c, p, x: model_ref.pyramid_pooling(c, p, x), [(2, 64, 8, 16)]),
+    'ffm_k3': (lambda C: C.FFM(64, 32, k=3, is_cat=False), lambda c, p, x: model_ref.ffm(c, p, x, 3), [(2, 64, 8, 16)]),
+    'ffm_cat': (lambda C: C.FFM(64, 64, k=1, is_cat=True), lambda c, p, x: model_ref.ffm(c, p, torch.cat(x, 1), 1), [(2, 16, 8, 16), (2, 48, 8, 16)]),
+}
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+@pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
+@pytest.mark.parametrize('name', list(CASES))
+def test_block(name, training, dtype):
+    from multiyolov5_amd.models import common as C
+    from multiyolov5_amd.utils.torch_utils import initialize_weights
+    ctor, fn, shapes = CASES[name]
+    torch.manual_seed(1)
+    mod = ctor(C)
+    initialize_weights(mod)
+    _randomize(mod)
+    mod = mod.to(DEV)
+    mod.train(training)
+    g = torch.Generator().manual_seed(3)
+    xs_cpu = [torch.randn(s, generator=g) for s in shapes]
+    xs = [x.to(DEV, dtype).requires_grad_(training) for x in xs_cpu]
+    ref_out, ref_params, ref_xin, ref_sd = _oracle(fn, mod, [x.to(dtype) for x in xs_cpu], training)
+    out = mod(xs[0] if len(xs) == 1 else xs)
+    tol = TOL[dtype]
+    bad = []
+    check(f'{name}/out', out, ref_out, tol, collect=bad)
+    if training:
+        r = torch.randn(ref_out.shape, generator=g)
+        (ref_out * r).sum().backward()
+        (out.float() * r.to(DEV)).sum().backward()
+        for i, x in enumerate(xs):
+            check(f'{name}/dx{i}', x.grad, ref_xin[i].grad, tol * 2, collect=bad)
+        for k, p in mod.named_parameters():
+            check(f'{name}/d{k}', p.grad, ref_params['m.' + k].grad, tol * 3, collect=bad)
+        for k, b in mod.named_buffers():
+            if 'running' in k:
+                check(f'{name}/{k}', b, ref_sd['m.' + k], tol, collect=bad)
+    assert not bad, '\n'.join(bad)
+
+
+def test_focus_f32_and_f16():
+    from multiyolov5_amd.models import common as C
+    from multiyolov5_amd.utils.torch_utils import initialize_weights
+    for dtype in (torch.float32, torch.float16):
+        mod = C.Focus(3, 32, 3)
+        initialize_weights(mod)
+        _randomize(mod)
+        mod = mod.to(DEV).eval()
+        x = torch.rand(2, 3, 32, 48)
+        ref_out, *_ = _oracle(lambda c, p, xx: model_ref.focus(c, p, xx), mod, [x.to(dtype)], False)
+        out = mod(x.to(DEV, dtype))
+        check(f'focus/{dtype}', out, ref_out, TOL[dtype])
