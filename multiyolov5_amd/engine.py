@@ -276,7 +276,7 @@ class ConvOp(Op):
                     self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
                     d.shift = self.shift.data_ptr()
             self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
-        self.d = d
+        self.fdesc = d
         if training:
             self._build_bwd(plan, two_pass, has_bn)
 
@@ -716,7 +716,8 @@ class Plan:
         for op in self.ops:
             op.build(self)
         self.built = True
-        self.prepare()
+        if torch.device(self.device).type == 'cuda':     # a CPU-device plan is a dry build (shape/launch-list checks only)
+            self.prepare()
 
     def prepare(self):
         st = L.stream_ptr()

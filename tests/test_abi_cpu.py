@@ -90,3 +90,19 @@ def test_dgrad_tap_math():
                 if 0 <= oy < Ho:
                     bwd.add((q * s + py, oy, kh))
     assert fwd == bwd
+
+
+@pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
+@pytest.mark.parametrize('tag', list(TAGS))
+def test_plan_dry_build_on_cpu(tag, training):
+    """host logic: the whole forward(+backward) launch list of every head builds without a GPU (no launch is made)."""
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    from tests.util import CFG
+    m = Model(os.path.join(CFG, TAGS[tag]))
+    m.train(training)
+    for dt in (torch.float16, torch.float32):
+        h = R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), dt, training)
+        nf = sum(len(o.fwd_calls) for o in h.plan.ops)
+        nb = sum(len(o.bwd_calls) for o in h.plan.ops)
+        assert nf > 70 and (nb > nf if training else nb == 0)

@@ -31,7 +31,8 @@ def _randomize(mod, seed=0):
 
 def _oracle(fn, mod, xs, training):
     """run an oracle block function on CPU with the module's parameters; returns (out, grads dict, input grads)."""
-    sd = {'m.' + k: v.detach().cpu().float().clone() for k, v in mod.state_dict().items()}
+    sd = {'m.' + k: (v.detach().cpu().float().clone() if v.dtype.is_floating_point else v.detach().cpu().clone())
+          for k, v in mod.state_dict().items()}
     params = {k: v.requires_grad_() for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k}
     ctx = model_ref.Ctx(sd, training, dropout_p=0.0)
     xin = [x.detach().cpu().float().clone().requires_grad_() for x in xs]
