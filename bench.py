@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""bench.py -- joint detection+segmentation training step of yolov5s_city_seg (PSP head) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" (BASELINE.json configs[1], SURVEY.md 8(d)(i) joint step): forward of a [16,3,512,1024] fp16 batch through
+the libmyolo plan (Model.forward), ComputeLoss + segmentation cross-entropy, backward, loss-scaled fused SGD(nesterov)
++ EMA update.  Inputs are synthetic Cityscapes-shaped tensors already resident in HBM.  N>1: one process per GPU,
+the same per-GPU batch (weak scaling), gradients all-reduced over RCCL by multiyolov5_amd.parallel.GradReducer.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (configs[1]: 16)')
+    ap.add_argument('--img', type=int, nargs=2, default=(512, 1024), help='H W')
+    ap.add_argument('--cfg', default='yolov5s_city_seg.yaml')
+    ap.add_argument('--dtype', default='f16', choices=['f16', 'f32'])
+    ap.add_argument('--stage', default='train', choices=['train', 'fwdbwd', 'infer'],
+                    help="dev only: 'fwdbwd' = model fwd+bwd with fixed output gradients (no loss/optimizer; NOT a valid "
+                         "bench line), 'infer' = detect.py path FPS only")
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-infer', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+def setup_dist(args):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend='nccl', init_method='env://', device_id=torch.device('cuda', local))
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+class Trainer:
+    """the reference's hot loop body (train.py:364-401) restricted to one joint batch."""
+
+    def __init__(self, args, world, rank, dev):
+        from multiyolov5_amd.models.yolo import Model
+        from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
+        from multiyolov5_amd.utils.optim import FusedSGD, GradScaler
+        from multiyolov5_amd.utils.torch_utils import ModelEMA
+        from multiyolov5_amd import synth
+        self.args, self.world, self.dev = args, world, dev
+        H, W = args.img
+        B = args.batch
+        torch.manual_seed(0)
+        m = Model(os.path.join(ROOT, 'multiyolov5_amd', 'cfg', args.cfg))
+        synth.randomize_(m, seed=0)                     # random-init weights + non-trivial BN stats (no checkpoints offline)
+        self.model = m.to(dev).train()
+        nc, nl = 10, 3
+        hyp = dict(box=0.05 * 3. / nl, cls=0.5 * nc / 80. * 3. / nl, obj=1.0 * (max(H, W) / 640) ** 2 * 3. / nl,
+                   cls_pw=1.0, obj_pw=1.0, anchor_t=4.0, fl_gamma=0.0, label_smoothing=0.0)   # hyp.scratch + train.py:248-250
+        m.nc, m.hyp, m.gr = nc, hyp, 1.0
+        self.dtype = torch.float16 if args.dtype == 'f16' else torch.float32
+        self.imgs = synth.images(B, H, W, seed=1 + rank).to(dev, self.dtype)
+        self.targets = synth.det_targets(B, 8, nc, seed=1 + rank).to(dev)
+        self.mask = synth.seg_targets(B, H, W, 19, seed=1 + rank).to(dev)
+        if args.stage == 'train':
+            self.compute_loss = ComputeLoss(m)
+            self.compute_seg_loss = SegmentationLosses()
+            pg0, pg1, pg2 = [], [], []                 # train.py:121-137
+            for k, v in m.named_modules():
+                if hasattr(v, 'bias') and isinstance(v.bias, torch.nn.Parameter):
+                    pg2.append(v.bias)
+                if isinstance(v, torch.nn.BatchNorm2d):
+                    pg0.append(v.weight)
+                elif hasattr(v, 'weight') and isinstance(v.weight, torch.nn.Parameter):
+                    pg1.append(v.weight)
+            total_bs = B * world
+            wd = 0.0005 * total_bs * max(round(64 / total_bs), 1) / 64
+            self.opt = FusedSGD([{'params': pg0}, {'params': pg1, 'weight_decay': wd}, {'params': pg2}],
+                                lr=0.0015, momentum=0.937, nesterov=True)
+            self.scaler = GradScaler(enabled=self.dtype == torch.float16)
+            self.ema = ModelEMA(m) if rank == 0 else None
+            self.reducer = None
+            if world > 1:
+                from multiyolov5_amd.parallel import GradReducer
+                self.reducer = GradReducer(m, world)
+        else:
+            self.fixed = None
+
+    def step(self):
+        a = self.args
+        m = self.model
+        if a.stage == 'fwdbwd':
+            det, seg = m(self.imgs)
+            if self.fixed is None:
+                g = torch.Generator(device=self.dev).manual_seed(3)
+                self.fixed = [torch.randn(d.shape, device=self.dev, generator=g).to(d.dtype) * 1e-3 for d in det] + \
+                    [torch.randn(seg.shape, device=self.dev, generator=g).to(seg.dtype) * 1e-4]
+            torch.autograd.backward(list(det) + [seg], self.fixed)
+            for p in m.parameters():
+                p.grad = None
+            return
+        B = a.batch
+        pred = m(self.imgs)                                              # train.py:364
+        loss, items = self.compute_loss(pred[0], self.targets)          # train.py:365
+        if self.world > 1:
+            loss = loss * self.world                                     # train.py:366-367
+        segloss = self.compute_seg_loss(pred[1], self.mask) * B         # train.py:385
+        total = loss * 0.6 + segloss * 0.35                              # train.py:290,370,391 (detgain, seggain)
+        self.scaler.scale(total).backward()                              # train.py:371/392
+        if self.reducer is not None:
+            self.reducer.wait()
+        self.scaler.step(self.opt)                                       # train.py:397
+        self.scaler.update()
+        self.opt.zero_grad()
+        if self.ema is not None:
+            self.ema.update(m)                                           # train.py:400-401
+        self.last = (loss, segloss)
+
+
+def conv_kernel_timing(trainer, nsteps=3):
+    """HIP-event timing of every myolo_conv launch (the dominant kernel) over `nsteps` steps, on the launch stream.
+    Returns (total algorithmic bytes, total flops, total seconds, launches) per step."""
+    from multiyolov5_amd import engine as E
+    rec = []
+
+    orig = E.Call.__call__
+
+    def timed(self, st):
+        if self.name != 'myolo_conv':
+            return orig(self, st)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(self, st)
+        e1.record()
+        rec.append((self, e0, e1))
+
+    E.Call.__call__ = timed
+    try:
+        for _ in range(nsteps):
+            trainer.step()
+        torch.cuda.synchronize()
+    finally:
+        E.Call.__call__ = orig
+    tot_t = sum(e0.elapsed_time(e1) for _, e0, e1 in rec) * 1e-3 / nsteps
+    tot_b = sum(E.conv_call_bytes(c) for c, _, _ in rec) / nsteps
+    tot_f = sum(E.conv_call_flops(c) for c, _, _ in rec) / nsteps
+    return tot_b, tot_f, tot_t, len(rec) // nsteps
+
+
+def infer_fps(args, dev, frames=30, warm=5):
+    """detect.py path (detect.py:144-193): fused eval forward at 1x3x1024x2048 fp16 + NMS + seg upsample/argmax."""
+    from multiyolov5_amd.models.yolo import Model
+    from multiyolov5_amd.utils.general import non_max_suppression, seg_argmax
+    from multiyolov5_amd import synth
+    m = Model(os.path.join(ROOT, 'multiyolov5_amd', 'cfg', 'yolov5s_city_seg.yaml'))
+    synth.randomize_(m, seed=0)
+    m = m.to(dev).half().fuse().eval()
+    img = synth.images(1, 1024, 2048, seed=7).to(dev, torch.float16)
+    pred_syn = synth.nms_pred(1, 129024, 10, seed=3, img_w=2048, img_h=1024).to(dev, torch.float16)
+
+    def frame():
+        with torch.no_grad():
+            out = m(img)
+            # random-init heads give no candidates above conf 0.25: NMS is fed the synthetic prediction
+            # tensor of the same shape/dtype so that suppression actually happens
+            det = non_max_suppression(pred_syn, 0.25, 0.45)
+            lab = seg_argmax(out[1], 1024, 2048)
+        return det, lab
+    for _ in range(warm):
+        frame()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        frame()
+    torch.cuda.synchronize()
+    return frames / (time.perf_counter() - t0)
+
+
+def cpu_baseline(args):
+    """the oracle (CPU restatement of the reference path, torch CPU fp32) timed on this box's host cores on a bounded
+    sample: BASELINE configs[0]-style joint step (fwd + both losses + bwd) at 2x3x512x1024."""
+    from oracle import cpu_bench
+    return cpu_bench.joint_step(cfg=args.cfg, batch=2, H=args.img[0], W=args.img[1], budget_s=20.0)
+
+
+def main():
+    args = parse()
+    world, rank, local = setup_dist(args)
+    dev = torch.device('cuda', local)
+    from multiyolov5_amd import _lib
+    _lib.lib()                                           # fail loudly if the HIP library is missing
+    out = {}
+    if args.stage == 'infer':
+        fps = infer_fps(args, dev)
+        if rank == 0:
+            print(json.dumps({'metric': 'detect.py FPS (fwd+NMS+argmax) 2048x1024', 'value': fps, 'unit': 'frames/s'}))
+        return
+    tr = Trainer(args, world, rank, dev)
+    for _ in range(args.warmup):
+        tr.step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.step()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    ips = args.batch * world * args.steps / dt
+    H, W = args.img
+    out = {
+        'metric': 'train images/sec (joint det+seg step: fwd + ComputeLoss + seg CE + bwd + SGD + EMA)',
+        'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': args.dtype, 'data': 'synthetic',
+        'config': {'workload': f'{args.cfg} psp head bs={args.batch}/GPU {W}x{H} fp16 joint train step (BASELINE configs[1])'
+                   if args.dtype == 'f16' else f'{args.cfg} bs={args.batch}/GPU {W}x{H} fp32 parity mode',
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'stage': args.stage},
+    }
+    if args.stage != 'train':
+        out['metric'] = 'DEV ONLY fwd+bwd images/sec (no loss / optimizer) -- not a bench line'
+    if rank == 0 and world == 1:
+        if not args.no_kernel_timing:
+            b, f, t, n = conv_kernel_timing(tr)
+            out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                               'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': None,
+                               'kernel': 'conv_igemm_kernel (fwd + dgrad launches)', 'launches_per_step': n,
+                               'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
+                               'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,
+                               'conv_time_frac_of_step': t / (ms * 1e-3)}
+        if args.stage == 'train' and not args.no_infer:
+            try:
+                out['detect_fps'] = {'value': infer_fps(args, dev), 'unit': 'frames/s',
+                                     'workload': 'pspv5s fused fp16 1x3x1024x2048 fwd + NMS(129024 cand) + x8 upsample+argmax'}
+            except Exception as e:                       # the secondary metric must not take the primary line down
+                out['detect_fps'] = {'value': None, 'error': repr(e)}
+        if args.stage == 'train' and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

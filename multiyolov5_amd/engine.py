@@ -805,3 +805,23 @@ class DecodeOp(Op):
                                                                C.c_float(float(self.h.strides[i])), wh, L.ptr(self.z),
                                                                a_total, row0)))
             row0 += rows[i]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# algorithmic work of one myolo_conv launch (bench.py roofline): input + weights + output moved once, 2*MAC flops
+def _conv_desc_of(call):
+    return call.args[0]._obj
+
+
+def conv_call_bytes(call):
+    d = _conv_desc_of(call)
+    es = 2 if d.x.dtype == L.F16 else 4
+    xin = d.x.n * d.x.h * d.x.w * d.x.c
+    yout = d.y.n * d.y.h * d.y.w * d.y.c
+    w = d.y.c * d.ntaps * d.x.c
+    return (xin + yout + w) * es
+
+
+def conv_call_flops(call):
+    d = _conv_desc_of(call)
+    return 2.0 * d.y.n * d.y.h * d.y.w * d.y.c * d.ntaps * d.x.c
