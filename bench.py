@@ -70,9 +70,6 @@ class Trainer:
 
     def __init__(self, args, world, rank, dev):
         from multiyolov5_amd.models.yolo import Model
-        from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
-        from multiyolov5_amd.utils.optim import FusedSGD, GradScaler
-        from multiyolov5_amd.utils.torch_utils import ModelEMA
         from multiyolov5_amd import synth
         self.args, self.world, self.dev = args, world, dev
         H, W = args.img
@@ -90,6 +87,9 @@ class Trainer:
         self.targets = synth.det_targets(B, 8, nc, seed=1 + rank).to(dev)
         self.mask = synth.seg_targets(B, H, W, 19, seed=1 + rank).to(dev)
         if args.stage == 'train':
+            from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
+            from multiyolov5_amd.utils.optim import FusedSGD, GradScaler
+            from multiyolov5_amd.utils.torch_utils import ModelEMA
             self.compute_loss = ComputeLoss(m)
             self.compute_seg_loss = SegmentationLosses()
             pg0, pg1, pg2 = [], [], []                 # train.py:121-137

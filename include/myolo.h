@@ -176,6 +176,45 @@ int myolo_detect_unpermute(const void* g, int g_dtype, int na, int no, const myo
 int myolo_detect_decode(const void* raw, int dtype, int n, int na, int ny, int nx, int no, float stride,
                         const float* anchor_wh_px, void* z, int64_t a_total, int64_t row0, void* stream);
 
+/* ---- losses ------------------------------------------------------------------------------------ */
+/* nn.CrossEntropyLoss(ignore_index) over [N,C,H,W]-logical logits with element strides (utils/loss.py:236-237).
+ * acc (double[2], device): zeroed here, then acc[0] = sum of per-pixel losses, acc[1] = number of valid pixels.
+ * pix (optional, float[N*H*W]): per-pixel loss as reduction='none' gives (0 at ignored pixels) -- OhemCELoss input.
+ * loss (optional, float[1]): acc[0]/acc[1]. */
+int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                     int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
+                     void* stream);
+/* OhemCELoss.forward_once (utils/loss.py:321-328) on the per-pixel losses: mean of losses > thresh, or, if fewer than
+ * n_min = acc[1]//16 qualify, mean of the n_min largest (device radix select, no host sync).
+ * st: double[5] scratch, ws: uint32[2052] scratch, loss: float[1], sel: float[4] selection record for the backward. */
+int myolo_ohem_select(const float* pix, int64_t total, float thresh, const double* acc, double* st, uint32_t* ws,
+                      float* loss, float* sel, void* stream);
+/* d loss / d logits = (softmax - onehot) * gout[0] / denom on the selected pixels (all valid pixels when sel == NULL). */
+int myolo_seg_ce_bwd(const void* logits, void* grad, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc,
+                     int64_t sh, int64_t sw, int64_t gsn, int64_t gsc, int64_t gsh, int64_t gsw, const int64_t* target,
+                     int ignore_index, const double* acc, const float* gout, const float* pix, const float* sel,
+                     float thresh, void* stream);
+
+/* ComputeLoss.__call__ + build_targets + bbox_iou(CIoU) (utils/loss.py:115-217, utils/general.py:343-380). */
+typedef struct myolo_detloss_desc {
+  int32_t nl, na, no, bs, nt, dtype;       /* levels, anchors/level, 5+nc, batch, target rows, dtype of p / gp */
+  const void* p[5];                        /* Detect training outputs [bs,na,ny,nx,no], dense */
+  void*       gp[5];                       /* their gradients (bwd only) */
+  int32_t ny[5], nx[5];
+  const float* anchors;                    /* [nl,na,2] in grid units (Detect.anchors, yolo.py:262), device */
+  const float* targets;                    /* [nt,6] (image, class, x, y, w, h) normalised, device */
+  float balance[5];                        /* loss.py:109 */
+  float box, obj, cls, cls_pw, obj_pw, anchor_t, gr, cp, cn;
+  int32_t* winner;                         /* workspace: int32 per cell of all levels */
+  float*   ciou;                           /* workspace: nl * 5*na*nt floats */
+  double*  acc;                            /* workspace: double[20] */
+  float*   out;                            /* float[5]: loss*bs, lbox, lobj, lcls, loss (loss.py:156-162) */
+  float*   gp32;                           /* bwd workspace when dtype is F16: fp32 copy of all gradients (atomics) */
+  const float* gout;                       /* bwd: d(objective)/d(out[0]), device scalar */
+} myolo_detloss_desc;
+int myolo_detloss_fwd(const myolo_detloss_desc* d, void* stream);
+int myolo_detloss_bwd(const myolo_detloss_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

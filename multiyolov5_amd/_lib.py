@@ -36,6 +36,16 @@ class WgradDesc(C.Structure):
                 ('ksplit', C.c_int32), ('cout', C.c_int32), ('cin', C.c_int32), ('reserved', C.c_int32)]
 
 
+class DetLossDesc(C.Structure):
+    _fields_ = [('nl', C.c_int32), ('na', C.c_int32), ('no', C.c_int32), ('bs', C.c_int32), ('nt', C.c_int32),
+                ('dtype', C.c_int32), ('p', C.c_void_p * 5), ('gp', C.c_void_p * 5), ('ny', C.c_int32 * 5),
+                ('nx', C.c_int32 * 5), ('anchors', C.c_void_p), ('targets', C.c_void_p), ('balance', C.c_float * 5),
+                ('box', C.c_float), ('obj', C.c_float), ('cls', C.c_float), ('cls_pw', C.c_float), ('obj_pw', C.c_float),
+                ('anchor_t', C.c_float), ('gr', C.c_float), ('cp', C.c_float), ('cn', C.c_float),
+                ('winner', C.c_void_p), ('ciou', C.c_void_p), ('acc', C.c_void_p), ('out', C.c_void_p),
+                ('gp32', C.c_void_p), ('gout', C.c_void_p)]
+
+
 class MyoloError(RuntimeError):
     pass
 
@@ -74,6 +84,13 @@ _PROTOS = {
     'myolo_detect_unpermute': (C.c_int, [P, C.c_int, C.c_int, C.c_int, TP, P]),
     'myolo_detect_decode': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.POINTER(C.c_float), P, C.c_int64, C.c_int64, P]),
+    'myolo_seg_ce_fwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                   P, C.c_int, P, P, P, P]),
+    'myolo_ohem_select': (C.c_int, [P, C.c_int64, C.c_float, P, P, P, P, P, P]),
+    'myolo_seg_ce_bwd': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                   C.c_int64, C.c_int64, C.c_int64, C.c_int64, P, C.c_int, P, P, P, P, C.c_float, P]),
+    'myolo_detloss_fwd': (C.c_int, [C.POINTER(DetLossDesc), P]),
+    'myolo_detloss_bwd': (C.c_int, [C.POINTER(DetLossDesc), P]),
 }
 
 

@@ -1,0 +1,570 @@
+// Losses of the joint det+seg step, fused per head (all HBM-bound streaming kernels, fp32 math, double accumulators).
+//   seg_ce_fwd / seg_ce_bwd : nn.CrossEntropyLoss(ignore_index) over [N,C,H,W] logits (reference utils/loss.py:236-237)
+//                             and OhemCELoss (utils/loss.py:303-328: per-pixel CE, keep loss > -log(thresh), else the
+//                             n_min = valid//16 hardest) -- the top-k fallback is a 3-pass radix select on device.
+//   detloss_fwd / detloss_bwd : ComputeLoss.__call__ + build_targets + bbox_iou(CIoU) (utils/loss.py:115-217,
+//                             utils/general.py:343-380): anchor matching, 5-neighbour expansion, CIoU, objectness target
+//                             scatter with the CPU's "last write wins" order, BCE obj / cls, and all gradients -- no host
+//                             sync, no boolean-mask indexing.
+#include "myolo_dev.h"
+
+namespace {
+
+struct Strided4 { void* ptr; int64_t sn, sc, sh, sw; int dtype; };
+__device__ __forceinline__ float ld_any(const void* p, int64_t i, int dt) {
+  return dt == MYOLO_F16 ? (float)((const half_t*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_any(void* p, int64_t i, int dt, float v) {
+  if (dt == MYOLO_F16) ((half_t*)p)[i] = (half_t)v; else ((float*)p)[i] = v;
+}
+
+constexpr int MAXC = 32;
+
+__device__ __forceinline__ double block_sum256(double v, double* sh) {
+  // wave reduce then across the 4 waves
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) sh[w] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+  __syncthreads();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------ segmentation CE
+// acc[0] += sum of per-pixel losses over valid pixels, acc[1] += number of valid pixels.
+// pix (optional): per-pixel loss (0 at ignored pixels), as CrossEntropyLoss(reduction='none') gives (loss.py:311,323)
+__global__ __launch_bounds__(256) void seg_ce_fwd_kernel(Strided4 x, const int64_t* tgt, int C, int H, int W, int64_t total,
+                                                         int ignore, double* acc, float* pix) {
+  __shared__ double sh[4];
+  double lsum = 0.0, lcnt = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W); const int y = (int)((i / W) % H); const int n = (int)(i / ((int64_t)W * H));
+    const int64_t t = tgt[i];
+    float l = 0.f;
+    if (t != ignore) {
+      const int64_t b = (int64_t)n * x.sn + (int64_t)y * x.sh + (int64_t)xx * x.sw;
+      float v[MAXC];
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) { v[c] = ld_any(x.ptr, b + (int64_t)c * x.sc, x.dtype); m = fmaxf(m, v[c]); }
+      float s = 0.f, xt = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c < C) { s += expf(v[c] - m); if (c == (int)t) xt = v[c]; }
+      l = (m + logf(s)) - xt;
+      lsum += (double)l;
+      lcnt += 1.0;
+    }
+    if (pix) pix[i] = l;
+  }
+  const double bs = block_sum256(lsum, sh);
+  const double bc = block_sum256(lcnt, sh);
+  if (threadIdx.x == 0) { atomicAdd(acc + 0, bs); atomicAdd(acc + 1, bc); }
+}
+
+// dlogit = (softmax - onehot) * w,  w = gout / denom for the selected pixels:
+//   plain CE : every valid pixel, denom = acc[1]
+//   OHEM     : sel[0] = mode (0: loss > thresh, 1: top-k), denom = sel[1];  top-k: loss > kth -> 1, loss == kth -> tie weight sel[3]
+struct OhemSel { float mode, denom, kth, tie_w; };
+__global__ __launch_bounds__(256) void seg_ce_bwd_kernel(Strided4 x, Strided4 g, const int64_t* tgt, int C, int H, int W,
+                                                         int64_t total, int ignore, const double* acc, const float* gout,
+                                                         const float* pix, const OhemSel* sel, float thresh) {
+  const float go = gout[0];
+  float wbase;
+  int mode = -1;
+  float kth = 0.f, tie_w = 0.f;
+  if (sel) {
+    mode = (int)sel->mode; kth = sel->kth; tie_w = sel->tie_w;
+    wbase = go / sel->denom;
+  } else {
+    wbase = (float)((double)go / acc[1]);
+  }
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % W); const int y = (int)((i / W) % H); const int n = (int)(i / ((int64_t)W * H));
+    const int64_t t = tgt[i];
+    const int64_t gb = (int64_t)n * g.sn + (int64_t)y * g.sh + (int64_t)xx * g.sw;
+    float w = (t != ignore) ? wbase : 0.f;
+    if (mode == 0) { if (!(pix[i] > thresh)) w = 0.f; }
+    else if (mode == 1) { const float l = pix[i]; w = l > kth ? wbase : (l == kth ? wbase * tie_w : 0.f); if (t == ignore) w = 0.f; }
+    if (w == 0.f) {
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < C) st_any(g.ptr, gb + (int64_t)c * g.sc, g.dtype, 0.f);
+      continue;
+    }
+    const int64_t b = (int64_t)n * x.sn + (int64_t)y * x.sh + (int64_t)xx * x.sw;
+    float v[MAXC];
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) { v[c] = ld_any(x.ptr, b + (int64_t)c * x.sc, x.dtype); m = fmaxf(m, v[c]); }
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) if (c < C) { v[c] = expf(v[c] - m); s += v[c]; }
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) st_any(g.ptr, gb + (int64_t)c * g.sc, g.dtype, (v[c] * inv - (c == (int)t ? 1.f : 0.f)) * w);
+  }
+}
+
+// ---- OHEM selection (loss.py:321-328) -------------------------------------------------------------------
+// ws layout (uint32 words): [0..2048) histogram, [2048] prefix bits, [2049] remaining k, [2050] pass shift
+// state (double): st[0] = sum(loss > thresh), st[1] = count(loss > thresh), st[2] = sum(loss > kth), st[3] = count(loss > kth),
+//                 st[4] = count(loss == kth)
+__global__ __launch_bounds__(256) void ohem_thresh_kernel(const float* pix, int64_t total, float thresh, double* st) {
+  __shared__ double sh[4];
+  double s = 0.0, c = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float l = pix[i];
+    if (l > thresh) { s += (double)l; c += 1.0; }
+  }
+  const double bs = block_sum256(s, sh), bc = block_sum256(c, sh);
+  if (threadIdx.x == 0) { atomicAdd(st + 0, bs); atomicAdd(st + 1, bc); }
+}
+// radix select of the k-th largest loss (losses are >= 0, so their IEEE bit patterns order like unsigned ints):
+// pass p histograms bits [shift, shift+nb) of the keys whose higher bits equal `prefix`
+__global__ __launch_bounds__(256) void ohem_hist_kernel(const float* pix, int64_t total, uint32_t* ws, int shift, int nb,
+                                                        uint32_t himask) {
+  __shared__ uint32_t h[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint32_t prefix = ws[2048];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint32_t k = __float_as_uint(pix[i]);
+    if ((k & himask) == prefix) atomicAdd(&h[(k >> shift) & ((1u << nb) - 1)], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256) if (h[i]) atomicAdd(&ws[i], h[i]);
+}
+// one workgroup: walk the histogram from the top bin down until the remaining k falls inside a bin
+__global__ __launch_bounds__(256) void ohem_pick_kernel(uint32_t* ws, int shift, int nb, const double* acc, int first) {
+  __shared__ uint32_t h[2048];
+  for (int i = threadIdx.x; i < 2048; i += 256) h[i] = ws[i];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t k = first ? (uint32_t)((int64_t)acc[1] / 16) : ws[2049];   // n_min = valid // 16 (loss.py:322)
+    if (k == 0) k = 1;                                                   // empty top-k: keep the select well-defined
+    const int bins = 1 << nb;
+    int b = bins - 1;
+    for (; b > 0; --b) {
+      if (h[b] >= k) break;
+      k -= h[b];
+    }
+    ws[2048] |= ((uint32_t)b) << shift;
+    ws[2049] = k;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2048; i += 256) ws[i] = 0;
+}
+__global__ __launch_bounds__(256) void ohem_topk_sum_kernel(const float* pix, int64_t total, const uint32_t* ws, double* st) {
+  __shared__ double sh[4];
+  const float kth = __uint_as_float(ws[2048]);
+  double s = 0.0, c = 0.0, e = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float l = pix[i];
+    if (l > kth) { s += (double)l; c += 1.0; }
+    else if (l == kth) e += 1.0;
+  }
+  const double bs = block_sum256(s, sh), bc = block_sum256(c, sh), be = block_sum256(e, sh);
+  if (threadIdx.x == 0) { atomicAdd(st + 2, bs); atomicAdd(st + 3, bc); atomicAdd(st + 4, be); }
+}
+// loss value + selection record for backward
+__global__ void ohem_final_kernel(const double* acc, const double* st, const uint32_t* ws, float* loss, OhemSel* sel) {
+  const double n_min = (double)((int64_t)acc[1] / 16);
+  if (st[1] >= n_min) {                      // enough hard pixels above the threshold (loss.py:325-326 not taken)
+    loss[0] = (float)(st[0] / st[1]);
+    sel->mode = 0.f; sel->denom = (float)st[1]; sel->kth = 0.f; sel->tie_w = 0.f;
+  } else {                                   // loss.topk(n_min) (loss.py:326)
+    const float kth = __uint_as_float(ws[2048]);
+    const double need = n_min - st[3];       // how many of the tied losses belong to the top-k
+    loss[0] = (float)((st[2] + need * (double)kth) / n_min);
+    sel->mode = 1.f; sel->denom = (float)n_min; sel->kth = kth;
+    sel->tie_w = st[4] > 0.0 ? (float)(need / st[4]) : 0.f;
+  }
+}
+__global__ void ce_final_kernel(const double* acc, float* loss) { loss[0] = (float)(acc[0] / acc[1]); }
+
+inline bool strided_ok(const void* p, int dt) { return p && (dt == MYOLO_F16 || dt == MYOLO_F32); }
+
+}  // namespace
+
+extern "C" int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                                int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
+                                void* stream) {
+  if (!strided_ok(logits, dtype) || !target || !acc || c < 1 || c > MAXC || n < 1 || h < 1 || w < 1) return MYOLO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  const int64_t total = (int64_t)n * h * w;
+  Strided4 x{const_cast<void*>(logits), sn, sc, sh, sw, dtype};
+  hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, x, target, c, h, w, total,
+                     ignore_index, acc, pix);
+  MYOLO_CHECK_LAUNCH();
+  if (loss) {
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, st, acc, loss);
+    MYOLO_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int myolo_ohem_select(const float* pix, int64_t total, float thresh, const double* acc, double* st,
+                                 uint32_t* ws, float* loss, float* sel, void* stream) {
+  if (!pix || !acc || !st || !ws || !loss || !sel || total < 1) return MYOLO_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(st, 0, 5 * sizeof(double), s);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(ws, 0, 2052 * sizeof(uint32_t), s);
+  if (e != hipSuccess) return (int)e;
+  const int grid = grid_for(total, 256, 2048);
+  hipLaunchKernelGGL(ohem_thresh_kernel, dim3(grid), dim3(256), 0, s, pix, total, thresh, st);
+  // 32-bit keys in passes of 11 + 11 + 10 bits
+  const int shifts[3] = {21, 10, 0}, nbs[3] = {11, 11, 10};
+  for (int p = 0; p < 3; ++p) {
+    const uint32_t himask = p == 0 ? 0u : (0xffffffffu << (shifts[p] + nbs[p]));
+    hipLaunchKernelGGL(ohem_hist_kernel, dim3(grid), dim3(256), 0, s, pix, total, ws, shifts[p], nbs[p], himask);
+    hipLaunchKernelGGL(ohem_pick_kernel, dim3(1), dim3(256), 0, s, ws, shifts[p], nbs[p], acc, p == 0 ? 1 : 0);
+  }
+  hipLaunchKernelGGL(ohem_topk_sum_kernel, dim3(grid), dim3(256), 0, s, pix, total, ws, st);
+  hipLaunchKernelGGL(ohem_final_kernel, dim3(1), dim3(1), 0, s, acc, st, ws, loss, reinterpret_cast<OhemSel*>(sel));
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_seg_ce_bwd(const void* logits, void* grad, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc,
+                                int64_t sh, int64_t sw, int64_t gsn, int64_t gsc, int64_t gsh, int64_t gsw,
+                                const int64_t* target, int ignore_index, const double* acc, const float* gout,
+                                const float* pix, const float* sel, float thresh, void* stream) {
+  if (!strided_ok(logits, dtype) || !grad || !target || !acc || !gout || c < 1 || c > MAXC) return MYOLO_EINVAL;
+  if ((sel != nullptr) != (pix != nullptr)) return MYOLO_EINVAL;
+  const int64_t total = (int64_t)n * h * w;
+  Strided4 x{const_cast<void*>(logits), sn, sc, sh, sw, dtype}, g{grad, gsn, gsc, gsh, gsw, dtype};
+  hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, g, target, c,
+                     h, w, total, ignore_index, acc, gout, pix, reinterpret_cast<const OhemSel*>(sel), thresh);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+// ================================================================================================ detection
+namespace {
+
+struct DetK {
+  int nl, na, no, bs, nt, dtype;
+  const void* p[5]; void* gp[5];
+  int ny[5], nx[5];
+  int64_t cell0[5];          // first cell of level l in the concatenated cell index space
+  const float* anchors; const float* targets;
+  float balance[5];
+  float box, obj, cls, cls_pw, obj_pw, anchor_t, gr, cp, cn;
+  int* winner; float* ciou; double* acc; float* out; float* gp32; const float* gout;
+};
+
+// forward-mode dual number over the 4 predicted box parameters (x, y, w, h)
+struct D4 {
+  float v, d[4];
+};
+__device__ __forceinline__ D4 dc(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 operator+(const D4& a, const D4& b) { return D4{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}}; }
+__device__ __forceinline__ D4 operator-(const D4& a, const D4& b) { return D4{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}}; }
+__device__ __forceinline__ D4 operator*(const D4& a, const D4& b) {
+  D4 r; r.v = a.v * b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = a.d[i] * b.v + a.v * b.d[i];
+  return r;
+}
+__device__ __forceinline__ D4 operator/(const D4& a, const D4& b) {
+  D4 r; r.v = a.v / b.v;
+  const float inv = 1.f / b.v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+  return r;
+}
+__device__ __forceinline__ D4 operator*(const D4& a, float s) { return D4{a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s, a.d[3] * s}}; }
+__device__ __forceinline__ D4 operator+(const D4& a, float s) { D4 r = a; r.v += s; return r; }
+__device__ __forceinline__ D4 dmin(const D4& a, const D4& b) { return a.v <= b.v ? a : b; }   // torch.min/max: tie -> first arg's value; grad split ignored (measure-zero)
+__device__ __forceinline__ D4 dmax(const D4& a, const D4& b) { return a.v >= b.v ? a : b; }
+__device__ __forceinline__ D4 dclamp0(const D4& a) { return a.v > 0.f ? a : (a.v == 0.f ? D4{0.f, {a.d[0], a.d[1], a.d[2], a.d[3]}} : dc(0.f)); }
+__device__ __forceinline__ D4 datan(const D4& a) {
+  const float g = 1.f / (1.f + a.v * a.v);
+  return D4{atanf(a.v), {a.d[0] * g, a.d[1] * g, a.d[2] * g, a.d[3] * g}};
+}
+
+// bbox_iou(box1=pbox, box2=tbox, x1y1x2y2=False, CIoU=True) (general.py:343-380), gradients w.r.t. pbox; alpha is constant
+// (computed under torch.no_grad, general.py:378-379)
+__device__ __forceinline__ D4 ciou_dual(const D4 px, const D4 py, const D4 pw, const D4 ph, float tx, float ty, float tw, float th) {
+  const float eps = 1e-7f;
+  const D4 b1x1 = px - pw * 0.5f, b1x2 = px + pw * 0.5f, b1y1 = py - ph * 0.5f, b1y2 = py + ph * 0.5f;
+  const float b2x1 = tx - tw / 2, b2x2 = tx + tw / 2, b2y1 = ty - th / 2, b2y2 = ty + th / 2;
+  const D4 iw = dclamp0(dmin(b1x2, dc(b2x2)) - dmax(b1x1, dc(b2x1)));
+  const D4 ih = dclamp0(dmin(b1y2, dc(b2y2)) - dmax(b1y1, dc(b2y1)));
+  const D4 inter = iw * ih;
+  const D4 w1 = b1x2 - b1x1, h1 = (b1y2 - b1y1) + eps;
+  const float w2 = b2x2 - b2x1, h2 = b2y2 - b2y1 + eps;
+  const D4 uni = ((w1 * h1 + w2 * h2) - inter) + eps;
+  const D4 iou = inter / uni;
+  const D4 cw = dmax(b1x2, dc(b2x2)) - dmin(b1x1, dc(b2x1));
+  const D4 ch = dmax(b1y2, dc(b2y2)) - dmin(b1y1, dc(b2y1));
+  const D4 c2 = (cw * cw + ch * ch) + eps;
+  const D4 dxs = (dc(b2x1 + b2x2) - b1x1) - b1x2, dys = (dc(b2y1 + b2y2) - b1y1) - b1y2;
+  const D4 rho2 = (dxs * dxs + dys * dys) * 0.25f;
+  const D4 at = dc(atanf(w2 / h2)) - datan(w1 / h1);
+  const D4 v = (at * at) * (4.f / (3.14159265358979323846f * 3.14159265358979323846f));
+  const float alpha = v.v / (v.v - iou.v + (1.f + eps));
+  return iou - (rho2 / c2 + v * alpha);
+}
+
+__device__ __forceinline__ float bce_logits(float x, float t, float pw) {
+  // binary_cross_entropy_with_logits with pos_weight: (1-t)*x + (1+(pw-1)*t) * (log1p(exp(-|x|)) + max(-x,0))
+  const float lw = 1.f + (pw - 1.f) * t;
+  return (1.f - t) * x + lw * (log1pf(expf(-fabsf(x))) + fmaxf(-x, 0.f));
+}
+__device__ __forceinline__ float bce_logits_grad(float x, float t, float pw) {
+  const float lw = 1.f + (pw - 1.f) * t;
+  const float s = 1.f / (1.f + expf(-x));
+  return (1.f - t) - lw * (1.f - s);
+}
+
+struct Cand {
+  bool valid; int b, a, cls, gj, gi; float tx, ty, tw, th, aw, ah;
+};
+// candidate (o, a, t) of level l in the reference's row order: offset-major, then anchor, then target (loss.py:170,189,197)
+__device__ __forceinline__ Cand make_cand(const DetK& k, int l, int idx) {
+  Cand c;
+  const int per_o = k.na * k.nt;
+  const int o = idx / per_o; const int r = idx - o * per_o; const int a = r / k.nt; const int t = r - a * k.nt;
+  const float* tg = k.targets + (int64_t)t * 6;
+  const float nx = (float)k.nx[l], ny = (float)k.ny[l];
+  const float gx = tg[2] * nx, gy = tg[3] * ny, gw = tg[4] * nx, gh = tg[5] * ny;
+  const float aw = k.anchors[(l * k.na + a) * 2], ah = k.anchors[(l * k.na + a) * 2 + 1];
+  const float rw = gw / aw, rh = gh / ah;
+  const float mr = fmaxf(fmaxf(rw, 1.f / rw), fmaxf(rh, 1.f / rh));
+  bool ok = mr < k.anchor_t;                                          // loss.py:186-187
+  float ox = 0.f, oy = 0.f;
+  if (o == 1) { ok = ok && (gx - floorf(gx) < 0.5f) && gx > 1.f; ox = 0.5f; }
+  else if (o == 2) { ok = ok && (gy - floorf(gy) < 0.5f) && gy > 1.f; oy = 0.5f; }
+  else if (o == 3) { const float q = nx - gx; ok = ok && (q - floorf(q) < 0.5f) && q > 1.f; ox = -0.5f; }
+  else if (o == 4) { const float q = ny - gy; ok = ok && (q - floorf(q) < 0.5f) && q > 1.f; oy = -0.5f; }
+  c.valid = ok;
+  int gi = (int)(gx - ox), gj = (int)(gy - oy);                        // .long() truncates toward zero (loss.py:206)
+  gi = gi < 0 ? 0 : (gi > k.nx[l] - 1 ? k.nx[l] - 1 : gi);             // clamp_ in place (loss.py:212) -> tbox sees it too
+  gj = gj < 0 ? 0 : (gj > k.ny[l] - 1 ? k.ny[l] - 1 : gj);
+  c.gi = gi; c.gj = gj;
+  c.b = (int)tg[0]; c.cls = (int)tg[1]; c.a = a;
+  c.tx = gx - (float)gi; c.ty = gy - (float)gj; c.tw = gw; c.th = gh;
+  c.aw = aw; c.ah = ah;
+  if (c.b < 0 || c.b >= k.bs) c.valid = false;
+  return c;
+}
+__device__ __forceinline__ int64_t cell_of(const DetK& k, int l, const Cand& c) {
+  return (((int64_t)c.b * k.na + c.a) * k.ny[l] + c.gj) * k.nx[l] + c.gi;
+}
+
+// pass A: per candidate CIoU / box + class loss sums / objectness-target winner
+__global__ __launch_bounds__(256) void det_cand_fwd_kernel(const DetK k) {
+  __shared__ double sh[4];
+  const int l = blockIdx.y;
+  const int ncand = 5 * k.na * k.nt;
+  double sbox = 0.0, scnt = 0.0, scls = 0.0;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncand; idx += gridDim.x * blockDim.x) {
+    const Cand c = make_cand(k, l, idx);
+    float ci = 0.f;
+    if (c.valid) {
+      const int64_t cell = cell_of(k, l, c);
+      const int64_t row = cell * k.no;
+      const float s0 = sigmoid_f(ld_any(k.p[l], row + 0, k.dtype)), s1 = sigmoid_f(ld_any(k.p[l], row + 1, k.dtype));
+      const float s2 = sigmoid_f(ld_any(k.p[l], row + 2, k.dtype)), s3 = sigmoid_f(ld_any(k.p[l], row + 3, k.dtype));
+      const float px = s0 * 2.f - 0.5f, py = s1 * 2.f - 0.5f;
+      const float pw = (s2 * 2.f) * (s2 * 2.f) * c.aw, ph = (s3 * 2.f) * (s3 * 2.f) * c.ah;
+      ci = ciou_dual(dc(px), dc(py), dc(pw), dc(ph), c.tx, c.ty, c.tw, c.th).v;
+      sbox += (double)(1.f - ci);
+      scnt += 1.0;
+      const int nc = k.no - 5;
+      if (nc > 1)
+        for (int j = 0; j < nc; ++j)
+          scls += (double)bce_logits(ld_any(k.p[l], row + 5 + j, k.dtype), j == c.cls ? k.cp : k.cn, k.cls_pw);
+      atomicMax(k.winner + k.cell0[l] + cell, idx);
+    }
+    k.ciou[(int64_t)l * ncand + idx] = ci;
+  }
+  const double a = block_sum256(sbox, sh), b = block_sum256(scnt, sh), c2 = block_sum256(scls, sh);
+  if (threadIdx.x == 0) { atomicAdd(k.acc + l * 4 + 0, a); atomicAdd(k.acc + l * 4 + 1, b); atomicAdd(k.acc + l * 4 + 2, c2); }
+}
+
+__device__ __forceinline__ int level_of(const DetK& k, int64_t cell, int64_t& local) {
+  int l = 0;
+  while (l + 1 < k.nl && cell >= k.cell0[l + 1]) ++l;
+  local = cell - k.cell0[l];
+  return l;
+}
+__device__ __forceinline__ float tobj_of(const DetK& k, int l, int64_t cell_global) {
+  const int wi = k.winner[cell_global];
+  if (wi < 0) return 0.f;
+  const float ci = k.ciou[(int64_t)l * (5 * k.na * k.nt) + wi];
+  return (1.f - k.gr) + k.gr * fmaxf(ci, 0.f);                        // loss.py:137
+}
+
+// pass B: objectness BCE over every cell of every level
+__global__ __launch_bounds__(256) void det_obj_fwd_kernel(const DetK k, int64_t ncell) {
+  __shared__ double sh[4];
+  double s[5] = {0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t local;
+    const int l = level_of(k, i, local);
+    const float x = ld_any(k.p[l], local * k.no + 4, k.dtype);
+    s[l] += (double)bce_logits(x, tobj_of(k, l, i), k.obj_pw);
+  }
+  for (int l = 0; l < k.nl; ++l) {
+    const double v = block_sum256(s[l], sh);
+    if (threadIdx.x == 0 && v != 0.0) atomicAdd(k.acc + l * 4 + 3, v);
+  }
+}
+
+__global__ void det_final_kernel(const DetK k) {
+  double lbox = 0, lobj = 0, lcls = 0;
+  const int nc = k.no - 5;
+  for (int l = 0; l < k.nl; ++l) {
+    const double n = k.acc[l * 4 + 1];
+    if (n > 0) {
+      lbox += k.acc[l * 4 + 0] / n;
+      if (nc > 1) lcls += k.acc[l * 4 + 2] / (n * nc);
+    }
+    const double cells = (double)k.bs * k.na * k.ny[l] * k.nx[l];
+    lobj += k.acc[l * 4 + 3] / cells * (double)k.balance[l];
+  }
+  lbox *= k.box; lobj *= k.obj; lcls *= k.cls;
+  const double loss = lbox + lobj + lcls;
+  k.out[0] = (float)(loss * k.bs); k.out[1] = (float)lbox; k.out[2] = (float)lobj; k.out[3] = (float)lcls; k.out[4] = (float)loss;
+}
+
+// backward pass 1: every cell row = zeros except the objectness logit gradient
+template <typename GT>
+__global__ __launch_bounds__(256) void det_obj_bwd_kernel(const DetK k, int64_t ncell, GT* const g0, GT* const g1, GT* const g2,
+                                                          GT* const g3, GT* const g4) {
+  const float go = k.gout[0] * (float)k.bs;
+  GT* const gs[5] = {g0, g1, g2, g3, g4};
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ncell; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t local;
+    const int l = level_of(k, i, local);
+    const float x = ld_any(k.p[l], local * k.no + 4, k.dtype);
+    const float cells = (float)k.bs * k.na * k.ny[l] * k.nx[l];
+    const float g = bce_logits_grad(x, tobj_of(k, l, i), k.obj_pw) * (go * k.obj * k.balance[l] / cells);
+    GT* row = gs[l] + local * k.no;
+    for (int j = 0; j < k.no; ++j) row[j] = (GT)(j == 4 ? g : 0.f);
+  }
+}
+// backward pass 2: box + class gradients of the matched cells (several candidates may hit one cell -> fp32 atomics)
+__global__ __launch_bounds__(256) void det_cand_bwd_kernel(const DetK k, float* const g0, float* const g1, float* const g2,
+                                                           float* const g3, float* const g4) {
+  const int l = blockIdx.y;
+  float* const gs[5] = {g0, g1, g2, g3, g4};
+  const int ncand = 5 * k.na * k.nt;
+  const double n = k.acc[l * 4 + 1];
+  if (n <= 0) return;
+  const float go = k.gout[0] * (float)k.bs;
+  const int nc = k.no - 5;
+  const float wbox = -go * k.box / (float)n;                 // d(1 - ciou).mean()
+  const float wcls = nc > 1 ? go * k.cls / (float)(n * nc) : 0.f;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < ncand; idx += gridDim.x * blockDim.x) {
+    const Cand c = make_cand(k, l, idx);
+    if (!c.valid) continue;
+    const int64_t row = cell_of(k, l, c) * k.no;
+    float s[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[j] = sigmoid_f(ld_any(k.p[l], row + j, k.dtype));
+    D4 px = dc(s[0] * 2.f - 0.5f), py = dc(s[1] * 2.f - 0.5f);
+    D4 pw = dc((s[2] * 2.f) * (s[2] * 2.f) * c.aw), ph = dc((s[3] * 2.f) * (s[3] * 2.f) * c.ah);
+    px.d[0] = 1.f; py.d[1] = 1.f; pw.d[2] = 1.f; ph.d[3] = 1.f;
+    const D4 ci = ciou_dual(px, py, pw, ph, c.tx, c.ty, c.tw, c.th);
+    // chain through the decode: dpx/dx = 2 s(1-s); dpw/dx = 8 s^2 (1-s) * anchor
+    const float dd[4] = {2.f * s[0] * (1.f - s[0]), 2.f * s[1] * (1.f - s[1]),
+                         8.f * s[2] * s[2] * (1.f - s[2]) * c.aw, 8.f * s[3] * s[3] * (1.f - s[3]) * c.ah};
+    float* g = gs[l] + row;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) atomicAdd(g + j, wbox * ci.d[j] * dd[j]);
+    if (nc > 1)
+      for (int j = 0; j < nc; ++j)
+        atomicAdd(g + 5 + j, wcls * bce_logits_grad(ld_any(k.p[l], row + 5 + j, k.dtype), j == c.cls ? k.cp : k.cn, k.cls_pw));
+  }
+}
+__global__ __launch_bounds__(256) void cast_f32_to_f16_kernel(const float* src, half_t* dst, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    dst[i] = (half_t)src[i];
+}
+
+int fill_detk(const myolo_detloss_desc* d, DetK& k, int64_t& ncell) {
+  if (!d || d->nl < 1 || d->nl > 5 || d->na < 1 || d->no < 5 || d->no - 5 > 256 || d->bs < 1 || d->nt < 0) return MYOLO_EINVAL;
+  if (d->dtype != MYOLO_F16 && d->dtype != MYOLO_F32) return MYOLO_EINVAL;
+  if (!d->anchors || (!d->targets && d->nt > 0) || !d->winner || !d->ciou || !d->acc || !d->out) return MYOLO_EINVAL;
+  k.nl = d->nl; k.na = d->na; k.no = d->no; k.bs = d->bs; k.nt = d->nt; k.dtype = d->dtype;
+  ncell = 0;
+  for (int l = 0; l < 5; ++l) {
+    k.p[l] = l < d->nl ? d->p[l] : nullptr; k.gp[l] = l < d->nl ? d->gp[l] : nullptr;
+    k.ny[l] = l < d->nl ? d->ny[l] : 0; k.nx[l] = l < d->nl ? d->nx[l] : 0;
+    k.balance[l] = d->balance[l];
+    k.cell0[l] = ncell;
+    if (l < d->nl) {
+      if (!d->p[l] || d->ny[l] < 1 || d->nx[l] < 1) return MYOLO_EINVAL;
+      ncell += (int64_t)d->bs * d->na * d->ny[l] * d->nx[l];
+    }
+  }
+  k.anchors = d->anchors; k.targets = d->targets;
+  k.box = d->box; k.obj = d->obj; k.cls = d->cls; k.cls_pw = d->cls_pw; k.obj_pw = d->obj_pw; k.anchor_t = d->anchor_t;
+  k.gr = d->gr; k.cp = d->cp; k.cn = d->cn;
+  k.winner = d->winner; k.ciou = d->ciou; k.acc = d->acc; k.out = d->out; k.gp32 = d->gp32; k.gout = d->gout;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int myolo_detloss_fwd(const myolo_detloss_desc* d, void* stream) {
+  DetK k; int64_t ncell;
+  int r = fill_detk(d, k, ncell);
+  if (r) return r;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(k.winner, 0xff, ncell * sizeof(int), st);      // -1
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(k.acc, 0, 5 * 4 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  const int ncand = 5 * k.na * k.nt;
+  if (ncand > 0) {
+    hipLaunchKernelGGL(det_cand_fwd_kernel, dim3(grid_for(ncand, 256, 256), k.nl), dim3(256), 0, st, k);
+    MYOLO_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(det_obj_fwd_kernel, dim3(grid_for(ncell, 256, 1024)), dim3(256), 0, st, k, ncell);
+  hipLaunchKernelGGL(det_final_kernel, dim3(1), dim3(1), 0, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_detloss_bwd(const myolo_detloss_desc* d, void* stream) {
+  DetK k; int64_t ncell;
+  int r = fill_detk(d, k, ncell);
+  if (r) return r;
+  if (!k.gout) return MYOLO_EINVAL;
+  for (int l = 0; l < k.nl; ++l) if (!k.gp[l]) return MYOLO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  const int ncand = 5 * k.na * k.nt;
+  const int grid = grid_for(ncell, 256, 1024);
+  if (k.dtype == MYOLO_F32) {
+    float* g[5];
+    for (int l = 0; l < 5; ++l) g[l] = (float*)k.gp[l];
+    hipLaunchKernelGGL(det_obj_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, k, ncell, g[0], g[1], g[2], g[3], g[4]);
+    if (ncand > 0)
+      hipLaunchKernelGGL(det_cand_bwd_kernel, dim3(grid_for(ncand, 256, 256), k.nl), dim3(256), 0, st, k, g[0], g[1], g[2], g[3], g[4]);
+  } else {
+    if (!k.gp32) return MYOLO_EINVAL;     // fp32 staging: atomics on fp32, then one cast pass into the fp16 gradients
+    float* g[5];
+    for (int l = 0; l < 5; ++l) g[l] = k.gp32 + k.cell0[l] * k.no;
+    hipLaunchKernelGGL(det_obj_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, k, ncell, g[0], g[1], g[2], g[3], g[4]);
+    if (ncand > 0)
+      hipLaunchKernelGGL(det_cand_bwd_kernel, dim3(grid_for(ncand, 256, 256), k.nl), dim3(256), 0, st, k, g[0], g[1], g[2], g[3], g[4]);
+    for (int l = 0; l < k.nl; ++l) {
+      const int64_t n = (int64_t)k.bs * k.na * k.ny[l] * k.nx[l] * k.no;
+      hipLaunchKernelGGL(cast_f32_to_f16_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, g[l], (half_t*)k.gp[l], n);
+    }
+  }
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

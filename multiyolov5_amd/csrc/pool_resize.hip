@@ -257,6 +257,71 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(myolo_tensor gout, my
   }
 }
 
+// large-footprint variant (PyramidPooling: 1x1..6x6 -> 64x128, common.py:534-537): one workgroup per (input pixel,
+// block of <=8 channel groups); the 256 threads stride over the pixel's output footprint and reduce through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_big_kernel(myolo_tensor gout, myolo_tensor gx, float sy, float sx, int acc,
+                                                               int gb) {
+  constexpr int SEG = ET<T>::SEG;
+  __shared__ float red[256 * 8];
+  const int G = gx.c / SEG;
+  const int nblk_c = (G + gb - 1) / gb;
+  int b = blockIdx.x;
+  const int cb = b % nblk_c; b /= nblk_c;
+  const int xx = b % gx.w; b /= gx.w;
+  const int y = b % gx.h; const int n = b / gx.h;
+  const int cgl = threadIdx.x % gb, lane = threadIdx.x / gb, lanes = 256 / gb;
+  const int cg = cb * gb + cgl;
+  int ylo, yhi, xlo, xhi;
+  out_range(y, gx.h, gout.h, sy, ylo, yhi);
+  out_range(xx, gx.w, gout.w, sx, xlo, xhi);
+  const int fw = xhi - xlo + 1, fp = (yhi - ylo + 1) * fw;
+  float a[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+  if (cg < G)
+    for (int p = lane; p < fp; p += lanes) {
+      const int oy = ylo + p / fw, ox = xlo + p % fw;
+      const float fy = sy * (float)oy, fx = sx * (float)ox;
+      const int y0 = (int)fy, x0 = (int)fx;
+      const int y1 = y0 + 1 < gx.h ? y0 + 1 : gx.h - 1, x1 = x0 + 1 < gx.w ? x0 + 1 : gx.w - 1;
+      const float ly = fy - (float)y0, lx = fx - (float)x0;
+      float wy = 0.f, wx = 0.f;
+      if (y0 == y) wy += 1.f - ly;
+      if (y1 == y) wy += ly;
+      if (x0 == xx) wx += 1.f - lx;
+      if (x1 == xx) wx += lx;
+      const float wgt = wy * wx;
+      if (wgt == 0.f) continue;
+      float f[SEG];
+      Vec<T>::unpack(ldg16(vptr<T>(gout, n, oy, ox) + cg * SEG), f);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += wgt * f[i];
+    }
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) red[threadIdx.x * 8 + i] = a[i];
+  __syncthreads();
+  for (int stride = lanes >> 1; stride > 0; stride >>= 1) {
+    if (lane < stride)
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) red[threadIdx.x * 8 + i] += red[(threadIdx.x + stride * gb) * 8 + i];
+    __syncthreads();
+  }
+  if (lane == 0 && cg < G) {
+    float o[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) o[i] = red[threadIdx.x * 8 + i];
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float q[SEG];
+      Vec<T>::unpack(ldg16(gp), q);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) o[i] += q[i];
+    }
+    stg16(gp, Vec<T>::pack(o));
+  }
+}
+
 // ---------------------------------------------------------------- adaptive average pool
 // bin i of k over H: [floor(i*H/k), ceil((i+1)*H/k))
 template <typename T>
@@ -515,6 +580,18 @@ extern "C" int myolo_bilinear_fwd(const myolo_tensor* x, const myolo_tensor* out
 }
 extern "C" int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream) {
   if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
+  const int64_t foot = (int64_t)(gout->h / (gx->h > 0 ? gx->h : 1)) * (gout->w / (gx->w > 0 ? gx->w : 1));
+  if (foot >= 64) {   // few input pixels, each gathering thousands of outputs: a workgroup per input pixel
+    const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
+    const int G = gx->c / seg;
+    int gb = 1;
+    while (gb < 8 && gb < G) gb <<= 1;
+    const int64_t blocks = (int64_t)gx->n * gx->h * gx->w * ((G + gb - 1) / gb);
+    if (blocks > 0x7fffffff) return MYOLO_EINVAL;
+    DISPATCH(gx->dtype, bilinear_bwd_big_kernel, (int)blocks, 256, 0, (hipStream_t)stream, *gout, *gx,
+             ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), accumulate, gb);
+    return 0;
+  }
   DISPATCH(gx->dtype, bilinear_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx,
            ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), accumulate);
   return 0;

@@ -67,10 +67,10 @@ def build_targets(p, targets, anchors, anchor_t=4.0):
         b, c = t[:, :2].long().T
         gxy, gwh = t[:, 2:4], t[:, 4:6]
         gij = (gxy - offsets).long()
-        gi, gj = gij.T
-        a = t[:, 6].long()
-        gj = gj.clamp(0, ny - 1)      # loss.py:212 (clamp_ with int bounds: the torch>=1.10 compatibility fix)
-        gi = gi.clamp(0, nx - 1)
+        gi, gj = gij.T                # views of gij: the reference clamps them IN PLACE (loss.py:212), so tbox (213) sees
+        a = t[:, 6].long()            # the clamped cell too
+        gj.clamp_(0, ny - 1)          # loss.py:212 (int bounds: the torch>=1.10 compatibility fix)
+        gi.clamp_(0, nx - 1)
         out.append((b, a, gj, gi, torch.cat((gxy - gij, gwh), 1), anchors[i][a], c))
     return out
 
@@ -92,7 +92,14 @@ def compute_loss(p, targets, anchors, hyp, gr=1.0, balance=(4.0, 1.0, 0.4)):
             pwh = (ps[:, 2:4].sigmoid() * 2) ** 2 * anch
             iou = ciou_xywh(torch.cat((pxy, pwh), 1), tbox)
             lbox = lbox + (1.0 - iou).mean()
-            tobj[b, a, gj, gi] = (1.0 - gr) + gr * iou.detach().clamp(0).type(tobj.dtype)   # last write wins
+            # loss.py:137 `tobj[b, a, gj, gi] = ...` with duplicate cells: index_put_ without accumulate is sequential on
+            # one CPU thread (rows < the parallel grain), i.e. the LAST row of a cell wins.  Stated explicitly so the
+            # oracle stays deterministic when torch parallelises large scatters.
+            val = (1.0 - gr) + gr * iou.detach().clamp(0).type(tobj.dtype)
+            lin = ((b * pi.shape[1] + a) * pi.shape[2] + gj) * pi.shape[3] + gi
+            win = torch.full((tobj.numel(),), -1, dtype=torch.long).scatter_reduce(0, lin, torch.arange(n), 'amax')
+            rows = win[win >= 0]
+            tobj.view(-1)[lin[rows]] = val[rows]
             if nc > 1:
                 t = torch.full_like(ps[:, 5:], cn)
                 t[range(n), tcls] = cp

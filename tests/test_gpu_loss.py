@@ -1,0 +1,138 @@
+"""-m gpu: the fused loss kernels (C ABI: myolo_detloss_*, myolo_seg_ce_*, myolo_ohem_select) through the reference's
+ComputeLoss / SegmentationLosses / OhemCELoss API, against the golden vectors generated from the reference itself
+(tests/golden/losses.npz) and against the CPU oracle at other sizes."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_ref, synth
+from tests.gpu_util import check
+from tests.util import golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def fake_model(anchors, hyp, nc=10):
+    det = types.SimpleNamespace(na=anchors.shape[1], nc=nc, nl=anchors.shape[0], anchors=torch.as_tensor(anchors).to(DEV))
+    return types.SimpleNamespace(hyp=hyp, gr=1.0, model=[det])
+
+
+@pytest.mark.parametrize('ls', [0.0, 0.1], ids=['ls0', 'ls1'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+def test_compute_loss_matches_reference_golden(ls, dtype):
+    from multiyolov5_amd.utils.loss import ComputeLoss
+    g = golden('losses')
+    tag = f'ls{int(ls * 10)}'
+    hyp = loss_ref.scaled_hyp(1024, 10, 3, label_smoothing=ls)
+    cl = ComputeLoss(fake_model(g['anchors'], hyp))
+    p = [torch.from_numpy(g[f'det_p{i}']).to(DEV, dtype).requires_grad_() for i in range(3)]
+    targets = torch.from_numpy(g['det_targets']).to(DEV)
+    loss, items = cl(p, targets)
+    (loss * 0.6).sum().backward()
+    tol = 2e-5 if dtype == torch.float32 else 3e-3
+    check(f'detloss/{tag}/loss', loss, g[f'det_{tag}_loss'], tol)
+    check(f'detloss/{tag}/items', items, g[f'det_{tag}_items'], tol)
+    for i in range(3):
+        check(f'detloss/{tag}/grad{i}', p[i].grad, g[f'det_{tag}_grad{i}'] * 0.6, 1e-4 if dtype == torch.float32 else 2e-2)
+    assert loss.shape == (1,) and items.shape == (4,)
+
+
+def test_compute_loss_empty_targets_and_border_rows():
+    from multiyolov5_amd.utils.loss import ComputeLoss
+    g = golden('losses')
+    cl = ComputeLoss(fake_model(g['anchors'], loss_ref.scaled_hyp(1024, 10, 3, label_smoothing=0.1)))
+    p = [torch.from_numpy(g[f'det_p{i}']).to(DEV).requires_grad_() for i in range(3)]
+    loss, items = cl(p, torch.zeros(0, 6, device=DEV))
+    check('detloss/empty/loss', loss, g['det_empty_loss'], 2e-5)
+    check('detloss/empty/items', items, g['det_empty_items'], 2e-5)
+    loss.sum().backward()
+    assert all(torch.isfinite(q.grad).all() for q in p)
+    assert float(p[0].grad[..., :4].abs().max()) == 0.0          # no matches: only the objectness logit has a gradient
+
+
+@pytest.mark.parametrize('nt', [1, 200, 1500])
+def test_compute_loss_vs_oracle_other_sizes(nt):
+    """larger grids / many targets (duplicate cells, clamped border cells) against the CPU restatement."""
+    from multiyolov5_amd.utils.loss import ComputeLoss
+    g = golden('losses')
+    rs = np.random.RandomState(11 + nt)
+    B, nc = 4, 10
+    shapes = ((32, 64), (16, 32), (8, 16))
+    pc = [torch.from_numpy(rs.normal(0, 1.5, (B, 3, ny, nx, 5 + nc)).astype(np.float32)).requires_grad_() for ny, nx in shapes]
+    t = synth.synth_det_targets(B, max(nt // B, 1), nc, seed=9)[:nt]
+    t[: min(4, nt), 2:4] = torch.tensor([[0.001, 0.5], [0.999, 0.5], [0.5, 0.002], [0.5, 0.998]])[: min(4, nt)]
+    hyp = loss_ref.scaled_hyp(1024, nc, 3, label_smoothing=0.05)
+    rl, ritems = loss_ref.compute_loss(pc, t, torch.from_numpy(g['anchors']), hyp)
+    rl.sum().backward()
+    cl = ComputeLoss(fake_model(g['anchors'], hyp))
+    p = [q.detach().to(DEV).requires_grad_() for q in pc]
+    loss, items = cl(p, t.to(DEV))
+    loss.sum().backward()
+    check(f'detloss/nt{nt}/loss', loss, rl, 2e-5)
+    check(f'detloss/nt{nt}/items', items, ritems, 2e-5)
+    for i in range(3):
+        check(f'detloss/nt{nt}/grad{i}', p[i].grad, pc[i].grad, 2e-4)
+
+
+@pytest.mark.parametrize('layout', ['nchw', 'nhwc'])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+def test_seg_ce_matches_reference_golden(layout, dtype):
+    from multiyolov5_amd.utils.loss import SegmentationLosses
+    g = golden('losses')
+    x = torch.from_numpy(g['seg_logits']).to(DEV, dtype)
+    if layout == 'nhwc':                                  # the memory layout Model.forward hands out (NHWC storage)
+        x = x.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    x.requires_grad_()
+    mask = torch.from_numpy(g['seg_mask'].astype(np.int64)).to(DEV)
+    loss = SegmentationLosses()(x, mask)
+    (loss * 2 * 0.35).backward()
+    tol = 1e-5 if dtype == torch.float32 else 2e-3
+    check(f'segce/{layout}/loss', loss, g['ce_loss'], tol)
+    check(f'segce/{layout}/grad', x.grad, g['ce_grad'] * 0.7, 2e-5 if dtype == torch.float32 else 5e-3)
+    assert x.grad.stride() == x.stride()
+
+
+@pytest.mark.parametrize('case', ['0.7', '0.999999', 'topk'])
+def test_ohem_matches_reference_golden(case):
+    from multiyolov5_amd.utils.loss import OhemCELoss
+    g = golden('losses')
+    mask = torch.from_numpy(g['seg_mask'].astype(np.int64)).to(DEV)
+    if case == 'topk':
+        x = torch.from_numpy(g['ohem_topk_logits']).to(DEV).requires_grad_()
+        crit, ref_l, ref_g = OhemCELoss(thresh=0.7), g['ohem_topk_loss'], g['ohem_topk_grad']
+    else:
+        x = torch.from_numpy(g['seg_logits']).to(DEV).requires_grad_()
+        crit, ref_l, ref_g = OhemCELoss(thresh=float(case)), g[f'ohem_{case}_loss'], g[f'ohem_{case}_grad']
+    loss = crit(x, mask)
+    loss.backward()
+    check(f'ohem/{case}/loss', loss, ref_l, 1e-5)
+    check(f'ohem/{case}/grad', x.grad, ref_g, 2e-5)
+
+
+def test_seg_ce_aux_and_full_size_properties():
+    """BiSe aux weighting (loss.py:244) vs the oracle, and a full-size [4,19,512,1024] pass checked through size-independent
+    properties: gradient rows sum to zero, ignored pixels get zero gradient, loss equals the mean of per-pixel losses."""
+    from multiyolov5_amd.utils.loss import SegmentationLosses
+    gen = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 19, 24, 40, generator=gen) * 2 for _ in range(3)]
+    mask = synth.synth_seg_targets(2, 24, 40, 19, seed=4, blocky=4)
+    ref = loss_ref.seg_ce_aux(xs, mask, aux_weight=0.1)
+    got = SegmentationLosses(aux=True, aux_num=2, aux_weight=0.1)(*[x.to(DEV) for x in xs], mask.to(DEV))
+    check('segce/aux', got, ref, 1e-5)
+    N, C, H, W = 4, 19, 512, 1024
+    x = (torch.randn(N, H, W, C, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1)) * 3).half() \
+        .permute(0, 3, 1, 2).requires_grad_()
+    m = synth.synth_seg_targets(N, H, W, 19, seed=2).to(DEV)
+    loss = SegmentationLosses()(x, m)
+    loss.backward()
+    g = x.grad.float()
+    valid = (m != -1)
+    assert float(g.sum(1).abs().max()) < 2e-3 / valid.sum().item() * 1e3
+    assert float(g.permute(0, 2, 3, 1)[~valid].abs().max()) == 0.0
+    ref_loss = torch.nn.functional.cross_entropy(x.detach().float().cpu()[:1], m.cpu()[:1], ignore_index=-1)
+    l1 = SegmentationLosses()(x.detach()[:1], m[:1])
+    check('segce/full_size_first_image', l1, ref_loss, 2e-4)
