@@ -215,6 +215,28 @@ typedef struct myolo_detloss_desc {
 int myolo_detloss_fwd(const myolo_detloss_desc* d, void* stream);
 int myolo_detloss_bwd(const myolo_detloss_desc* d, void* stream);
 
+/* ---- optimizer side (multi-tensor, one launch for all tensors) ---------------------------------- */
+/* table: device int64 [ntensors][6] = {ptr0, ptr1, ptr2, numel, group, 0} (fp32 tensors); chunks: device int32 [nchunks][2]
+ * = {tensor index, first element}; workgroup b covers chunk_elems elements of its tensor. */
+typedef struct myolo_sgd_hyper {
+  float lr[8], momentum[8], weight_decay[8];    /* per param group (train.py:121-137: BN weights | weights + decay | biases) */
+  int32_t nesterov;
+  int32_t reserved;
+} myolo_sgd_hyper;
+/* torch.optim.SGD step (train.py:397): ptr0 = param, ptr1 = grad, ptr2 = momentum buffer (zero-initialised).
+ * scale (optional, device float): gradients are divided by scale[0] (AMP unscale);
+ * found_inf (optional, device float): the whole update is skipped when found_inf[0] != 0 (GradScaler.step). */
+int myolo_mt_sgd(const int64_t* table, const int32_t* chunks, int nchunks, int chunk_elems, const myolo_sgd_hyper* hyper,
+                 const float* scale, const float* found_inf, void* stream);
+/* found_inf[0] = 1 if any element of ptr<which> is inf/nan (never cleared here). */
+int myolo_mt_check_finite(const int64_t* table, const int32_t* chunks, int nchunks, int chunk_elems, int which,
+                          float* found_inf, void* stream);
+/* ModelEMA.update (utils/torch_utils.py:290-300): ptr0 = ema tensor, ptr1 = model tensor: v = v*decay + (1-decay)*m */
+int myolo_mt_ema(const int64_t* table, const int32_t* chunks, int nchunks, int chunk_elems, float decay, void* stream);
+/* GradScaler.update: backoff on found_inf, growth after `interval` clean steps; clears found_inf. */
+int myolo_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth, float backoff, int interval,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,11 @@ class DetLossDesc(C.Structure):
                 ('gp32', C.c_void_p), ('gout', C.c_void_p)]
 
 
+class SgdHyper(C.Structure):
+    _fields_ = [('lr', C.c_float * 8), ('momentum', C.c_float * 8), ('weight_decay', C.c_float * 8),
+                ('nesterov', C.c_int32), ('reserved', C.c_int32)]
+
+
 class MyoloError(RuntimeError):
     pass
 
@@ -91,6 +96,10 @@ _PROTOS = {
                                    C.c_int64, C.c_int64, C.c_int64, C.c_int64, P, C.c_int, P, P, P, P, C.c_float, P]),
     'myolo_detloss_fwd': (C.c_int, [C.POINTER(DetLossDesc), P]),
     'myolo_detloss_bwd': (C.c_int, [C.POINTER(DetLossDesc), P]),
+    'myolo_mt_sgd': (C.c_int, [P, P, C.c_int, C.c_int, C.POINTER(SgdHyper), P, P, P]),
+    'myolo_mt_check_finite': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
+    'myolo_mt_ema': (C.c_int, [P, P, C.c_int, C.c_int, C.c_float, P]),
+    'myolo_scaler_update': (C.c_int, [P, P, P, C.c_float, C.c_float, C.c_int, P]),
 }
 
 

@@ -686,6 +686,9 @@ class Plan:
         """fp32 gradient slot of a parameter inside the plan's flat gradient buffer."""
         if p is None:
             return None
+        cur = getattr(self, '_building', None)
+        if cur is not None:
+            self._pg_first_op[id(p)] = min(self._pg_first_op.get(id(p), cur), cur)
         return self._pgrad[id(p)]
 
     # ---- build --------------------------------------------------------------------------------------
@@ -713,8 +716,11 @@ class Plan:
                 b.gwritten = []
             for op in reversed(self.ops):
                 op.plan_bwd(self)
-        for op in self.ops:
+        self._pg_first_op = {}
+        for i, op in enumerate(self.ops):
+            self._building = i
             op.build(self)
+        self._building = None
         self.built = True
         if torch.device(self.device).type == 'cuda':     # a CPU-device plan is a dry build (shape/launch-list checks only)
             self.prepare()
@@ -736,15 +742,33 @@ class Plan:
             for c in op.fwd_calls:
                 c(st)
 
-    def run_bwd(self):
+    def grad_buckets(self, reducer):
+        """bucket layout of flat_grad for a parallel.GradReducer (cached per reducer)."""
+        key = id(reducer)
+        if getattr(self, '_bucket_key', None) != key:
+            sizes = [p.numel() for p in self.params]
+            first = [self._pg_first_op.get(id(p), 0) for p in self.params]
+            self._buckets = reducer.layout(sizes, first)
+            self._bucket_key = key
+        return self._buckets
+
+    def run_bwd(self, reducer=None):
         st = L.stream_ptr()
         if self._used[1]:
             self._arena[1][:self._used[1]].zero_()
         if self.training:
             self.flat_grad.zero_()
-        for op in reversed(self.ops):
-            for c in op.bwd_calls:
+        pending = list(self.grad_buckets(reducer)) if reducer is not None else []
+        for i in range(len(self.ops) - 1, -1, -1):
+            for c in self.ops[i].bwd_calls:
                 c(st)
+            while pending and pending[0][2] >= i:       # every kernel writing into this slice has been enqueued
+                lo, hi, _ = pending.pop(0)
+                reducer.reduce_slice(self.flat_grad, lo, hi)
+        if reducer is not None:
+            for lo, hi, _ in pending:
+                reducer.reduce_slice(self.flat_grad, lo, hi)
+            reducer.finish(self.flat_grad)
 
     def nbytes(self):
         tot = 0

@@ -1,0 +1,77 @@
+"""Data-parallel gradient exchange for the joint det+seg step: one process per GPU, RCCL (`backend='nccl'`) over xGMI.
+
+The reference wraps the model in torch DDP (train.py:243-245): 25 MB buckets discovered through ~230 AccumulateGrad hooks.
+Here the whole backward is one launch plan that writes every parameter gradient into ONE flat fp32 buffer
+(engine.Plan.flat_grad, 31 MB for yolov5s+PSP), so the exchange is a few large in-place all-reduces of contiguous slices,
+issued on a side HIP stream the moment the backward launch list has finished the last kernel writing into a slice
+(head and neck first, backbone last) and overlapped with the rest of the backward.  Gradients are averaged over ranks
+exactly like DDP (the reference compensates for the detection loss only, train.py:366-367).
+
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): 31 MB is latency-dominated on every algorithm RCCL can pick, so few
+large buckets (default 3) beat DDP's 25 MB + remainder split.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, model, world_size=None, nbuckets=3, group=None):
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.group = group
+        self.nbuckets = max(1, int(nbuckets))
+        self.stream = None
+        self._works = []
+        model.__dict__['_grad_reducer'] = self         # consulted by runtime.PlanFn.backward
+
+    # ---- bucket layout (called once per plan) ---------------------------------------------------------
+    def layout(self, sizes, first_op):
+        """sizes[i]: numel of parameter i (flat order); first_op[i]: lowest op index of the plan writing its gradient
+        (the backward runs ops from high to low index, so the gradient is final once that op has run).
+        Returns buckets [(lo, hi, ready_after_op)] over the flat buffer, in completion order."""
+        total = sum(sizes)
+        target = max(1, (total + self.nbuckets - 1) // self.nbuckets)
+        buckets, lo, acc, ready = [], 0, 0, None
+        off = 0
+        for n, op in zip(sizes, first_op):
+            acc += n
+            off += n
+            ready = op if ready is None else min(ready, op)
+            if acc >= target:
+                buckets.append((lo, off, ready))
+                lo, acc, ready = off, 0, None
+        if acc:
+            buckets.append((lo, off, ready))
+        # a bucket may only be sent once every parameter inside it is final; completion order = descending ready op
+        return sorted(buckets, key=lambda b: -b[2])
+
+    # ---- exchange ----------------------------------------------------------------------------------------
+    def reduce_slice(self, flat, lo, hi):
+        if self.world == 1:
+            return
+        view = flat[lo:hi]
+        if flat.is_cuda:
+            if self.stream is None:
+                self.stream = torch.cuda.Stream(device=flat.device)
+            ev = torch.cuda.Event()
+            ev.record()
+            self.stream.wait_event(ev)
+            with torch.cuda.stream(self.stream):
+                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:                                           # gloo (CPU tests): no AVG
+            dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+            view.div_(self.world)
+
+    def finish(self, flat):
+        """make the current stream wait for every outstanding slice."""
+        if self.world == 1 or not flat.is_cuda or self.stream is None:
+            self._works = []
+            return
+        with torch.cuda.stream(self.stream):
+            for w in self._works:
+                w.wait()
+        self._works = []
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+    def wait(self):
+        """kept for call-site symmetry with DDP's implicit sync: PlanFn.backward already waited before handing out grads."""
+        return

@@ -105,7 +105,7 @@ class PlanFn(torch.autograd.Function):
                 dst.zero_()
             else:
                 dst.copy_(g)
-        plan.run_bwd()
+        plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
         holder.pending_bwd = False
         in_grads = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]
         flat = plan.flat_grad.clone()
@@ -123,6 +123,7 @@ class PlanHolder:
     def __init__(self, module, tensors, spec, dtype, training):
         dev = tensors[0].device
         self.plan = plan = E.Plan(dev, dtype, training)
+        self.module = module
         self.n_in = len(tensors)
         self.in_requires_grad = [bool(t.requires_grad) for t in tensors]
         handles = []

@@ -1,0 +1,81 @@
+"""world_size-2 gloo tests of the data-parallel gradient exchange (multiyolov5_amd/parallel.py) -- no GPU needed: the bucket
+layout comes from a dry-built training plan, the reduction runs on CPU tensors through the same GradReducer code path."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from multiyolov5_amd import runtime as R
+        from multiyolov5_amd.models.yolo import Model
+        from multiyolov5_amd.parallel import GradReducer
+        from tests.util import CFG, TAGS
+        torch.manual_seed(0)
+        m = Model(os.path.join(CFG, TAGS['s_psp'])).train()
+        red = GradReducer(m, world, nbuckets=3)
+        h = R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float32, True)     # dry build (CPU device)
+        plan = h.plan
+        buckets = plan.grad_buckets(red)
+        total = plan.flat_grad.numel()
+        # buckets tile the flat buffer exactly, and arrive in backward completion order (descending op index)
+        assert sorted((lo, hi) for lo, hi, _ in buckets)[0][0] == 0
+        cover = sorted((lo, hi) for lo, hi, _ in buckets)
+        assert all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1)) and cover[-1][1] == total
+        assert [b[2] for b in buckets] == sorted([b[2] for b in buckets], reverse=True)
+        # Detect/seg-head parameters (end of the flat buffer) are final first; the Focus conv (offset 0) last
+        assert buckets[0][1] == total and buckets[-1][0] == 0
+        # the exchange itself: rank r holds r+1 everywhere -> mean 1.5; every slice is reduced exactly once
+        g = torch.Generator().manual_seed(100 + rank)
+        local = torch.randn(total, generator=g)
+        plan.flat_grad.copy_(local)
+        for lo, hi, _ in buckets:
+            red.reduce_slice(plan.flat_grad, lo, hi)
+        red.finish(plan.flat_grad)
+        ref = sum(torch.randn(total, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)) / world
+        err = (plan.flat_grad - ref).abs().max().item()
+        q.put((rank, 'ok', err, len(buckets)))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'fail', traceback.format_exc(), 0))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_grad_reducer_world2_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, status, err, nb in res:
+        assert status == 'ok', err
+        assert err < 1e-6 and nb == 3
+
+
+def test_layout_single_process():
+    from multiyolov5_amd.parallel import GradReducer
+
+    class M:
+        pass
+    red = GradReducer(M(), world_size=4, nbuckets=2)
+    b = red.layout([10, 10, 10, 10], [0, 3, 5, 9])
+    assert b == [(20, 40, 5), (0, 20, 0)]
+    assert GradReducer(M(), 1).layout([5], [2]) == [(0, 5, 2)]
