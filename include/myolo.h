@@ -237,6 +237,16 @@ int myolo_mt_ema(const int64_t* table, const int32_t* chunks, int nchunks, int c
 int myolo_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf, float growth, float backoff, int interval,
                         void* stream);
 
+/* ---- inference post-processing ------------------------------------------------------------------- */
+/* non_max_suppression (utils/general.py:421-509) + torchvision.ops.nms (call site general.py:493), all images at once.
+ * pred: dense [batch, A, no] (xywh, obj, cls...), f16|f32 (arithmetic is fp32).  Workspaces (device, caller-owned):
+ * counts int32[batch], cand float[batch][cap][6], cand_idx int32[batch][cap], sorted float[batch][max_nms][6];
+ * cap >= A (A*nc when multi_label).  Results: out float[batch][max_det][6] = (x1,y1,x2,y2,conf,cls) in descending conf,
+ * nkeep int32[batch]. */
+int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres, int multi_label,
+              int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts, float* cand,
+              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

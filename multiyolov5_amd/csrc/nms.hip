@@ -1,0 +1,204 @@
+// Batched non-maximum suppression for the detect.py / test.py path, all images in one launch sequence, no host round trip
+// until the kept rows are read back (reference utils/general.py:421-509 + torchvision.ops.nms, call site general.py:493).
+//
+//   nms_filter : obj > conf (general.py:430,446), cls *= obj (462), xywh->xyxy (465), best class / multi-label (468-473),
+//                wave-aggregated compaction into per-image candidate lists
+//   nms_rank   : descending-score rank of every candidate (ties broken by the original row for determinism); candidates are
+//                scattered to their sorted slot, truncated to max_nms (487-488)
+//   nms_scan   : one workgroup per image walks the sorted list in chunks of 64: the wave resolves the chunk's internal
+//                suppressions with 64-bit lane masks, then all threads mark the later boxes the chunk's survivors suppress.
+//                IoU is taken on the class-offset boxes (box + cls*max_wh, 491-492) with torchvision's formula
+//                inter/(a+b-inter), strict '>'; stops once max_det boxes are kept (494-495).
+#include "myolo_dev.h"
+
+namespace {
+
+__device__ __forceinline__ float ldp(const void* p, int64_t i, int dt) {
+  return dt == MYOLO_F16 ? (float)((const half_t*)p)[i] : ((const float*)p)[i];
+}
+
+__global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int dt, int A, int no, float conf, int multi,
+                                                         int cap, int* counts, float* cand, int* cand_idx) {
+  const int b = blockIdx.y;
+  const int nc = no - 5;
+  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
+    const int64_t row = ((int64_t)b * A + a) * no;
+    const float obj = ldp(pred, row + 4, dt);
+    if (!(obj > conf)) continue;
+    const float x = ldp(pred, row, dt), y = ldp(pred, row + 1, dt), w = ldp(pred, row + 2, dt), h = ldp(pred, row + 3, dt);
+    const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;
+    if (multi && nc > 1) {
+      for (int j = 0; j < nc; ++j) {
+        const float s = ldp(pred, row + 5 + j, dt) * obj;
+        if (s > conf) {
+          const int slot = atomicAdd(counts + b, 1);
+          if (slot < cap) {
+            float* c = cand + ((int64_t)b * cap + slot) * 6;
+            c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = s; c[5] = (float)j;
+            cand_idx[(int64_t)b * cap + slot] = a * nc + j;
+          }
+        }
+      }
+    } else {
+      float best = -INFINITY; int bj = 0;
+      for (int j = 0; j < nc; ++j) {
+        const float s = ldp(pred, row + 5 + j, dt) * obj;
+        if (s > best) { best = s; bj = j; }                        // first maximum (torch.max)
+      }
+      if (best > conf) {
+        const int slot = atomicAdd(counts + b, 1);
+        if (slot < cap) {
+          float* c = cand + ((int64_t)b * cap + slot) * 6;
+          c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = best; c[5] = (float)bj;
+          cand_idx[(int64_t)b * cap + slot] = a;
+        }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, const float* cand, const int* cand_idx, int cap,
+                                                       int max_nms, float* sorted) {
+  __shared__ float ss[256];
+  __shared__ int si[256];
+  const int b = blockIdx.y;
+  int n = counts[b];
+  if (n > cap) n = cap;
+  const int i0 = blockIdx.x * 256;
+  if (i0 >= n) return;
+  const int i = i0 + threadIdx.x;
+  const float* cb = cand + (int64_t)b * cap * 6;
+  const int* ib = cand_idx + (int64_t)b * cap;
+  const float s = i < n ? cb[(int64_t)i * 6 + 4] : 0.f;
+  const int id = i < n ? ib[i] : 0;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 256) {
+    const int j = j0 + threadIdx.x;
+    ss[threadIdx.x] = j < n ? cb[(int64_t)j * 6 + 4] : -INFINITY;
+    si[threadIdx.x] = j < n ? ib[j] : 0x7fffffff;
+    __syncthreads();
+    const int lim = n - j0 < 256 ? n - j0 : 256;
+    for (int q = 0; q < lim; ++q) {
+      const float sj = ss[q];
+      rank += (sj > s || (sj == s && si[q] < id)) ? 1 : 0;
+    }
+    __syncthreads();
+  }
+  if (i < n && rank < max_nms) {
+    float* d = sorted + ((int64_t)b * max_nms + rank) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) d[q] = cb[(int64_t)i * 6 + q];
+  }
+}
+
+__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2, float by2,
+                                       float thr) {
+  const float aa = (ax2 - ax1) * (ay2 - ay1), ab = (bx2 - bx1) * (by2 - by1);
+  const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
+  const float inter = w * h;
+  return inter / (aa + ab - inter) > thr;
+}
+
+constexpr int SCAN_THREADS = 1024;
+constexpr int MAXW = 1024;            // removed-bit words: up to 65536 sorted candidates per image
+
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* counts, const float* sorted, int cap, int max_nms,
+                                                                int max_det, float iou_thr, float max_wh, int agnostic,
+                                                                float* out, int* nkeep) {
+  __shared__ unsigned long long removed[MAXW];
+  __shared__ float cbox[64][4];
+  __shared__ float kbox[64][4];
+  __shared__ int s_nk, s_total;
+  const int b = blockIdx.x;
+  int m = counts[b];
+  if (m > cap) m = cap;
+  if (m > max_nms) m = max_nms;
+  const float* sb = sorted + (int64_t)b * max_nms * 6;
+  const int tid = threadIdx.x;
+  const int words = (m + 63) >> 6;
+  for (int i = tid; i < words; i += SCAN_THREADS) removed[i] = 0ull;
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  const float off = agnostic ? 0.f : max_wh;
+  for (int c = 0; c < words; ++c) {
+    const int base = c << 6;
+    if (tid < 64) {
+      const int i = base + tid;
+      float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+      if (i < m) {
+        const float o = sb[(int64_t)i * 6 + 5] * off;                 // class offset (general.py:491-492)
+        x1 = sb[(int64_t)i * 6] + o; y1 = sb[(int64_t)i * 6 + 1] + o; x2 = sb[(int64_t)i * 6 + 2] + o; y2 = sb[(int64_t)i * 6 + 3] + o;
+      }
+      cbox[tid][0] = x1; cbox[tid][1] = y1; cbox[tid][2] = x2; cbox[tid][3] = y2;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // lane i: mask of the chunk's later boxes it suppresses
+      const int i = base + tid;
+      unsigned long long mask = 0ull;
+      if (i < m) {
+        const float x1 = cbox[tid][0], y1 = cbox[tid][1], x2 = cbox[tid][2], y2 = cbox[tid][3];
+        for (int j = tid + 1; j < 64 && base + j < m; ++j)
+          if (iou_gt(x1, y1, x2, y2, cbox[j][0], cbox[j][1], cbox[j][2], cbox[j][3], iou_thr)) mask |= 1ull << j;
+      }
+      unsigned long long rem = removed[c];
+      unsigned long long keepbits = 0ull;
+      const int lim = m - base < 64 ? m - base : 64;
+      for (int i2 = 0; i2 < lim; ++i2) {
+        const unsigned int lo = __shfl((unsigned int)mask, i2, 64), hi = __shfl((unsigned int)(mask >> 32), i2, 64);
+        if (!((rem >> i2) & 1ull)) {
+          keepbits |= 1ull << i2;
+          rem |= ((unsigned long long)hi << 32) | lo;
+        }
+      }
+      // survivors of this chunk -> kbox (in order) and the output rows
+      const bool mine = (keepbits >> tid) & 1ull;
+      const int pos = __popcll(keepbits & ((1ull << tid) - 1ull));
+      const int total = s_total;
+      if (mine) {
+        kbox[pos][0] = cbox[tid][0]; kbox[pos][1] = cbox[tid][1]; kbox[pos][2] = cbox[tid][2]; kbox[pos][3] = cbox[tid][3];
+        const int o = total + pos;
+        if (o < max_det) {
+          float* d = out + ((int64_t)b * max_det + o) * 6;
+#pragma unroll
+          for (int q = 0; q < 6; ++q) d[q] = sb[(int64_t)(base + tid) * 6 + q];
+        }
+      }
+      if (tid == 0) { s_nk = __popcll(keepbits); s_total = total + __popcll(keepbits); }
+    }
+    __syncthreads();
+    const int nk = s_nk;
+    if (s_total >= max_det) break;
+    // later boxes suppressed by this chunk's survivors
+    for (int j = base + 64 + tid; j < m; j += SCAN_THREADS) {
+      if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
+      const float o = sb[(int64_t)j * 6 + 5] * off;
+      const float x1 = sb[(int64_t)j * 6] + o, y1 = sb[(int64_t)j * 6 + 1] + o, x2 = sb[(int64_t)j * 6 + 2] + o, y2 = sb[(int64_t)j * 6 + 3] + o;
+      bool dead = false;
+      for (int q = 0; q < nk && !dead; ++q) dead = iou_gt(kbox[q][0], kbox[q][1], kbox[q][2], kbox[q][3], x1, y1, x2, y2, iou_thr);
+      if (dead) atomicOr(&removed[j >> 6], 1ull << (j & 63));
+    }
+    __syncthreads();
+  }
+  if (tid == 0) nkeep[b] = s_total < max_det ? s_total : max_det;
+}
+
+}  // namespace
+
+extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres,
+                         int multi_label, int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts,
+                         float* cand, int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, void* stream) {
+  if (!pred || (dtype != MYOLO_F16 && dtype != MYOLO_F32) || batch < 1 || A < 1 || no < 6 || cap < 1 || max_det < 1 ||
+      max_nms < 1 || max_nms > MAXW * 64 || !counts || !cand || !cand_idx || !sorted || !out || !nkeep)
+    return MYOLO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, batch * sizeof(int32_t), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), 0, st, pred, dtype, A, no, conf_thres,
+                     multi_label, cap, counts, cand, cand_idx);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), 0, st, counts, sorted, cap, max_nms, max_det, iou_thres,
+                     max_wh, agnostic, out, nkeep);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

@@ -571,6 +571,7 @@ class SegOutOp(Op):
         store = torch.empty(lw.n, H, W, lw.c, dtype=plan.dtype, device=plan.device)
         out = store.permute(0, 3, 1, 2)                 # [N,C,H,W] logical, NHWC memory
         plan.outputs[self.slot] = out
+        out._myolo_low = lw.torch_view()                # low-res class logits: utils.general.seg_argmax fuses resize+argmax on them
         self.ld = lw.desc()
         sn, sc, sh, sw = out.stride()
         self.fwd_calls.append(Call('myolo_seg_upsample_fwd', (C.byref(self.ld), L.ptr(out), L.DT[out.dtype], H, W, sn, sc, sh, sw),

@@ -37,3 +37,65 @@ def scale_coords(img1_shape, coords, img0_shape, ratio_pad=None):
     coords[:, :4] /= gain
     clip_coords(coords, img0_shape)
     return coords
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# inference post-processing on MI355X (libmyolo csrc/nms.hip, csrc/seg_out.hip); no CPU path
+import ctypes as _C
+
+from .. import _lib as _L
+
+
+def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
+                        labels=()):
+    """general.py:421-509: list (one per image) of [n,6] tensors (x1, y1, x2, y2, conf, cls), descending conf, n <= 300.
+    One batched launch sequence for all images; the only host synchronisation is reading the per-image keep counts.
+    fp16 predictions are scored and intersected in fp32 (the reference multiplies cls*obj in the input dtype)."""
+    if classes is not None or (labels is not None and len(labels)):
+        raise NotImplementedError('classes= / labels= filtering (general.py:448-456,476-477) is not on the gfx950 hot path')
+    _L.require_gpu(prediction)
+    if prediction.dim() != 3 or prediction.dtype not in (torch.float16, torch.float32):
+        raise _L.MyoloError('prediction must be a [B,A,5+nc] fp16/fp32 tensor')
+    pred = prediction.contiguous()
+    B, A, no = pred.shape
+    nc = no - 5
+    max_wh, max_det, max_nms = 4096.0, 300, 30000                 # general.py:433-435
+    multi = bool(multi_label and nc > 1)                          # general.py:438
+    cap = A * nc if multi else A
+    dev = pred.device
+    counts = torch.empty(B, dtype=torch.int32, device=dev)
+    cand = torch.empty(B * cap * 6, dtype=torch.float32, device=dev)
+    cidx = torch.empty(B * cap, dtype=torch.int32, device=dev)
+    srt = torch.empty(B * max_nms * 6, dtype=torch.float32, device=dev)
+    out = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
+    nkeep = torch.empty(B, dtype=torch.int32, device=dev)
+    _L.check(_L.lib().myolo_nms(_L.ptr(pred), _L.DT[pred.dtype], B, A, no, _C.c_float(conf_thres), _C.c_float(iou_thres),
+                                int(multi), int(bool(agnostic)), _C.c_float(max_wh), max_nms, max_det, cap, _L.ptr(counts),
+                                _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), _L.stream_ptr()),
+             'myolo_nms')
+    n = nkeep.tolist()                                            # the one sync (the reference syncs per image, 446-495)
+    return [out[i, :n[i]].to(prediction.dtype) for i in range(B)]
+
+
+def seg_argmax(seg, h0=None, w0=None, out_dtype=torch.int64):
+    """detect.py:191-193 fused: bilinear(align_corners=True) resize of the class logits to (h0, w0) + argmax over classes ->
+    labels [N,h0,w0].  `seg` is the model's segmentation output [N,C,H,W]; when (h0,w0) == (H,W) the resize is taken
+    straight from the head's low-res logits (the x8 upsample of yolo.py:163 is folded in, bit-identical)."""
+    _L.require_gpu(seg)
+    n, c, H, W = seg.shape
+    h0, w0 = int(h0 or H), int(w0 or W)
+    low = getattr(seg, '_myolo_low', None)
+    if low is not None and (h0, w0) == (H, W):
+        src = low                                                 # [N,h,w,C] view of the plan's NHWC buffer
+    else:
+        src = seg.permute(0, 2, 3, 1)
+        if src.stride(3) != 1:
+            src = src.contiguous()
+    if src.dtype not in (torch.float16, torch.float32) or c > 32:
+        raise _L.MyoloError('seg_argmax: fp16/fp32 logits with at most 32 classes')
+    d = _L.Tensor(src.data_ptr(), src.shape[0], src.shape[1], src.shape[2], src.shape[3], src.stride(0), src.stride(1),
+                  src.stride(2), _L.DT[src.dtype], 0)
+    labels = torch.empty(n, h0, w0, dtype=out_dtype, device=seg.device)
+    _L.check(_L.lib().myolo_seg_argmax(_C.byref(d), _L.ptr(labels), _L.DT[out_dtype], h0, w0, _L.stream_ptr()),
+             'myolo_seg_argmax')
+    return labels

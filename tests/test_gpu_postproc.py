@@ -1,0 +1,98 @@
+"""-m gpu: inference post-processing through the reference's API (utils.general.non_max_suppression) and the fused
+resize+argmax, against the golden vectors produced by the reference's own non_max_suppression (tests/golden/nms.npz, greedy
+kernel restated -- torchvision is absent, oracle/nms_ref.py) and against the CPU oracle at full size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms_ref, synth
+from tests.util import CFG, TAGS, golden, synth_sd
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _same(got, ref, name):
+    assert got.shape == ref.shape, f'{name}: kept {got.shape[0]} rows, reference {ref.shape[0]}'
+    # box / class indices bit-exact: identical rows in identical order
+    np.testing.assert_array_equal(got[:, 5], ref[:, 5], err_msg=name + ' classes')
+    np.testing.assert_array_equal(got, ref, err_msg=name)
+
+
+@pytest.mark.parametrize('mode', ['single', 'multi'])
+def test_nms_matches_reference_golden(mode):
+    from multiyolov5_amd.utils.general import non_max_suppression
+    g = golden('nms')
+    pred = synth.synth_nms_pred(2, 3000, 10, seed=3).to(DEV)
+    kw = dict(conf_thres=0.25, iou_thres=0.45) if mode == 'single' else dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    out = non_max_suppression(pred, **kw)
+    assert len(out) == 2
+    for i, o in enumerate(out):
+        _same(o.cpu().numpy(), g[f'{mode}_{i}'], f'nms/{mode}/{i}')
+
+
+@pytest.mark.parametrize('A,wh', [(32256, (1024, 512)), (129024, (2048, 1024))])
+def test_nms_full_size_vs_oracle(A, wh):
+    from multiyolov5_amd.utils.general import non_max_suppression
+    pred = synth.synth_nms_pred(2, A, 10, seed=5, img_w=wh[0], img_h=wh[1])
+    ref = nms_ref.non_max_suppression(pred.numpy(), 0.25, 0.45)
+    out = non_max_suppression(pred.to(DEV), 0.25, 0.45)
+    for i in range(2):
+        _same(out[i].cpu().numpy(), ref[i], f'nms/full{A}/{i}')
+        assert out[i].shape[0] <= 300 and (np.diff(out[i][:, 4].cpu().numpy()) <= 0).all()
+    # idempotence: feeding the survivors back (as xywh + obj=1) keeps all of them
+    o = out[0].float()
+    x = torch.zeros(1, o.shape[0], 15, device=DEV)
+    x[0, :, 0], x[0, :, 1] = (o[:, 0] + o[:, 2]) / 2, (o[:, 1] + o[:, 3]) / 2
+    x[0, :, 2], x[0, :, 3] = o[:, 2] - o[:, 0], o[:, 3] - o[:, 1]
+    x[0, :, 4] = 1.0
+    x[0, torch.arange(o.shape[0]), 5 + o[:, 5].long()] = o[:, 4]
+    again = non_max_suppression(x, 0.25, 0.45)[0]
+    assert again.shape[0] == o.shape[0]
+
+
+def test_nms_edge_cases():
+    from multiyolov5_amd.utils.general import non_max_suppression
+    # nothing above the threshold -> empty [0,6]; fp16 input returns fp16 rows
+    pred = torch.zeros(3, 500, 15, device=DEV)
+    out = non_max_suppression(pred)
+    assert [tuple(o.shape) for o in out] == [(0, 6)] * 3
+    p16 = synth.synth_nms_pred(1, 4000, 10, seed=8).to(DEV).half()
+    out16 = non_max_suppression(p16, 0.25, 0.45)[0]
+    ref16 = nms_ref.non_max_suppression(p16.float().cpu().numpy(), 0.25, 0.45)[0]
+    assert out16.dtype == torch.float16 and out16.shape[0] == ref16.shape[0]
+    np.testing.assert_array_equal(out16.float().cpu().numpy()[:, 5], ref16[:, 5])
+    # more than max_det survivors: exactly 300 rows, the 300 best
+    rs = np.random.RandomState(0)
+    far = np.zeros((1, 1000, 15), np.float32)
+    far[0, :, 0] = np.arange(1000) * 60 % 2000 + 10
+    far[0, :, 1] = np.arange(1000) // 33 * 30 + 10
+    far[0, :, 2:4] = 8
+    far[0, :, 4] = 0.9
+    far[0, :, 5] = rs.uniform(0.5, 1.0, 1000)
+    o = non_max_suppression(torch.from_numpy(far).to(DEV), 0.25, 0.45)[0]
+    r = nms_ref.non_max_suppression(far, 0.25, 0.45)[0]
+    assert o.shape[0] == 300
+    np.testing.assert_array_equal(o.cpu().numpy(), r)
+
+
+def test_seg_argmax_fused_matches_oracle_and_model_output():
+    from multiyolov5_amd.models.yolo import Model
+    from multiyolov5_amd.utils.general import seg_argmax
+    m = Model(os.path.join(CFG, TAGS['s_psp']))
+    m.load_state_dict(synth_sd('s_psp'), strict=True)
+    m = m.to(DEV).fuse().eval()
+    x = synth.synth_images(2, 64, 128, seed=1)[:1].to(DEV)
+    with torch.no_grad():
+        (pred, raw), seg = m(x)
+    g = golden('model_s_psp')
+    lab = seg_argmax(seg)                                   # fused from the low-res logits (no second resize)
+    assert lab.dtype == torch.int64 and tuple(lab.shape) == (1, 64, 128)
+    assert (lab.cpu().numpy() != g['eval_seg_argmax']).mean() < 1e-3       # vs the reference's own argmax
+    np.testing.assert_array_equal(lab.cpu().numpy(), seg.argmax(1).cpu().numpy())   # bit-identical to the materialised logits
+    # detect.py:191 resize to a different original size: second-stage bilinear of the full-res logits + argmax
+    lab2 = seg_argmax(seg, 100, 180, out_dtype=torch.uint8)
+    ref2 = nms_ref.seg_argmax(seg[0].float().cpu().numpy(), 100, 180)
+    assert (lab2[0].cpu().numpy() != ref2).mean() < 2e-3
