@@ -1,7 +1,10 @@
+# usage: bash scripts/gpu_prof.sh <tag>   -- bench + rocprofv3 kernel trace of the training step (+ inference) on the GPU box
+TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-timeout 300 python bench.py --stage fwdbwd --steps 10 --warmup 3 > gpurun_out/b3.log 2>&1
-tail -5 gpurun_out/b3.log
-timeout 400 rocprofv3 --kernel-trace --stats -d gpurun_out/prof3 -o fwdbwd -- python bench.py --stage fwdbwd --steps 5 --warmup 2 --no-kernel-timing > gpurun_out/p3.log 2>&1
-tail -3 gpurun_out/p3.log
-ls -R gpurun_out/prof3 | head
+mkdir -p gpurun_out
+timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.log 2>&1
+tail -1 gpurun_out/bench_$TAG.log | cut -c1-1500
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o train -- python bench.py --steps 5 --warmup 2 --no-kernel-timing --no-infer --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
+tail -2 gpurun_out/prof_$TAG.log | cut -c1-300
+ls gpurun_out/prof_$TAG | head
