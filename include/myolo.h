@@ -58,6 +58,10 @@ int myolo_pack_weight(const void* w_oihw, int src_dtype, int cout, int cin, int 
                       void* dst, int dst_dtype, int rows_pad, int cols_pad, int transpose,
                       const float* row_scale, void* stream);
 
+/* all weight packs of a plan in one launch.  jobs: device int64 [njobs][10] = {src, dst, cout, cin, ntaps, rows_pad,
+ * cols_pad, transpose, src_dtype, dst_dtype}; chunks: device int32 [nchunks][2] = {job, first packed element}. */
+int myolo_pack_weights_mt(const int64_t* jobs, const int32_t* chunks, int nchunks, int chunk_elems, void* stream);
+
 /* Focus slicing + cat (common.py:550) fused with the image cast: NCHW [n,3,h,w] (f32|f16|u8, value*mul)
  * -> NHWC [n,h/2,w/2,16]: channel 3*q+c, q=(row parity, col parity) in order (0,0),(1,0),(0,1),(1,1);
  * channels 12..15 are zero. */

@@ -62,6 +62,7 @@ _PROTOS = {
     'myolo_version': (C.c_int, []),
     'myolo_arch': (C.c_char_p, []),
     'myolo_pack_weight': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    'myolo_pack_weights_mt': (C.c_int, [P, P, C.c_int, C.c_int, P]),
     'myolo_focus_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, TP, P]),
     'myolo_conv': (C.c_int, [C.POINTER(ConvDesc), P]),
     'myolo_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), P]),

@@ -187,6 +187,103 @@ __global__ void ohem_final_kernel(const double* acc, const double* st, const uin
 }
 __global__ void ce_final_kernel(const double* acc, float* loss) { loss[0] = (float)(acc[0] / acc[1]); }
 
+
+// ---- fast paths: dense channels-last logits ([N,H,W,C] contiguous, the layout Model.forward hands out).  A workgroup owns a
+// strip of 256 consecutive pixels = 256*C contiguous elements, moved with 16-byte accesses through LDS. -------------------
+constexpr int STRIP = 256;
+template <typename T>
+__global__ __launch_bounds__(STRIP) void seg_ce_fwd_cl_kernel(const T* x, const int64_t* tgt, int C, int64_t total, int ignore,
+                                                              double* acc, float* pix) {
+  __shared__ __attribute__((aligned(16))) T buf[STRIP * MAXC];
+  __shared__ double sh[4];
+  double lsum = 0.0, lcnt = 0.0;
+  const int64_t nstrips = (total + STRIP - 1) / STRIP;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t p0 = sidx * STRIP;
+    const int npix = total - p0 < STRIP ? (int)(total - p0) : STRIP;
+    __syncthreads();
+    strip_load(x + p0 * C, buf, npix * C);
+    __syncthreads();
+    if ((int)threadIdx.x < npix) {
+      const int64_t i = p0 + threadIdx.x;
+      const int64_t t = tgt[i];
+      float l = 0.f;
+      if (t != ignore) {
+        float v[MAXC];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) { v[c] = (float)buf[threadIdx.x * C + c]; m = fmaxf(m, v[c]); }
+        float sm = 0.f, xt = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) { sm += expf(v[c] - m); if (c == (int)t) xt = v[c]; }
+        l = (m + logf(sm)) - xt;
+        lsum += (double)l;
+        lcnt += 1.0;
+      }
+      if (pix) pix[i] = l;
+    }
+  }
+  const double bs = block_sum256(lsum, sh);
+  const double bc = block_sum256(lcnt, sh);
+  if (threadIdx.x == 0) { atomicAdd(acc + 0, bs); atomicAdd(acc + 1, bc); }
+}
+
+template <typename T>
+__global__ __launch_bounds__(STRIP) void seg_ce_bwd_cl_kernel(const T* x, T* g, const int64_t* tgt, int C, int64_t total,
+                                                              int ignore, const double* acc, const float* gout,
+                                                              const float* pix, const OhemSel* sel, float thresh) {
+  __shared__ __attribute__((aligned(16))) T buf[STRIP * MAXC];
+  const float go = gout[0];
+  float wbase;
+  int mode = -1;
+  float kth = 0.f, tie_w = 0.f;
+  if (sel) { mode = (int)sel->mode; kth = sel->kth; tie_w = sel->tie_w; wbase = go / sel->denom; }
+  else wbase = (float)((double)go / acc[1]);
+  const int64_t nstrips = (total + STRIP - 1) / STRIP;
+  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+    const int64_t p0 = sidx * STRIP;
+    const int npix = total - p0 < STRIP ? (int)(total - p0) : STRIP;
+    __syncthreads();
+    strip_load(x + p0 * C, buf, npix * C);
+    __syncthreads();
+    if ((int)threadIdx.x < npix) {
+      const int64_t i = p0 + threadIdx.x;
+      const int64_t t = tgt[i];
+      float w = (t != ignore) ? wbase : 0.f;
+      if (mode == 0) { if (!(pix[i] > thresh)) w = 0.f; }
+      else if (mode == 1) { const float l = pix[i]; w = l > kth ? wbase : (l == kth ? wbase * tie_w : 0.f); if (t == ignore) w = 0.f; }
+      T* row = buf + threadIdx.x * C;
+      if (w == 0.f) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < C) row[c] = (T)0.f;
+      } else {
+        float v[MAXC];
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) { v[c] = (float)row[c]; m = fmaxf(m, v[c]); }
+        float sm = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < C) { v[c] = expf(v[c] - m); sm += v[c]; }
+        const float inv = 1.f / sm;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+          if (c < C) row[c] = (T)((v[c] * inv - (c == (int)t ? 1.f : 0.f)) * w);
+      }
+    }
+    __syncthreads();
+    strip_store(g + p0 * C, buf, npix * C);
+  }
+}
+
+inline bool dense_cl(const void* p, int dt, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
+  const int es = dt == MYOLO_F16 ? 2 : 4;
+  return (dt == MYOLO_F16 || dt == MYOLO_F32) && sc == 1 && sw == C && sh == (int64_t)W * C && sn == (int64_t)H * W * C &&
+         (STRIP * C * es) % 16 == 0 && ((uintptr_t)p & 15) == 0 && C <= MAXC;
+}
+
 inline bool strided_ok(const void* p, int dt) { return p && (dt == MYOLO_F16 || dt == MYOLO_F32); }
 
 }  // namespace
@@ -200,8 +297,16 @@ extern "C" int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int
   if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)n * h * w;
   Strided4 x{const_cast<void*>(logits), sn, sc, sh, sw, dtype};
-  hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, x, target, c, h, w, total,
-                     ignore_index, acc, pix);
+  if (dense_cl(logits, dtype, c, h, w, sn, sc, sh, sw)) {          // all pixels of all images are one contiguous [P][C] array
+    const int grid = grid_for(total, STRIP, 4096);
+    if (dtype == MYOLO_F16)
+      hipLaunchKernelGGL(seg_ce_fwd_cl_kernel<half_t>, dim3(grid), dim3(STRIP), 0, st, (const half_t*)logits, target, c, total, ignore_index, acc, pix);
+    else
+      hipLaunchKernelGGL(seg_ce_fwd_cl_kernel<float>, dim3(grid), dim3(STRIP), 0, st, (const float*)logits, target, c, total, ignore_index, acc, pix);
+  } else {
+    hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, x, target, c, h, w, total,
+                       ignore_index, acc, pix);
+  }
   MYOLO_CHECK_LAUNCH();
   if (loss) {
     hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, st, acc, loss);
@@ -241,8 +346,18 @@ extern "C" int myolo_seg_ce_bwd(const void* logits, void* grad, int dtype, int n
   if ((sel != nullptr) != (pix != nullptr)) return MYOLO_EINVAL;
   const int64_t total = (int64_t)n * h * w;
   Strided4 x{const_cast<void*>(logits), sn, sc, sh, sw, dtype}, g{grad, gsn, gsc, gsh, gsw, dtype};
-  hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, g, target, c,
-                     h, w, total, ignore_index, acc, gout, pix, reinterpret_cast<const OhemSel*>(sel), thresh);
+  if (dense_cl(logits, dtype, c, h, w, sn, sc, sh, sw) && dense_cl(grad, dtype, c, h, w, gsn, gsc, gsh, gsw)) {
+    const int grid = grid_for(total, STRIP, 4096);
+    if (dtype == MYOLO_F16)
+      hipLaunchKernelGGL(seg_ce_bwd_cl_kernel<half_t>, dim3(grid), dim3(STRIP), 0, (hipStream_t)stream, (const half_t*)logits, (half_t*)grad,
+                         target, c, total, ignore_index, acc, gout, pix, reinterpret_cast<const OhemSel*>(sel), thresh);
+    else
+      hipLaunchKernelGGL(seg_ce_bwd_cl_kernel<float>, dim3(grid), dim3(STRIP), 0, (hipStream_t)stream, (const float*)logits, (float*)grad,
+                         target, c, total, ignore_index, acc, gout, pix, reinterpret_cast<const OhemSel*>(sel), thresh);
+  } else {
+    hipLaunchKernelGGL(seg_ce_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, g, target, c,
+                       h, w, total, ignore_index, acc, gout, pix, reinterpret_cast<const OhemSel*>(sel), thresh);
+  }
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

@@ -85,6 +85,26 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- strips of a dense channels-last [N,H,W,C] tensor: `npix` consecutive pixels of one row = npix*C contiguous elements.
+// Staged through LDS so that HBM sees 16-byte row-contiguous accesses although C (19 classes) is not a vector multiple.
+// `gbase` must be 16-byte aligned (callers check (W*C*sizeof(T)) % 16 == 0 and a 256-pixel strip pitch).
+template <typename T>
+__device__ __forceinline__ void strip_load(const T* gbase, T* lds, int nelem) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int nvec = nelem / V;
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x)
+    reinterpret_cast<uint4*>(lds)[v] = reinterpret_cast<const uint4*>(gbase)[v];
+  for (int e = nvec * V + threadIdx.x; e < nelem; e += blockDim.x) lds[e] = gbase[e];
+}
+template <typename T>
+__device__ __forceinline__ void strip_store(T* gbase, const T* lds, int nelem) {
+  constexpr int V = 16 / (int)sizeof(T);
+  const int nvec = nelem / V;
+  for (int v = threadIdx.x; v < nvec; v += blockDim.x)
+    reinterpret_cast<uint4*>(gbase)[v] = reinterpret_cast<const uint4*>(lds)[v];
+  for (int e = nvec * V + threadIdx.x; e < nelem; e += blockDim.x) gbase[e] = lds[e];
+}
+
 static inline int grid_for(int64_t work_items, int threads, int max_blocks = 2048) {
   int64_t b = (work_items + threads - 1) / threads;
   if (b < 1) b = 1;

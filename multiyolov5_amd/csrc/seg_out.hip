@@ -9,6 +9,7 @@
 //                      (autograd of yolo.py:214 view/permute)
 //   detect_decode    : eval-mode box decode of the three levels into [N, sum(na*ny*nx), no] (yolo.py:216-225)
 #include "myolo_dev.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -119,6 +120,113 @@ __global__ __launch_bounds__(256) void seg_up_bwd_kernel(Strided4 g, int H, int 
   }
 }
 
+
+// ---- fast paths for dense channels-last storage ([N,H,W,C] contiguous: the layout Model.forward hands out) -------------
+constexpr int STRIP = 256;
+template <typename T>
+__global__ __launch_bounds__(STRIP) void seg_up_fwd_cl_kernel(myolo_tensor low, T* out, int H, int W, float sy, float sx) {
+  __shared__ __attribute__((aligned(16))) T buf[STRIP * MAXC];
+  const int C = low.c;
+  const int strips = (W + STRIP - 1) / STRIP;
+  int b = blockIdx.x;
+  const int xs = b % strips; b /= strips;
+  const int y = b % H; const int n = b / H;
+  const int x0 = xs * STRIP;
+  const int npix = W - x0 < STRIP ? W - x0 : STRIP;
+  const int x = x0 + threadIdx.x;
+  if ((int)threadIdx.x < npix) {
+    const float fy = sy * (float)y, fx = sx * (float)x;
+    const int y0 = (int)fy, xx0 = (int)fx;
+    const int y1 = y0 + 1 < low.h ? y0 + 1 : low.h - 1, x1 = xx0 + 1 < low.w ? xx0 + 1 : low.w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)xx0;
+    const T* lp = reinterpret_cast<const T*>(low.ptr) + (int64_t)n * low.sn;
+    const T* p00 = lp + (int64_t)y0 * low.sh + (int64_t)xx0 * low.sw;
+    const T* p01 = lp + (int64_t)y0 * low.sh + (int64_t)x1 * low.sw;
+    const T* p10 = lp + (int64_t)y1 * low.sh + (int64_t)xx0 * low.sw;
+    const T* p11 = lp + (int64_t)y1 * low.sh + (int64_t)x1 * low.sw;
+    for (int c = 0; c < C; ++c) {
+      const float a = (float)p00[c], bb = (float)p01[c], cc = (float)p10[c], d = (float)p11[c];
+      buf[threadIdx.x * C + c] = (T)((1.f - ly) * ((1.f - lx) * a + lx * bb) + ly * ((1.f - lx) * cc + lx * d));
+    }
+  }
+  __syncthreads();
+  strip_store(out + (((int64_t)n * H + y) * W + x0) * C, buf, npix * C);
+}
+
+// transpose of the above for one low-res row segment of LXP pixels: the workgroup streams the hi-res rows of the footprint
+// through LDS (16-byte loads) while each thread accumulates its (low x, class) pairs.
+constexpr int LXP = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, int W, myolo_tensor glow, float sy, float sx,
+                                                            int acc, int xalign) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* buf = reinterpret_cast<T*>(smem_raw);
+  const int C = glow.c;
+  const int segs = (glow.w + LXP - 1) / LXP;
+  int b = blockIdx.x;
+  const int xsg = b % segs; b /= segs;
+  const int iy = b % glow.h; const int n = b / glow.h;
+  const int lx0 = xsg * LXP;
+  const int nlx = glow.w - lx0 < LXP ? glow.w - lx0 : LXP;
+  int ylo, yhi, xlo, xhi, t0, t1;
+  out_range(iy, glow.h, H, sy, ylo, yhi);
+  out_range(lx0, glow.w, W, sx, xlo, t0);
+  out_range(lx0 + nlx - 1, glow.w, W, sx, t1, xhi);
+  xlo = xlo / xalign * xalign;
+  const int npix = xhi - xlo + 1;
+  constexpr int MAXP = 3;                       // (lx, c) pairs per thread: LXP*MAXC/256 = 4 > 32*19/256 = 2.4
+  float a[MAXP + 1];
+#pragma unroll
+  for (int q = 0; q <= MAXP; ++q) a[q] = 0.f;
+  const int npairs = nlx * C;
+  for (int oy = ylo; oy <= yhi; ++oy) {
+    const float fy = sy * (float)oy; const int y0 = (int)fy; const int y1 = y0 + 1 < glow.h ? y0 + 1 : glow.h - 1;
+    const float ly = fy - (float)y0;
+    float wy = 0.f;
+    if (y0 == iy) wy += 1.f - ly;
+    if (y1 == iy) wy += ly;
+    if (wy == 0.f) continue;                     // uniform over the workgroup
+    __syncthreads();
+    strip_load(g + (((int64_t)n * H + oy) * W + xlo) * C, buf, npix * C);
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q <= MAXP; ++q) {
+      const int p = threadIdx.x + q * 256;
+      if (p >= npairs) break;
+      const int li = p / C, c = p - li * C;
+      const int ix = lx0 + li;
+      int pxlo, pxhi;
+      out_range(ix, glow.w, W, sx, pxlo, pxhi);
+      float s = 0.f;
+      for (int ox = pxlo; ox <= pxhi; ++ox) {
+        const float fx = sx * (float)ox; const int x0 = (int)fx; const int x1 = x0 + 1 < glow.w ? x0 + 1 : glow.w - 1;
+        const float lx = fx - (float)x0;
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx != 0.f) s += wx * (float)buf[(ox - xlo) * C + c];
+      }
+      a[q] += wy * s;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q <= MAXP; ++q) {
+    const int p = threadIdx.x + q * 256;
+    if (p >= npairs) break;
+    const int li = p / C, c = p - li * C;
+    T* o = reinterpret_cast<T*>(glow.ptr) + (int64_t)n * glow.sn + (int64_t)iy * glow.sh + (int64_t)(lx0 + li) * glow.sw + c;
+    float v = a[q];
+    if (acc) v += (float)*o;
+    *o = (T)v;
+  }
+}
+
+inline bool dense_cl(const void* p, int dt, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
+  const int es = dt == MYOLO_F16 ? 2 : 4;
+  return (dt == MYOLO_F16 || dt == MYOLO_F32) && sc == 1 && sw == C && sh == (int64_t)W * C && sn == (int64_t)H * W * C &&
+         ((int64_t)W * C * es) % 16 == 0 && ((uintptr_t)p & 15) == 0 && C <= MAXC;
+}
+
 // g: dense [N,na,ny,nx,no] (dtype gdt) -> out NHWC view [N,ny,nx,na*no] (padded channels untouched)
 __global__ __launch_bounds__(256) void detect_unpermute_kernel(const void* g, int gdt, int na, int no, myolo_tensor out) {
   const int C = na * no;
@@ -168,6 +276,15 @@ extern "C" int myolo_seg_upsample_fwd(const myolo_tensor* low, void* out, int ou
   if (!low || !low->ptr || !out || H < 1 || W < 1) return MYOLO_EINVAL;
   Strided4 o{out, sn, sc, sh, sw, out_dtype};
   const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
+  if (!getenv("MYOLO_NO_FAST_UPF") && out_dtype == low->dtype && dense_cl(out, out_dtype, low->c, H, W, sn, sc, sh, sw) && (H > low->h || W > low->w)) {
+    const int64_t blocks = (int64_t)low->n * H * ((W + STRIP - 1) / STRIP);
+    if (out_dtype == MYOLO_F16)
+      hipLaunchKernelGGL(seg_up_fwd_cl_kernel<half_t>, dim3((int)blocks), dim3(STRIP), 0, (hipStream_t)stream, *low, (half_t*)out, H, W, sy, sx);
+    else
+      hipLaunchKernelGGL(seg_up_fwd_cl_kernel<float>, dim3((int)blocks), dim3(STRIP), 0, (hipStream_t)stream, *low, (float*)out, H, W, sy, sx);
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(seg_up_fwd_kernel, dim3(grid_for((int64_t)low->n * H * W, 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, *low, o, H, W, sy, sx);
   MYOLO_CHECK_LAUNCH();
@@ -178,6 +295,24 @@ extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, 
   if (!glow || !glow->ptr || !g) return MYOLO_EINVAL;
   Strided4 gg{const_cast<void*>(g), sn, sc, sh, sw, g_dtype};
   const float sy = H > 1 ? (float)(glow->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(glow->w - 1) / (float)(W - 1) : 0.f;
+  if (!getenv("MYOLO_NO_FAST_UPB") && g_dtype == glow->dtype && dense_cl(g, g_dtype, glow->c, H, W, sn, sc, sh, sw) && H >= 2 * glow->h && W >= 2 * glow->w) {
+    const int es = g_dtype == MYOLO_F16 ? 2 : 4;
+    int gcd = 16, t = glow->c * es;
+    while (t) { const int r = gcd % t; gcd = t; t = r; }
+    const int xalign = 16 / gcd;                                   // pixels per 16-byte boundary of the row
+    const int scale_x = (W + glow->w - 1) / glow->w;
+    const int maxpix = (LXP + 3) * scale_x + xalign + 8;
+    const int smem = (maxpix * glow->c * es + 15) / 16 * 16;
+    const int64_t blocks = (int64_t)glow->n * glow->h * ((glow->w + LXP - 1) / LXP);
+    if (smem <= 64 * 1024) {
+      if (g_dtype == MYOLO_F16)
+        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<half_t>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const half_t*)g, H, W, *glow, sy, sx, accumulate, xalign);
+      else
+        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<float>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const float*)g, H, W, *glow, sy, sx, accumulate, xalign);
+      MYOLO_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(seg_up_bwd_kernel, dim3(grid_for((int64_t)glow->n * glow->h * glow->w * glow->c, 256, 8192)), dim3(256),
                      0, (hipStream_t)stream, gg, H, W, *glow, sy, sx, accumulate);
   MYOLO_CHECK_LAUNCH();

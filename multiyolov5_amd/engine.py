@@ -221,9 +221,11 @@ class ConvOp(Op):
         cin_pad, cout_pad = rup(self.x.c, kc), rup(self.cout, 32)
         self.wpack = torch.zeros(cout_pad, ntaps, cin_pad, dtype=dt, device=dev)
         w = self.weight
-        pack = Call('myolo_pack_weight', (L.ptr(w), L.DT[w.dtype], self.cout, self.cin, self.k, self.k, L.ptr(self.wpack),
-                                          L.DT[dt], cout_pad, cin_pad, 0, None), keep=w)
-        (self.fwd_calls if training else self.prep_calls).append(pack)
+        if training:      # repacked from the live fp32 master every forward (= autocast's cast): batched into one launch
+            plan.add_pack_job(w, self.wpack, self.cout, self.cin, ntaps, cout_pad, cin_pad, 0)
+        else:
+            self.prep_calls.append(Call('myolo_pack_weight', (L.ptr(w), L.DT[w.dtype], self.cout, self.cin, self.k, self.k,
+                                                              L.ptr(self.wpack), L.DT[dt], cout_pad, cin_pad, 0, None), keep=w))
         d = L.ConvDesc()
         d.x = self.x.desc()
         d.w = self.wpack.data_ptr()
@@ -339,9 +341,7 @@ class ConvOp(Op):
             ntaps = self.k * self.k
             self.wpack_t = torch.zeros(cout_pad_t, ntaps, cin_pad_t, dtype=dt, device=dev)
             w = self.weight
-            self.fwd_calls.append(Call('myolo_pack_weight', (
-                L.ptr(w), L.DT[w.dtype], self.cout, self.cin, self.k, self.k, L.ptr(self.wpack_t), L.DT[dt], cout_pad_t,
-                cin_pad_t, 1, None), keep=w))
+            plan.add_pack_job(w, self.wpack_t, self.cout, self.cin, ntaps, cout_pad_t, cin_pad_t, 1)
             self.dg = []
             s = self.s
             gx_full = self.x.desc(grad=True)
@@ -621,6 +621,7 @@ class Plan:
         self.input_grads, self.outputs, self.output_grads = {}, {}, {}
         self.det_grads = []
         self.params, self._pgrad = [], {}
+        self._pack_jobs, self._pack_call = [], None
         self.built = False
 
     # ---- graph construction -------------------------------------------------------------------------
@@ -637,6 +638,25 @@ class Plan:
     def add(self, op):
         self.ops.append(op)
         return op
+
+    def add_pack_job(self, w, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose):
+        self._pack_jobs.append((w, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose))
+
+    def _build_pack_table(self):
+        CH = 8192
+        rows, chunks = [], []
+        for j, (w, dst, cout, cin, ntaps, rp, cp, tr) in enumerate(self._pack_jobs):
+            rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, ntaps, rp, cp, tr, L.DT[w.dtype], L.DT[dst.dtype]))
+            for s0 in range(0, rp * ntaps * cp, CH):
+                chunks.append((j, s0))
+        self._pack_key = tuple(r[0] for r in rows)
+        if not rows:
+            self._pack_call = None
+            return
+        dev = self.device
+        self._pack_tab = torch.tensor(rows, dtype=torch.int64).reshape(-1, 10).to(dev)
+        self._pack_chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
+        self._pack_call = Call('myolo_pack_weights_mt', (L.ptr(self._pack_tab), L.ptr(self._pack_chunks), len(chunks), CH))
 
     def add_input(self, t):
         """declare an input tensor slot (shape/stride/dtype are part of the plan; the pointer is rebound per run)."""
@@ -722,6 +742,7 @@ class Plan:
             self._building = i
             op.build(self)
         self._building = None
+        self._build_pack_table()
         self.built = True
         if torch.device(self.device).type == 'cuda':     # a CPU-device plan is a dry build (shape/launch-list checks only)
             self.prepare()
@@ -739,6 +760,10 @@ class Plan:
         st = L.stream_ptr()
         if self._used[0]:
             self._arena[0][:self._used[0]].zero_()
+        if self._pack_call is not None:
+            if self._pack_key != tuple(j[0].data_ptr() for j in self._pack_jobs):     # a parameter was re-allocated (.to(), load)
+                self._build_pack_table()
+            self._pack_call(st)
         for op in self.ops:
             for c in op.fwd_calls:
                 c(st)

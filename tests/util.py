@@ -62,3 +62,39 @@ class fp16_storage:
 
     def __exit__(self, *exc):
         self.mr.F = self.F
+
+
+def maxpool_tie_gap(tag, x):
+    """smallest relative gap between the two largest values of any SPP max-pool window of the oracle forward on `x`.
+    A gap below the forward rounding noise (~3e-5 in fp32) means the arg-max -- hence the gradient routing -- is decided by
+    rounding: such inputs cannot pin a backward pass and are not used for gradient parity."""
+    import torch.nn.functional as F
+    from oracle import model_ref
+    gaps = []
+    orig = model_ref.spp
+
+    def spp(ctx, p, xx, ks=(5, 9, 13)):
+        x1 = model_ref.conv_block(ctx, p + '.cv1', xx)
+        n, c, _, _ = x1.shape
+        for k in ks:
+            u = F.unfold(F.pad(x1.detach(), (k // 2,) * 4, value=-1e30), k).view(n, c, k * k, -1)
+            t = u.topk(2, dim=2).values
+            gaps.append(((t[:, :, 0] - t[:, :, 1]) / (t[:, :, 0].abs() + 1e-6)).min().item())
+        return model_ref.conv_block(ctx, p + '.cv2', torch.cat([x1] + [F.max_pool2d(x1, k, 1, k // 2) for k in ks], 1))
+    model_ref.spp = spp
+    try:
+        with torch.no_grad():
+            model_ref.forward(load_cfg(tag), {k: v.clone() for k, v in synth_sd(tag).items()}, x, training=True, dropout_p=0.0)
+    finally:
+        model_ref.spp = orig
+    return min(gaps) if gaps else 1.0
+
+
+def tie_free_images(tag, b, h, w, min_gap=1e-4):
+    """first synthetic image batch (seed 1, 2, ...) whose max-pool windows have no near-tie (see maxpool_tie_gap)."""
+    from oracle import synth
+    for seed in range(1, 12):
+        x = synth.synth_images(b, h, w, seed=seed)
+        if maxpool_tie_gap(tag, x) >= min_gap:
+            return x, seed
+    raise RuntimeError('no tie-free synthetic batch found')
