@@ -96,7 +96,8 @@ typedef struct myolo_conv_desc {
 int myolo_conv(const myolo_conv_desc* d, void* stream);
 
 /* wgrad: dw_oihw[co][ci][t] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, (oy*stride+tap_dy[t])>>up, (ox*stride+tap_dx[t])>>up, ci]
- * (fp32 atomics into an OIHW fp32 gradient buffer = Parameter.grad layout).  db (optional, fp32[cout]) += sum dy. */
+ * (into an OIHW fp32 gradient buffer = Parameter.grad layout; split-K partials go through `ws` when given, else fp32 atomics).
+ * db (optional, fp32[cout]) += sum dy. */
 typedef struct myolo_wgrad_desc {
   myolo_tensor x, dy;
   float*  dw;
@@ -106,6 +107,9 @@ typedef struct myolo_wgrad_desc {
   int32_t ksplit;            /* 0 = auto */
   int32_t cout, cin;         /* real weight dims when dy.c / x.c are channel-padded views (0: use dy.c / x.c) */
   int32_t reserved;
+  float*  ws;                /* optional split-K workspace (16-byte aligned): partial tiles are stored there and summed by a
+                                second launch instead of fp32 atomics into dw; NULL: atomics */
+  int64_t ws_bytes;
 } myolo_wgrad_desc;
 int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream);
 

@@ -33,7 +33,8 @@ class WgradDesc(C.Structure):
     _fields_ = [('x', Tensor), ('dy', Tensor), ('dw', C.c_void_p), ('db', C.c_void_p),
                 ('ntaps', C.c_int32), ('stride', C.c_int32), ('up_shift', C.c_int32),
                 ('tap_dy', C.c_int32 * MAX_TAPS), ('tap_dx', C.c_int32 * MAX_TAPS),
-                ('ksplit', C.c_int32), ('cout', C.c_int32), ('cin', C.c_int32), ('reserved', C.c_int32)]
+                ('ksplit', C.c_int32), ('cout', C.c_int32), ('cin', C.c_int32), ('reserved', C.c_int32),
+                ('ws', C.c_void_p), ('ws_bytes', C.c_int64)]
 
 
 class DetLossDesc(C.Structure):

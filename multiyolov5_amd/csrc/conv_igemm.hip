@@ -143,17 +143,19 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
         }
       }
       const int c0 = kc * KC + lseg * SEG;
+      // unconditional loads, out-of-image / padded-channel lanes read the zero page (see myolo_dev.h: a `cond ? load : 0`
+      // select would make hipcc wait vmcnt(0) per element and serialise the prefetch)
 #pragma unroll
       for (int r = 0; r < 2; ++r) {
-        if (arow[r] != nullptr && c0 < p.Cin) ra[r] = ldg16(arow[r] + (int64_t)c0 * ES);
-        else ra[r] = uint4{0u, 0u, 0u, 0u};
+        const char* ap = (arow[r] != nullptr && c0 < p.Cin) ? arow[r] + (int64_t)c0 * ES : zero_page();
+        ra[r] = ldg16(ap);
       }
       const int wt = p.tap_w[tap];
 #pragma unroll
       for (int r = 0; r < BROWS; ++r) {
-        const int brow = lrow + r * 64;
-        if (BN >= 64 || brow < BN)
-          rb[r] = ldg16(wbase + ((int64_t)(brow * p.wtaps + wt) * p.cin_pad + c0) * ES);
+        int brow = lrow + r * 64;
+        if (BN < 64) brow &= (BN - 1);                 // BN = 32: the upper half of the threads reloads a valid row (unused)
+        rb[r] = ldg16(wbase + ((int64_t)(brow * p.wtaps + wt) * p.cin_pad + c0) * ES);
       }
     };
     auto store_lds = [&](int buf) {
@@ -262,17 +264,21 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
   }
 
   if (p.stats) {
-    // reduce partials over the 4 lane groups (rows), then one atomic per channel per wave
+    // lanes -> wave (rows of the fragment) -> workgroup (LDS) -> one coalesced atomic per channel per workgroup
+    float* red = reinterpret_cast<float*>(smem);       // [4 waves][2*BN]; the last tile's epilogue ended with a barrier
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       float s = st_s[nf], q = st_q[nf];
       s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
       q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      const int c = tn * BN + nf * 16 + (lane & 15);
-      if (lane < 16 && c < p.Cout) {
-        atomicAdd(p.stats + c, s);
-        atomicAdd(p.stats + p.Cout + c, q);
-      }
+      if (lane < 16) { red[wave * 2 * BN + nf * 16 + lane] = s; red[wave * 2 * BN + BN + nf * 16 + lane] = q; }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += THREADS) {
+      const float a = red[t] + red[2 * BN + t] + red[4 * BN + t] + red[6 * BN + t];
+      const int cl = t < BN ? t : t - BN;
+      const int c = tn * BN + cl;
+      if (c < p.Cout) atomicAdd(p.stats + (t < BN ? c : p.Cout + c), a);
     }
   }
 }
@@ -305,6 +311,10 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   if (d->x.c % seg || d->x.sw % seg || d->x.sh % seg || d->x.sn % seg || ((uintptr_t)d->x.ptr & 15)) return MYOLO_EINVAL;
   if (d->det_no > 0 && (d->y.c % d->det_no)) return MYOLO_EINVAL;
   if (d->res.ptr && d->res.dtype != dt) return MYOLO_EINVAL;
+  if (dt == MYOLO_F16) {                       // HBM-bound layers: the streaming kernel (conv_stream.hip)
+    const int r = myolo_conv_stream_try(d, stream);
+    if (r != -1) return r;
+  }
   ConvK k;
   k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw;
   k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;

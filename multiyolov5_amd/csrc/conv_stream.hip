@@ -1,0 +1,370 @@
+// Streaming implicit-GEMM convolution for the HBM-bound layers (fp16): small K = taps*Cin, huge M = pixels.
+//
+//   The per-layer roofline puts 69 of the 79 convolutions of yolov5s+PSP on the memory side: the job is to
+//   stream activations at HBM rate, the MFMA work hides underneath.  So, unlike the LDS-tiled kernel in conv_igemm.hip
+//   (one 64-byte K chunk per workgroup barrier), here
+//     * the whole weight panel of the workgroup's N tile ([BN][taps*cin_pad], <= ~96 KB) is staged in LDS ONCE;
+//     * every wave owns 32-pixel row tiles and loads its MFMA A fragments straight from global memory (lane = pixel row
+//       lane&15, 16-byte K segment lane>>4: whole 64-byte pieces of NHWC rows), through a 4-deep register ring: three
+//       chunks (12 KB per wave) are always in flight, and there is NO barrier in the main loop -- waves never wait for
+//       each other, only for their own loads (counted vmcnt);
+//     * the epilogue (BN statistics, scale/shift, SiLU, residual) goes through a small wave-private LDS transpose so that
+//       NHWC stores are 16-byte row-contiguous.
+//   Workgroups are persistent over XCD-contiguous ranges of row tiles (3x3 halos of neighbouring tiles hit the same L2).
+//
+// Same contract as myolo_conv (include/myolo.h); selected by myolo_conv when the layer qualifies (conv_igemm.hip).
+#include "myolo_dev.h"
+#include <stdlib.h>
+
+namespace stream {
+
+constexpr int WAVES = 8;
+constexpr int THREADS = WAVES * 64;
+constexpr int RING = 4;
+
+struct ConvS {
+  const char* x; int64_t x_sn, x_sh, x_sw; int Hi, Wi, Cin;
+  char* y; int64_t y_sn, y_sh, y_sw; int Ho, Wo, Cout, N;
+  const char* w; int cin_pad, cout_pad, wtaps, ntaps, stride, up;
+  int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS], tap_w[MYOLO_MAX_TAPS];
+  const float* scale; const float* shift; int act; int accumulate;
+  const char* res; int64_t r_sn, r_sh, r_sw;
+  float* stats; int M; int ntiles; int tiles_per_xcd; int pitchB; int xdense, ydense; int dbg;
+};
+
+__device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // H = {0,2,3,1}
+
+// EPI 0: raw output (+ BatchNorm statistics) -- the training forward and every dgrad;  EPI 1: scale/shift + activation (eval)
+template <int BN, int KB, int EPI, int EXTRA>
+__global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
+  constexpr int NF = BN / 16;
+  constexpr int KCH = 32 * KB;                 // halves per A chunk
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sB = smem;                             // [BN][pitchB] weight panel
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int tn = blockIdx.y;
+
+  // ---- stage the weight panel once ----
+  {
+    const int vec_per_tap = p.cin_pad / 8;
+    const int vec_per_row = p.ntaps * vec_per_tap;
+    const int total = BN * vec_per_row;
+    for (int v = tid; v < total; v += THREADS) {
+      const int r = v / vec_per_row; const int q = v - r * vec_per_row;
+      const int t = q / vec_per_tap; const int s = q - t * vec_per_tap;
+      const uint4 val = ldg16(p.w + ((int64_t)((tn * BN + r) * p.wtaps + p.tap_w[t]) * p.cin_pad + s * 8) * 2);
+      const int g = t * vec_per_tap + s;                      // 16-byte segment index inside the panel row
+      *reinterpret_cast<uint4*>(sB + r * p.pitchB + (g >> 2) * 64 + (((g & 3) ^ swz(r)) << 4)) = val;
+    }
+  }
+  // epilogue constants live in LDS: a global load inside the epilogue would sit BEHIND the prefetched activations in the
+  // in-order vmcnt queue and drain the whole pipeline every tile
+  float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [2][BN] scale, shift
+  if (EPI == 1)
+    for (int c = tid; c < BN; c += THREADS) {
+      const int cg = tn * BN + c;
+      sT[c] = (p.scale && cg < p.Cout) ? p.scale[cg] : 1.0f;
+      sT[BN + c] = (p.shift && cg < p.Cout) ? p.shift[cg] : 0.0f;
+    }
+  int* sTap = reinterpret_cast<int*>(sT + 2 * BN);                        // [2][MAX_TAPS] tap_dy, tap_dx
+  for (int t = tid; t < p.ntaps; t += THREADS) { sTap[t] = p.tap_dy[t]; sTap[MYOLO_MAX_TAPS + t] = p.tap_dx[t]; }
+  __syncthreads();
+
+  const int kchunks = p.cin_pad / KCH;
+  const int cpt = p.ntaps * kchunks;            // chunks per tile
+  const int HWo = p.Ho * p.Wo;
+  const int Hlog = p.Hi << p.up, Wlog = p.Wi << p.up;
+
+  // tiles of this wave: XCD-contiguous ranges, interleaved over the waves resident on the XCD
+  const int xcd = blockIdx.x & 7;
+  const int wslot = (blockIdx.x >> 3) * WAVES + wave;
+  const int wstride = (gridDim.x >> 3) * WAVES;
+  const int tile_lo = xcd * p.tiles_per_xcd;
+  int tile_hi = tile_lo + p.tiles_per_xcd;
+  if (tile_hi > p.ntiles) tile_hi = p.ntiles;
+  const int my_first = tile_lo + wslot;
+  const int ntl = my_first < tile_hi ? (tile_hi - my_first + wstride - 1) / wstride : 0;   // tiles of this wave
+  const int nchunks = ntl * cpt;
+
+  // The MFMA is issued as D^T = W . X^T: acc[nf][r] belongs to output channel tn*BN + nf*16 + 4*lq + r of pixel (lane&15),
+  // i.e. every lane owns 4 CONSECUTIVE channels of one pixel: 8-byte NHWC stores straight from registers (no LDS transpose).
+  float st_s[NF][4], st_q[NF][4];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st_s[nf][r] = 0.f; st_q[nf][r] = 0.f; }
+
+  // ---- issue cursor ----
+  int i_tile = my_first, i_tap = 0, i_kc = 0, i_left = nchunks;
+  const char* i_base[2] = {nullptr, nullptr};
+  int i_y0[2], i_x0[2]; bool i_ok[2];
+  auto decode_issue = [&]() {
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int m = i_tile * 32 + mf * 16 + l15;
+      i_ok[mf] = m < p.M;
+      const int mm = i_ok[mf] ? m : 0;
+      if (p.xdense) {                       // 1x1 stride 1 over a pixel-dense view: pixel m is at base + m*sw
+        i_base[mf] = p.x + (int64_t)mm * p.x_sw * 2;
+        i_y0[mf] = 0; i_x0[mf] = 0;
+      } else {
+        const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+        i_base[mf] = p.x + (int64_t)n * p.x_sn * 2;
+        i_y0[mf] = oy * p.stride; i_x0[mf] = ox * p.stride;
+      }
+    }
+  };
+  if (i_left > 0) decode_issue();
+  uint4 ring[RING][2 * KB];
+  auto issue = [&](uint4* dst) {
+    // branch-free: every load is issued unconditionally, dead lanes / padded channels / finished waves read the zero page
+    const bool live = i_left > 0;
+    const char* zp = zero_page();
+    if (p.xdense) {
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int c0 = i_kc * KCH + kb * 32 + lq * 8;
+          const char* ptr = (live && i_ok[mf] && c0 < p.Cin) ? i_base[mf] + c0 * 2 : zp;
+          dst[mf * KB + kb] = ldg16(ptr);
+        }
+    } else {
+      // wave-uniform tap index -> scalar loads of the tap table (a VGPR-indexed table read is a global_load that would
+      // queue BEHIND the prefetched activations in the in-order vmcnt queue)
+      const int ut = __builtin_amdgcn_readfirstlane(i_tap);
+      const int dy = sTap[ut], dx = sTap[MYOLO_MAX_TAPS + ut];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf) {
+        int iy = i_y0[mf] + dy, ix = i_x0[mf] + dx;
+        const bool ok = live && i_ok[mf] && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
+        iy >>= p.up; ix >>= p.up;
+        const char* rp = i_base[mf] + ((int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * 2;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+          const int c0 = i_kc * KCH + kb * 32 + lq * 8;
+          const char* ptr = (ok && c0 < p.Cin) ? rp + c0 * 2 : zp;
+          dst[mf * KB + kb] = ldg16(ptr);
+        }
+      }
+    }
+    if (live) {
+      --i_left;
+      if (++i_kc == kchunks) {
+        i_kc = 0;
+        if (++i_tap == p.ntaps) { i_tap = 0; i_tile += wstride; if (i_left > 0) decode_issue(); }
+      }
+    }
+  };
+
+  // ---- compute cursor ----
+  int c_tile = my_first, c_tap = 0, c_kc = 0;
+  f4_t acc[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  auto epilogue = [&](int tile) {
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int m = tile * 32 + mf * 16 + l15;
+      const bool mok = m < p.M;
+      int64_t yoff, roff = 0;
+      if (p.ydense) {
+        yoff = (int64_t)m * p.y_sw;
+        if (p.res) roff = (int64_t)m * p.r_sw;
+      } else {
+        const int mm = mok ? m : 0;
+        const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+        yoff = (int64_t)n * p.y_sn + (int64_t)oy * p.y_sh + (int64_t)ox * p.y_sw;
+        if (p.res) roff = (int64_t)n * p.r_sn + (int64_t)oy * p.r_sh + (int64_t)ox * p.r_sw;
+      }
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int c0 = tn * BN + nf * 16 + 4 * lq;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = acc[mf][nf][r];
+          acc[mf][nf][r] = 0.f;
+          if (EPI == 0) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; v[r] = v0; }
+          else {
+            const int cl = nf * 16 + 4 * lq + r;
+            v[r] = act_f(v0 * sT[cl] + sT[BN + cl], p.act);
+          }
+        }
+        if (!mok || c0 >= p.Cout) continue;            // Cout % 4 == 0 (checked on the host): whole 8-byte groups only
+        half_t* yp = reinterpret_cast<half_t*>(p.y) + yoff + c0;
+        if (EXTRA) {                                   // residual / accumulate: loads inside the epilogue (drain the prefetch queue)
+          if (p.res) {
+            const h4_t g = *reinterpret_cast<const h4_t*>(reinterpret_cast<const half_t*>(p.res) + roff + c0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)g[r];
+          }
+          if (p.accumulate) {
+            const h4_t g = *reinterpret_cast<const h4_t*>(yp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)g[r];
+          }
+        }
+        h4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+        *reinterpret_cast<h4_t*>(yp) = o;
+      }
+    }
+  };
+
+  auto compute = [&](const uint4* a, const bool live) {
+    // panel rows are 64-byte blocks with the 16-byte segment XOR-swizzled by H[(row>>2)&3] (pitch/64 is odd): conflict-free
+    // for the ds_read_b128 lane groups of the fragment pattern (row = lane&15, segment = lane>>4)
+    const char* brow = sB + l15 * p.pitchB + (c_tap * p.cin_pad + c_kc * KCH) * 2 + ((lq ^ swz(l15)) << 4);
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const uint4 b = *reinterpret_cast<const uint4*>(brow + nf * 16 * p.pitchB + kb * 64);
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)      // weights as the A operand, pixels as the B operand: D[cout][pixel]
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8_t*>(&b),
+                                                               *reinterpret_cast<const h8_t*>(&a[mf * KB + kb]), acc[mf][nf], 0, 0, 0);
+      }
+    }
+    if (live && ++c_kc == kchunks) {
+      c_kc = 0;
+      if (++c_tap == p.ntaps) { c_tap = 0; epilogue(c_tile); c_tile += wstride; }
+    }
+  };
+
+  // ---- software pipeline: RING-1 chunks in flight ----
+#pragma unroll
+  for (int j = 0; j < RING - 1; ++j) issue(ring[j]);
+  for (int q = 0; q < nchunks; q += RING) {
+#pragma unroll
+    for (int j = 0; j < RING; ++j) {
+      issue(ring[(j + RING - 1) % RING]);
+      compute(ring[j], q + j < nchunks);          // dead chunks (zero page) only add zeros
+    }
+  }
+
+  if (EPI == 0 && p.stats) {
+    // per-channel sums: lanes -> wave (shuffles over the 16 pixel lanes) -> workgroup (LDS) -> ONE coalesced atomic per
+    // channel per workgroup.  (Per-wave atomics on the same 2*Cout addresses cost ~400 us per launch.)
+    __syncthreads();                                   // every wave is done with the weight panel
+    float* red = reinterpret_cast<float*>(smem);       // [WAVES][2*BN]
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = st_s[nf][r], q2 = st_q[nf][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q2 += __shfl_xor(q2, o, 64); }
+        if (l15 == 0) {
+          const int cl = nf * 16 + 4 * lq + r;
+          red[wave * 2 * BN + cl] = s;
+          red[wave * 2 * BN + BN + cl] = q2;
+        }
+      }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += THREADS) {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) a += red[w * 2 * BN + t];
+      const int cl = t < BN ? t : t - BN;
+      const int c = tn * BN + cl;
+      if (c < p.Cout) atomicAdd(p.stats + (t < BN ? c : p.Cout + c), a);
+    }
+  }
+}
+
+template <int BN, int KB, int EPI, int EXTRA>
+int launch3(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
+  auto kern = conv_stream_kernel<BN, KB, EPI, EXTRA>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+template <int BN, int KB, int EPI>
+int launch2(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
+  const bool extra = k.res != nullptr || k.accumulate;
+  return extra ? launch3<BN, KB, EPI, 1>(k, grid_x, ntile_n, smem, st) : launch3<BN, KB, EPI, 0>(k, grid_x, ntile_n, smem, st);
+}
+template <int BN, int KB>
+int launch(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
+  const bool raw = !k.scale && !k.shift && k.act == MYOLO_ACT_NONE;
+  return raw ? launch2<BN, KB, 0>(k, grid_x, ntile_n, smem, st) : launch2<BN, KB, 1>(k, grid_x, ntile_n, smem, st);
+}
+
+}  // namespace stream
+
+static inline int panel_pitch(int K) {                    // bytes; multiple of 64 with an odd number of 64-byte blocks
+  int blocks = (K * 2 + 63) / 64;
+  if (!(blocks & 1)) ++blocks;
+  return blocks * 64;
+}
+
+// returns -1 when the layer does not qualify (caller falls back to the LDS-tiled kernel), else a hipError_t / 0
+int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
+  using namespace stream;
+  static const int min_tiles = getenv("MYOLO_STREAM_MIN_TILES") ? atoi(getenv("MYOLO_STREAM_MIN_TILES")) : 2048;
+  static const bool off = getenv("MYOLO_NO_STREAM") != nullptr;
+  if (off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
+  if (d->cin_pad % 32) return -1;
+  // N tile: the weight panel [BN][ntaps*cin_pad] (+16 B row padding) must fit beside the 8 wave-private staging areas
+  const int K = d->ntaps * d->cin_pad;
+  int bn = 0;
+  const int cands[2] = {64, 32};               // BN = 128 needs > 200 VGPRs with the per-channel statistics: two N tiles instead
+  for (int i = 0; i < 2; ++i) {
+    const int b = cands[i];
+    if (d->cout_pad % b) continue;
+    if (b * panel_pitch(K) + 2 * b * 4 + 256 <= 144 * 1024) { bn = b; break; }
+  }
+  if (!bn) return -1;
+  if (d->cout_pad / bn > 4) return -1;                 // A would be re-streamed too often: the tiled kernel wins
+  ConvS k;
+  k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw;
+  k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;
+  k.y = (char*)d->y.ptr; k.y_sn = d->y.sn; k.y_sh = d->y.sh; k.y_sw = d->y.sw;
+  k.Ho = d->y.h; k.Wo = d->y.w; k.Cout = d->y.c; k.N = d->y.n;
+  k.w = (const char*)d->w; k.cin_pad = d->cin_pad; k.cout_pad = d->cout_pad; k.wtaps = d->wtaps;
+  k.ntaps = d->ntaps; k.stride = d->stride; k.up = d->up_shift;
+  for (int i = 0; i < MYOLO_MAX_TAPS; ++i) { k.tap_dy[i] = d->tap_dy[i]; k.tap_dx[i] = d->tap_dx[i]; k.tap_w[i] = d->tap_w[i]; }
+  k.scale = d->scale; k.shift = d->shift; k.act = d->act; k.accumulate = d->accumulate;
+  k.res = (const char*)d->res.ptr; k.r_sn = d->res.sn; k.r_sh = d->res.sh; k.r_sw = d->res.sw;
+  k.stats = d->stats;
+  const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
+  if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
+  k.M = (int)M;
+  k.ntiles = (int)((M + 31) / 32);
+  if (k.ntiles < min_tiles) return -1;                      // small maps: launch/prologue bound, keep the tiled kernel
+  k.tiles_per_xcd = (k.ntiles + 7) / 8;
+  k.pitchB = panel_pitch(K);
+  auto dense = [](int64_t sn, int64_t sh, int64_t sw, int H, int W) { return sh == (int64_t)W * sw && sn == (int64_t)H * sh; };
+  k.ydense = dense(k.y_sn, k.y_sh, k.y_sw, k.Ho, k.Wo) && (!k.res || dense(k.r_sn, k.r_sh, k.r_sw, k.Ho, k.Wo));
+  k.xdense = d->ntaps == 1 && d->stride == 1 && d->up_shift == 0 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 &&
+             k.Hi == k.Ho && k.Wi == k.Wo && dense(k.x_sn, k.x_sh, k.x_sw, k.Hi, k.Wi);
+  static const int dbg = getenv("MYOLO_STREAM_DBG") ? atoi(getenv("MYOLO_STREAM_DBG")) : 0;
+  k.dbg = dbg;
+  if (k.stats && (k.scale || k.shift || k.act != MYOLO_ACT_NONE)) return -1;   // statistics only with the raw epilogue
+  int smem = bn * k.pitchB + 2 * bn * 4 + 2 * MYOLO_MAX_TAPS * 4;
+  if (smem < WAVES * 2 * bn * 4) smem = WAVES * 2 * bn * 4;
+  const int ntile_n = d->cout_pad / bn;
+  int per_cu = (160 * 1024) / (smem + 1024);
+  if (per_cu > 2) per_cu = 2;                          // 8-wave workgroups: 2 per CU at <= 128 VGPRs
+  if (per_cu < 1) per_cu = 1;
+  int per_xcd = 32 * per_cu / ntile_n;                 // 32 CUs per XCD
+  if (per_xcd < 1) per_xcd = 1;
+  const int need = (k.tiles_per_xcd + WAVES - 1) / WAVES;
+  if (per_xcd > need) per_xcd = need;
+  const int grid_x = per_xcd * 8;
+  hipStream_t st = (hipStream_t)stream;
+  const bool kb2 = (d->cin_pad % 64) == 0;
+  if (bn == 64) return kb2 ? launch<64, 2>(k, grid_x, ntile_n, smem, st) : launch<64, 1>(k, grid_x, ntile_n, smem, st);
+  return kb2 ? launch<32, 2>(k, grid_x, ntile_n, smem, st) : launch<32, 1>(k, grid_x, ntile_n, smem, st);
+}

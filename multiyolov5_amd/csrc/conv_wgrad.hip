@@ -13,6 +13,7 @@
 // range of pixels (split-K); partial tiles are combined with fp32 atomics.  Replaces the autograd wgrad of
 // nn.Conv2d (reference models/common.py:38,42; invoked by loss.backward() at train.py:371,392).
 #include "myolo_dev.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,6 +29,8 @@ struct WgradK {
   int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
   int M, ksplit, pix_per_split, tiles_co, tiles_ci;
   int cout_w, cin_w;   // real (unpadded) weight dims: bounds of dw
+  float* ws;           // split-K partials [ksplit][ntaps][tiles_co*64][tiles_ci*64] (plain stores) or NULL (atomics)
+  int dbg;
 };
 
 template <typename T> struct Pitch;                       // LDS row pitch in bytes for a [KP][64] tile
@@ -74,20 +77,20 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradK p) {
       const int v = tid + l * THREADS;
       const int prow = v / SEGS_PER_ROW, cs = v - prow * SEGS_PER_ROW;
       const int m = m_begin + s * KP + prow;
-      rd[l] = uint4{0u, 0u, 0u, 0u};
-      rx[l] = uint4{0u, 0u, 0u, 0u};
-      if (m < m_end) {
-        const int n = m / HWo; const int rem = m - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
-        const int cd = co0 + cs * SEG;
-        if (cd < p.Cout)
-          rd[l] = ldg16(p.dy + ((int64_t)n * p.d_sn + (int64_t)oy * p.d_sh + (int64_t)ox * p.d_sw + cd) * ES);
-        int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
-        const int cx = ci0 + cs * SEG;
-        if (iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog && cx < p.Cin) {
-          iy >>= p.up; ix >>= p.up;
-          rx[l] = ldg16(p.x + ((int64_t)n * p.x_sn + (int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw + cx) * ES);
-        }
-      }
+      // unconditional loads; rows past the split / outside the image / padded channels read the zero page (myolo_dev.h)
+      const bool live = m < m_end;
+      const int mm = live ? m : m_begin;
+      const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+      const int cd = co0 + cs * SEG;
+      const char* dp = (live && cd < p.Cout)
+          ? p.dy + ((int64_t)n * p.d_sn + (int64_t)oy * p.d_sh + (int64_t)ox * p.d_sw + cd) * ES : zero_page();
+      rd[l] = (p.dbg & 2) ? uint4{0u, 0u, 0u, 0u} : ldg16(dp);
+      int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
+      const int cx = ci0 + cs * SEG;
+      const bool xin = live && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog && cx < p.Cin;
+      iy >>= p.up; ix >>= p.up;
+      const char* xp = xin ? p.x + ((int64_t)n * p.x_sn + (int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw + cx) * ES : zero_page();
+      rx[l] = (p.dbg & 2) ? uint4{0u, 0u, 0u, 0u} : ldg16(xp);
     }
   };
   auto stage = [&](int buf) {
@@ -160,17 +163,62 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradK p) {
   }
 
   // acc[i][j][r] = D[row(co) = wr*32+i*16+4*(lane>>4)+r][col(ci) = wc*32+j*16+(lane&15)]
+  if (p.ws) {
+    // split-K partial tile -> workspace with plain 64-byte-coalesced stores; wgrad_reduce_kernel sums the splits.
+    // (fp32 atomics straight into OIHW cost 120 of 165 us on a 3x3 64->64 layer: 4M scattered read-modify-writes.)
+    const int CoP = p.tiles_co * WT, CiP = p.tiles_ci * WT;
+    float* wt = p.ws + ((int64_t)(split * p.ntaps + tap) * CoP) * CiP;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = co0 + wr * 32 + i * 16 + 4 * (lane >> 4) + r;
-        const int ci = ci0 + wc * 32 + j * 16 + (lane & 15);
-        if (co < p.cout_w && ci < p.cin_w) atomicAdd(p.dw + ((int64_t)co * p.cin_w + ci) * p.ntaps + tap, acc[i][j][r]);
-      }
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wr * 32 + i * 16 + 4 * (lane >> 4) + r;
+          const int ci = ci0 + wc * 32 + j * 16 + (lane & 15);
+          wt[(int64_t)co * CiP + ci] = acc[i][j][r];
+        }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wr * 32 + i * 16 + 4 * (lane >> 4) + r;
+          const int ci = ci0 + wc * 32 + j * 16 + (lane & 15);
+          if (co < p.cout_w && ci < p.cin_w && !(p.dbg & 1)) atomicAdd(p.dw + ((int64_t)co * p.cin_w + ci) * p.ntaps + tap, acc[i][j][r]);
+        }
+  }
   if (p.db && tci == 0 && tap == 0 && tid < WT && co0 + tid < p.cout_w) atomicAdd(p.db + co0 + tid, bias_part);
+}
+
+// dw[co][ci][t] += sum over splits of ws[s][t][co][ci].  A workgroup owns 64 consecutive weights (coalesced along ci); its 4
+// waves take every 4th split and combine through LDS.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ks, int ntaps,
+                                                           int CoP, int CiP, int cout, int cin) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t total = (int64_t)ntaps * cout * cin;
+  const int64_t slice = (int64_t)ntaps * CoP * CiP;
+  for (int64_t base = (int64_t)blockIdx.x * 64; base < total; base += (int64_t)gridDim.x * 64) {
+    const int64_t i = base + lane;
+    float a = 0.f;
+    int ci = 0, co = 0, t = 0;
+    if (i < total) {
+      ci = (int)(i % cin); co = (int)((i / cin) % cout); t = (int)(i / ((int64_t)cin * cout));
+      const float* src = ws + ((int64_t)t * CoP + co) * CiP + ci;
+      float a0 = 0.f, a1 = 0.f;
+      int s = wave;
+      for (; s + 4 < ks; s += 8) { a0 += src[(int64_t)s * slice]; a1 += src[(int64_t)(s + 4) * slice]; }
+      for (; s < ks; s += 4) a0 += src[(int64_t)s * slice];
+      a = a0 + a1;
+    }
+    red[wave][lane] = a;
+    __syncthreads();
+    if (wave == 0 && i < total) dw[((int64_t)co * cin + ci) * ntaps + t] += red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    __syncthreads();
+  }
 }
 
 }  // namespace
@@ -205,13 +253,30 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;
   }
+  const int CoP = k.tiles_co * WT, CiP = k.tiles_ci * WT;
+  const int64_t slice_bytes = (int64_t)k.ntaps * CoP * CiP * sizeof(float);
+  k.ws = nullptr;
+  // 1x1 convs keep the atomics: their OIHW gradient is contiguous along ci, so the atomics coalesce (22 us for 4M of them) and
+  // beat a second pass over ~1000 tiny slices; k x k gradients are strided by the tap count and go through the workspace.
+  if (d->ws && k.ntaps > 1 && d->ws_bytes >= slice_bytes * 2 && ks > 1 && (((uintptr_t)d->ws) & 15) == 0) {
+    const int64_t fit = d->ws_bytes / slice_bytes;
+    if (ks > fit) ks = (int)fit;
+    k.ws = d->ws;
+  }
   int pps = (int)((M + ks - 1) / ks);
   pps = (pps + KP - 1) / KP * KP;
   ks = (int)((M + pps - 1) / pps);
   k.ksplit = ks; k.pix_per_split = pps;
+  static const int dbg = getenv("MYOLO_WGRAD_DBG") ? atoi(getenv("MYOLO_WGRAD_DBG")) : 0;
+  k.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   if (dt == MYOLO_F16) hipLaunchKernelGGL(wgrad_kernel<half_t>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
   else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
+  if (k.ws) {
+    const int64_t total = (int64_t)k.ntaps * k.cout_w * k.cin_w;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, st, k.ws, k.dw, ks, k.ntaps, CoP, CiP,
+                       k.cout_w, k.cin_w);
+  }
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

@@ -70,8 +70,17 @@ template <> struct Vec<float> {
   }
 };
 
-__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
-__device__ __forceinline__ void stg16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+// explicit global address space: pointers that went through a select (e.g. with the zero page) would otherwise decay to
+// FLAT loads, which also count on lgkmcnt and defeat counted vmcnt waits
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4_t g_u32x4_t;
+__device__ __forceinline__ uint4 ldg16(const void* p) {
+  const u32x4_t v = *(const g_u32x4_t*)(p);
+  return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void stg16(void* p, const uint4& v) {
+  *(g_u32x4_t*)(p) = u32x4_t{v.x, v.y, v.z, v.w};
+}
 
 // view addressing (strides in elements)
 template <typename T>
@@ -84,6 +93,12 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+
+// 256 zero bytes in device memory.  Out-of-bounds / padded fragment loads are redirected here with an ADDRESS select and the
+// load itself stays unconditional: a `cond ? load : 0` select makes hipcc branch around every load and wait vmcnt(0) per
+// element, which serialises a software-pipelined K loop (cdna_hip_programming.md, section 5 trap 4c).
+__device__ __attribute__((aligned(256))) static unsigned int g_zero_page[64];
+__device__ __forceinline__ const char* zero_page() { return reinterpret_cast<const char*>(g_zero_page); }
 
 // ---- strips of a dense channels-last [N,H,W,C] tensor: `npix` consecutive pixels of one row = npix*C contiguous elements.
 // Staged through LDS so that HBM sees 16-byte row-contiguous accesses although C (19 classes) is not a vector multiple.
@@ -111,3 +126,6 @@ static inline int grid_for(int64_t work_items, int threads, int max_blocks = 204
   if (b > max_blocks) b = max_blocks;
   return (int)b;
 }
+
+// conv_stream.hip: streaming variant of myolo_conv; -1 = layer does not qualify
+int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream);

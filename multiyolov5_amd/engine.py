@@ -372,6 +372,8 @@ class ConvOp(Op):
         wd.dw = plan.pgrad(self.weight).data_ptr()
         wd.db = plan.pgrad(self.bias).data_ptr() if self.bias is not None else None
         wd.ntaps, wd.stride, wd.up_shift, wd.ksplit, wd.cout, wd.cin = self.k * self.k, self.s, 0, 0, self.cout, self.cin
+        ws = plan.wgrad_workspace()
+        wd.ws, wd.ws_bytes = ws.data_ptr(), ws.numel() * 4
         tdy, tdx, _ = taps_fwd(self.k, self.d, self.pad)
         fill_taps(wd, tdy, tdx)
         self.wd = wd
@@ -697,6 +699,12 @@ class Plan:
     def f32_bwd_zero(self, n):
         """fp32 scratch zeroed at the start of every backward (BN backward sums, gate partials)."""
         return self._carve(1, n)
+
+    def wgrad_workspace(self):
+        """split-K partial tiles of myolo_conv_wgrad (shared by all convs of the plan: launches are stream-ordered)."""
+        if not hasattr(self, '_wg_ws'):
+            self._wg_ws = torch.empty(48 << 20 >> 2, dtype=torch.float32, device=self.device)
+        return self._wg_ws
 
     def rng_counter(self):
         if not hasattr(self, '_rng'):
