@@ -147,8 +147,9 @@ int myolo_copy_up_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int scal
 /* bilinear, align_corners=True (yolo.py:57..174, common.py:534-537, detect.py:191) */
 int myolo_bilinear_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream);
 int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
-/* nn.AdaptiveAvgPool2d(k) (common.py:521-524, 214): out [n,k,k,c] */
-int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream);
+/* nn.AdaptiveAvgPool2d(k) (common.py:521-524, 214): out [n,k,k,c].  scratch (optional): fp32[n*k*k*c] ZEROED by the caller;
+ * with it, big bins are summed by many workgroups in parallel. */
+int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, float* scratch, void* stream);
 int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
 /* FFM gate: out = feat*att + feat, att [n,1,1,c] (common.py:228-229) */
 int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream);

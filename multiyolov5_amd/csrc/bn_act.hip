@@ -18,6 +18,16 @@ struct PixDec {  // linear pixel -> (n,y,x) of a view
   }
 };
 
+// all views of a plan slice CHANNELS of dense NHWC buffers: pixel p of such a view sits at ptr + p*sw (no div/mod per vector)
+__device__ __forceinline__ bool pix_dense(const myolo_tensor& t) { return t.sh == (int64_t)t.w * t.sw && t.sn == (int64_t)t.h * t.sh; }
+template <typename T>
+__device__ __forceinline__ T* pptr(const myolo_tensor& t, bool dense, const PixDec& pd, int64_t pix) {
+  if (dense) return reinterpret_cast<T*>(t.ptr) + pix * t.sw;
+  int n, yy, xx;
+  pd.get(pix, n, yy, xx);
+  return vptr<T>(t, n, yy, xx);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -53,22 +63,21 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
   const int G = C / SEG;
   const int64_t total = M * G;
   const PixDec pd(y);
+  const bool dense = pix_dense(y) && pix_dense(out) && (!res.ptr || pix_dense(res));
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = v / G;
     const int cg = (int)(v - pix * G);
-    int n, yy, xx;
-    pd.get(pix, n, yy, xx);
     float f[SEG];
-    Vec<T>::unpack(ldg16(vptr<T>(y, n, yy, xx) + cg * SEG), f);
+    Vec<T>::unpack(ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), f);
 #pragma unroll
     for (int i = 0; i < SEG; ++i) f[i] = act_f(f[i] * tab[cg * SEG + i] + tab[C + cg * SEG + i], act);
     if (res.ptr) {
       float g[SEG];
-      Vec<T>::unpack(ldg16(vptr<T>(res, n, yy, xx) + cg * SEG), g);
+      Vec<T>::unpack(ldg16(pptr<T>(res, dense, pd, pix) + cg * SEG), g);
 #pragma unroll
       for (int i = 0; i < SEG; ++i) f[i] += g[i];
     }
-    stg16(vptr<T>(out, n, yy, xx) + cg * SEG, Vec<T>::pack(f));
+    stg16(pptr<T>(out, dense, pd, pix) + cg * SEG, Vec<T>::pack(f));
   }
 }
 
@@ -95,17 +104,23 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
     s0[i] = 0.f; s1[i] = 0.f;
   }
   const PixDec pd(y);
-  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += (int64_t)gridDim.x * PPB) {
-    int n, yy, xx;
-    pd.get(pix, n, yy, xx);
-    float fy[SEG], fg[SEG];
-    Vec<T>::unpack(ldg16(vptr<T>(y, n, yy, xx) + cg * SEG), fy);
-    Vec<T>::unpack(ldg16(vptr<T>(gout, n, yy, xx) + cg * SEG), fg);
+  const bool dense = pix_dense(y) && pix_dense(gout);
+  const int64_t stride = (int64_t)gridDim.x * PPB;
+  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += 2 * stride) {      // two pixels in flight per thread
+    const int64_t pix2 = pix + stride;
+    const bool has2 = pix2 < M;
+    float fy[SEG], fg[SEG], fy2[SEG], fg2[SEG];
+    const uint4 ry = ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), rg = ldg16(pptr<T>(gout, dense, pd, pix) + cg * SEG);
+    const int64_t q = has2 ? pix2 : pix;
+    const uint4 ry2 = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG), rg2 = ldg16(pptr<T>(gout, dense, pd, q) + cg * SEG);
+    Vec<T>::unpack(ry, fy); Vec<T>::unpack(rg, fg); Vec<T>::unpack(ry2, fy2); Vec<T>::unpack(rg2, fg2);
+    const float w2 = has2 ? 1.f : 0.f;
 #pragma unroll
     for (int i = 0; i < SEG; ++i) {
       const float dz = fg[i] * act_grad_f(fy[i] * sc[i] + sh[i], act);
-      s0[i] += dz;
-      s1[i] += dz * (fy[i] - mean[i]) * istd[i];
+      const float dz2 = w2 * fg2[i] * act_grad_f(fy2[i] * sc[i] + sh[i], act);
+      s0[i] += dz + dz2;
+      s1[i] += (dz * (fy[i] - mean[i]) + dz2 * (fy2[i] - mean[i])) * istd[i];
     }
   }
   float* mine = red + (size_t)pl * (G * SEG * 2) + cg * SEG * 2;
@@ -150,14 +165,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
   const int G = C / SEG;
   const int64_t total = M * G;
   const PixDec pd(y);
+  const bool dense = pix_dense(y) && pix_dense(gout) && pix_dense(dy) && (!gres.ptr || pix_dense(gres));
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
     const int64_t pix = v / G;
     const int cg = (int)(v - pix * G);
-    int n, yy, xx;
-    pd.get(pix, n, yy, xx);
     float fy[SEG], fg[SEG], o[SEG];
-    Vec<T>::unpack(ldg16(vptr<T>(y, n, yy, xx) + cg * SEG), fy);
-    Vec<T>::unpack(ldg16(vptr<T>(gout, n, yy, xx) + cg * SEG), fg);
+    Vec<T>::unpack(ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), fy);
+    Vec<T>::unpack(ldg16(pptr<T>(gout, dense, pd, pix) + cg * SEG), fg);
 #pragma unroll
     for (int i = 0; i < SEG; ++i) {
       const int c = cg * SEG + i;
@@ -166,9 +180,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
       const float xh = (fy[i] - tab[2 * C + c]) * tab[3 * C + c];
       o[i] = gamma ? sc * (dz - tab[4 * C + c] - xh * tab[5 * C + c]) : dz;
     }
-    stg16(vptr<T>(dy, n, yy, xx) + cg * SEG, Vec<T>::pack(o));
+    stg16(pptr<T>(dy, dense, pd, pix) + cg * SEG, Vec<T>::pack(o));
     if (gres.ptr) {
-      T* gp = vptr<T>(gres, n, yy, xx) + cg * SEG;
+      T* gp = pptr<T>(gres, dense, pd, pix) + cg * SEG;
       if (gres_acc) {
         float a[SEG];
         Vec<T>::unpack(ldg16(gp), a);
@@ -224,7 +238,7 @@ extern "C" int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_ten
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
   int grid = (int)((M + PPB * 8 - 1) / (PPB * 8));   // >= 8 pixels per thread
-  if (grid > 1024) grid = 1024;
+  if (grid > 2048) grid = 2048;
   if (grid < 1) grid = 1;
   const size_t smem = (size_t)PPB * G * seg * 2 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;

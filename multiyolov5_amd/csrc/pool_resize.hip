@@ -370,6 +370,67 @@ __global__ __launch_bounds__(256) void aap_fwd_kernel(myolo_tensor x, myolo_tens
     __syncthreads();
   }
 }
+// split variant for big bins (PyramidPooling k=1..3 on a 64x128 map: thousands of pixels per bin but only n*k*k bins): every
+// bin is cut into gridDim.y pixel chunks; partial sums go to an fp32 scratch (zeroed by the caller) with one atomic per
+// channel per workgroup, aap_finish_kernel scales and casts.
+template <typename T>
+__global__ __launch_bounds__(256) void aap_fwd_split_kernel(myolo_tensor x, int kb, int kw, float* scratch) {
+  constexpr int SEG = ET<T>::SEG;
+  __shared__ float red[256 * 8];
+  const int G = x.c / SEG;
+  int b = blockIdx.x;
+  const int bx = b % kw; b /= kw;
+  const int by = b % kb; const int n = b / kb;
+  const int y0 = (by * x.h) / kb, y1 = ((by + 1) * x.h + kb - 1) / kb;
+  const int x0 = (bx * x.w) / kw, x1 = ((bx + 1) * x.w + kw - 1) / kw;
+  const int bw = x1 - x0, npix = (y1 - y0) * bw;
+  const int chunk = (npix + gridDim.y - 1) / gridDim.y;
+  const int p0 = blockIdx.y * chunk;
+  const int p1 = p0 + chunk < npix ? p0 + chunk : npix;
+  float* dst = scratch + ((int64_t)(n * kb + by) * kw + bx) * x.c;
+  for (int cg0 = 0; cg0 < G; cg0 += 256) {
+    const int gcount = (G - cg0) < 256 ? (G - cg0) : 256;
+    const int lanes = 256 / gcount;
+    const int cg = cg0 + threadIdx.x % gcount, pl = threadIdx.x / gcount;
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+    if (pl < lanes)
+      for (int p = p0 + pl; p < p1; p += lanes) {
+        const int yy = y0 + p / bw, xx = x0 + p % bw;
+        float f[SEG];
+        Vec<T>::unpack(ldg16(vptr<T>(x, n, yy, xx) + cg * SEG), f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += f[i];
+      }
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) red[threadIdx.x * 8 + i] = a[i];
+    __syncthreads();
+    if (threadIdx.x < gcount) {
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        float sm = 0.f;
+        for (int q = 0; q < lanes; ++q) sm += red[(q * gcount + threadIdx.x) * 8 + i];
+        atomicAdd(dst + (cg0 + threadIdx.x) * SEG + i, sm);
+      }
+    }
+    __syncthreads();
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void aap_finish_kernel(myolo_tensor x, myolo_tensor out, const float* scratch) {
+  const int kb = out.h, kw = out.w;
+  const int64_t total = (int64_t)out.n * kb * kw * out.c;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % out.c); int64_t r = i / out.c;
+    const int bx = (int)(r % kw); r /= kw;
+    const int by = (int)(r % kb); const int n = (int)(r / kb);
+    const int y0 = (by * x.h) / kb, y1 = ((by + 1) * x.h + kb - 1) / kb;
+    const int x0 = (bx * x.w) / kw, x1 = ((bx + 1) * x.w + kw - 1) / kw;
+    vptr<T>(out, n, by, bx)[c] = (T)(scratch[i] / (float)((y1 - y0) * (x1 - x0)));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_tensor gx, int acc) {
   constexpr int SEG = ET<T>::SEG;
@@ -596,9 +657,25 @@ extern "C" int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* 
            ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), accumulate);
   return 0;
 }
-extern "C" int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream) {
+extern "C" int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, float* scratch, void* stream) {
   if (!vec_ok(x) || !vec_ok(out) || !same_nc(x, out) || out->h > x->h || out->w > x->w) return MYOLO_EINVAL;
-  DISPATCH(x->dtype, aap_fwd_kernel, out->n * out->h * out->w, 256, 0, (hipStream_t)stream, *x, *out);
+  const int bins = out->n * out->h * out->w;
+  const int64_t pix_per_bin = ((int64_t)x->h * x->w) / ((int64_t)out->h * out->w);
+  if (scratch && bins < 1024 && pix_per_bin >= 512) {
+    int split = (int)(2048 / bins);
+    if (split > pix_per_bin / 128) split = (int)(pix_per_bin / 128);
+    if (split < 2) split = 2;
+    if (x->dtype == MYOLO_F16) {
+      hipLaunchKernelGGL(aap_fwd_split_kernel<half_t>, dim3(bins, split), dim3(256), 0, (hipStream_t)stream, *x, out->h, out->w, scratch);
+      hipLaunchKernelGGL(aap_finish_kernel<half_t>, dim3(grid_for((int64_t)bins * out->c, 256)), dim3(256), 0, (hipStream_t)stream, *x, *out, scratch);
+    } else {
+      hipLaunchKernelGGL(aap_fwd_split_kernel<float>, dim3(bins, split), dim3(256), 0, (hipStream_t)stream, *x, out->h, out->w, scratch);
+      hipLaunchKernelGGL(aap_finish_kernel<float>, dim3(grid_for((int64_t)bins * out->c, 256)), dim3(256), 0, (hipStream_t)stream, *x, *out, scratch);
+    }
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
+  DISPATCH(x->dtype, aap_fwd_kernel, bins, 256, 0, (hipStream_t)stream, *x, *out);
   return 0;
 }
 extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate,

@@ -433,7 +433,9 @@ class BilinearOp(SimpleOp):
 
 class AvgPoolOp(SimpleOp):
     def emit_fwd(self, plan):
-        self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd', (C.byref(self.sd), C.byref(self.dd))))
+        d = self.dst
+        self.scratch = plan.f32_fwd_zero(d.n * d.h * d.w * d.buf.c)
+        self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd', (C.byref(self.sd), C.byref(self.dd), L.ptr(self.scratch))))
 
     def emit_bwd(self, plan):
         self.bwd_calls.append(Call('myolo_adaptive_avgpool_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc)))
