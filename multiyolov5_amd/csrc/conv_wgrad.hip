@@ -193,6 +193,128 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradK p) {
   if (p.db && tci == 0 && tap == 0 && tid < WT && co0 + tid < p.cout_w) atomicAdd(p.db + co0 + tid, bias_part);
 }
 
+
+// ---- k x k convolutions (fp16): all NT taps in ONE workgroup ---------------------------------------------------------------
+// The per-tap kernel above re-streams dy and x once per tap and issues only 4 MFMAs per wave between barriers.  Here the dy
+// tile of a 32-pixel K step is staged once and multiplied against the NT shifted x tiles (the shifted pixels are L1/L2 hits):
+// 4*NT MFMAs per wave per step, dy traffic / NT, NT accumulator sets (144 VGPRs for 3x3) held across the whole pixel range.
+template <int NT>
+__global__ __launch_bounds__(THREADS) void wgrad_fused_kernel(const WgradK p) {
+  typedef half_t T;
+  constexpr int ES = 2, SEG = 8;
+  constexpr int PITCH = Pitch<T>::V;
+  constexpr int SEGS_PER_ROW = WT / SEG;                  // 8: one 16-byte load per thread covers a [32 px][64 ch] tile
+  __shared__ __attribute__((aligned(16))) char sD[KP * PITCH];
+  __shared__ __attribute__((aligned(16))) char sX[NT][KP * PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  int b = blockIdx.x;
+  const int tci = b % p.tiles_ci; const int tco = b / p.tiles_ci;
+  const int split = blockIdx.y;
+  const int co0 = tco * WT, ci0 = tci * WT;
+  const int HWo = p.Ho * p.Wo;
+  const int Hlog = p.Hi << p.up, Wlog = p.Wi << p.up;
+  const int m_begin = split * p.pix_per_split;
+  int m_end = m_begin + p.pix_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int nsteps = m_end > m_begin ? (m_end - m_begin + KP - 1) / KP : 0;
+
+  f4_t acc[NT][2][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[t][i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  float bias_part = 0.f;
+
+  const int prow = tid / SEGS_PER_ROW, cs = tid - prow * SEGS_PER_ROW;
+  const int cd = co0 + cs * SEG, cx = ci0 + cs * SEG;
+  uint4 rd, rx[NT];
+  auto issue = [&](int s) {
+    const int m = m_begin + s * KP + prow;
+    const bool live = m < m_end;
+    const int mm = live ? m : m_begin;
+    const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+    const char* dp = (live && cd < p.Cout)
+        ? p.dy + ((int64_t)n * p.d_sn + (int64_t)oy * p.d_sh + (int64_t)ox * p.d_sw + cd) * ES : zero_page();
+    rd = ldg16(dp);
+    const char* xn = p.x + ((int64_t)n * p.x_sn + cx) * ES;
+    const bool cok = live && cx < p.Cin;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int iy = oy * p.stride + p.tap_dy[t], ix = ox * p.stride + p.tap_dx[t];
+      const bool ok = cok && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
+      iy >>= p.up; ix >>= p.up;
+      const char* xp = ok ? xn + ((int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * ES : zero_page();
+      rx[t] = ldg16(xp);
+    }
+  };
+
+  if (nsteps > 0) issue(0);
+  for (int s = 0; s < nsteps; ++s) {
+    *reinterpret_cast<uint4*>(&sD[prow * PITCH + cs * 16]) = rd;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4*>(&sX[t][prow * PITCH + cs * 16]) = rx[t];
+    __syncthreads();
+    if (s + 1 < nsteps) issue(s + 1);                    // next step's loads fly while this one computes
+    // dy fragments (see wgrad_kernel for the transpose-read lane map)
+    const int g = lane >> 4, kq = (lane & 15) >> 2, q = lane & 3;
+    h8_t fa[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int ca = (wr * 32 + f * 16 + q * 4) * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pr = 8 * g + 4 * h + kq;
+        fp16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(&sD[pr * PITCH + ca]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fa[f][4 * h + e] = (half_t)va[e];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      h8_t fb[2];
+#pragma unroll
+      for (int f = 0; f < 2; ++f) {
+        const int cb = (wc * 32 + f * 16 + q * 4) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int pr = 8 * g + 4 * h + kq;
+          fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(&sX[t][pr * PITCH + cb]));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fb[f][4 * h + e] = (half_t)vb[e];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[t][i][j], 0, 0, 0);
+    }
+    if (p.db && tci == 0 && tid < WT)
+      for (int r = 0; r < KP; ++r) bias_part += (float)*reinterpret_cast<const T*>(&sD[r * PITCH + tid * ES]);
+    __syncthreads();
+  }
+
+  const int CoP = p.tiles_co * WT, CiP = p.tiles_ci * WT;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wr * 32 + i * 16 + 4 * (lane >> 4) + r;
+          const int ci = ci0 + wc * 32 + j * 16 + (lane & 15);
+          if (p.ws) p.ws[(((int64_t)(split * NT + t) * CoP) + co) * CiP + ci] = acc[t][i][j][r];
+          else if (co < p.cout_w && ci < p.cin_w) atomicAdd(p.dw + ((int64_t)co * p.cin_w + ci) * NT + t, acc[t][i][j][r]);
+        }
+  if (p.db && tci == 0 && tid < WT && co0 + tid < p.cout_w) atomicAdd(p.db + co0 + tid, bias_part);
+}
+
 // dw[co][ci][t] += sum over splits of ws[s][t][co][ci].  A workgroup owns 64 consecutive weights (coalesced along ci); its 4
 // waves take every 4th split and combine through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ks, int ntaps,
@@ -245,10 +367,11 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   if (k.cout_w > k.Cout || k.cin_w > k.Cin) return MYOLO_EINVAL;
   k.tiles_co = (k.cout_w + WT - 1) / WT;
   k.tiles_ci = (k.cin_w + WT - 1) / WT;
-  const int out_tiles = k.tiles_co * k.tiles_ci * k.ntaps;
+  const bool fused = dt == MYOLO_F16 && k.ntaps == 9;        // every tap in one workgroup (wgrad_fused_kernel)
+  const int out_tiles = k.tiles_co * k.tiles_ci * (fused ? 1 : k.ntaps);
   int ks = d->ksplit;
   if (ks <= 0) {
-    ks = (1024 + out_tiles - 1) / out_tiles;                  // aim at ~1024 workgroups
+    ks = ((fused ? 512 : 1024) + out_tiles - 1) / out_tiles;  // aim at ~1024 workgroups (512 of the 9x heavier fused ones)
     const int max_ks = (int)((M + 8 * KP - 1) / (8 * KP));    // but at least 8 K-steps each
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;
@@ -270,7 +393,8 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   static const int dbg = getenv("MYOLO_WGRAD_DBG") ? atoi(getenv("MYOLO_WGRAD_DBG")) : 0;
   k.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
-  if (dt == MYOLO_F16) hipLaunchKernelGGL(wgrad_kernel<half_t>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
+  if (fused) hipLaunchKernelGGL(wgrad_fused_kernel<9>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
+  else if (dt == MYOLO_F16) hipLaunchKernelGGL(wgrad_kernel<half_t>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
   else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
   if (k.ws) {
     const int64_t total = (int64_t)k.ntaps * k.cout_w * k.cin_w;
