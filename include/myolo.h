@@ -35,6 +35,7 @@ extern "C" {
 
 #define MYOLO_EINVAL (-22)
 #define MYOLO_MAX_TAPS 25
+#define MYOLO_STAT_COPIES 8
 
 typedef struct myolo_tensor {
   void*   ptr;
@@ -74,8 +75,9 @@ int myolo_focus_pack(const void* img_nchw, int src_dtype, int n, int h, int w, f
  * weights / flipped taps, the autograd dgrad of all of them.
  *   y[n,oy,ox,:] (+)= epilogue( sum_t  x[n, (oy*stride+tap_dy[t])>>up, (ox*stride+tap_dx[t])>>up, :] . W[:,tap_w[t],:] )
  *   epilogue(v) = act(v*scale[c] + shift[c]) + res      (each part optional)
- *   stats != NULL: atomically accumulates per-channel sum / sum of squares of the raw fp32 accumulators
- *                  into stats[0..cout) / stats[cout..2cout)   (training-mode BatchNorm statistics)
+ *   stats != NULL: atomically accumulates per-channel sum / sum of squares of the raw fp32 accumulators into ONE of
+ *                  MYOLO_STAT_COPIES (8) interleaved copies [copy][2][cout] (copy = workgroup id % 8; the consumer adds the
+ *                  copies): stats is fp32[8*2*cout], zeroed by the caller   (training-mode BatchNorm statistics)
  *   det_no  > 0 : y is written in Detect's permuted layout [n, na, h, w, det_no] (yolo.py:214)           */
 typedef struct myolo_conv_desc {
   myolo_tensor x;            /* [N,Hi,Wi,Cin] (source dims; logical dims are <<up_shift) */
@@ -89,7 +91,7 @@ typedef struct myolo_conv_desc {
   int32_t act;
   int32_t accumulate;        /* 1: y += result */
   myolo_tensor res;          /* res.ptr == NULL: none */
-  float*  stats;             /* fp32[2*cout] or NULL */
+  float*  stats;             /* fp32[MYOLO_STAT_COPIES*2*cout] or NULL */
   int32_t det_no;
   int32_t reserved;
 } myolo_conv_desc;
@@ -115,7 +117,7 @@ int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream);
 
 /* ---- BatchNorm(+SiLU)(+residual) around a raw conv output (training mode) ----------------------
  * fwd: nn.BatchNorm2d batch-stat path + nn.SiLU + Bottleneck add (common.py:43,105), eps/momentum from
- * initialize_weights (torch_utils.py:150-151).  `stats` are the sums produced by myolo_conv.
+ * initialize_weights (torch_utils.py:150-151).  `stats` are the sums produced by myolo_conv (MYOLO_STAT_COPIES copies).
  *   mean = s/M, var = q/M - mean^2;  out = act((y-mean)*rsqrt(var+eps)*gamma + beta) + res
  *   block 0 also: saved[0..c)=mean, saved[c..2c)=invstd; running_mean/var (unbiased) momentum update,
  *   num_batches_tracked += 1 (int64).
@@ -124,7 +126,8 @@ int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const float* gam
                      float* running_mean, float* running_var, int64_t* num_batches_tracked,
                      float* saved, float eps, float momentum, int act,
                      const myolo_tensor* res, const myolo_tensor* out, void* stream);
-/* bwd pass 1: dsum[0..c) += sum dz, dsum[c..2c) += sum dz*xhat   with dz = gout * act'(z) */
+/* bwd pass 1: dsum[copy][0..c) += sum dz, dsum[copy][c..2c) += sum dz*xhat   with dz = gout * act'(z); dsum is
+ * fp32[MYOLO_STAT_COPIES*2*c] zeroed by the caller, pass 2 adds the copies */
 int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
                             const float* gamma, const float* beta, int act, float* dsum, void* stream);
 /* bwd pass 2: dy = gamma*invstd*(dz - dsum0/M - xhat*dsum1/M); dgamma += dsum1, dbeta += dsum0 (block 0);

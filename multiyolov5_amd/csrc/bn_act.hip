@@ -40,8 +40,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sc = 1.f, sh = 0.f;
     if (gamma) {
-      const float mean = stats[c] / (float)M;
-      float var = stats[C + c] / (float)M - mean * mean;
+      float ssum = 0.f, qsum = 0.f;
+#pragma unroll
+      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { ssum += stats[k * 2 * C + c]; qsum += stats[k * 2 * C + C + c]; }
+      const float mean = ssum / (float)M;
+      float var = qsum / (float)M - mean * mean;
       var = var > 0.f ? var : 0.f;
       const float invstd = rsqrtf(var + eps);
       sc = gamma[c] * invstd;
@@ -131,7 +134,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
     float a = 0.f;
     for (int q = 0; q < PPB; ++q) a += red[(size_t)q * (G * SEG * 2) + j];
     const int c = j >> 1;
-    atomicAdd(dsum + ((j & 1) ? C + c : c), a);
+    atomicAdd(dsum + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * C + ((j & 1) ? C + c : c), a);
   }
 }
 
@@ -152,10 +155,13 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
       const float mean = saved[c], istd = saved[C + c];
       const float sc = gamma[c] * istd;
       tab[c] = sc; tab[C + c] = beta[c] - mean * sc; tab[2 * C + c] = mean; tab[3 * C + c] = istd;
-      tab[4 * C + c] = dsum[c] / (float)M; tab[5 * C + c] = dsum[C + c] / (float)M;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { d0 += dsum[k * 2 * C + c]; d1 += dsum[k * 2 * C + C + c]; }
+      tab[4 * C + c] = d0 / (float)M; tab[5 * C + c] = d1 / (float)M;
       if (blockIdx.x == 0) {
-        if (dgamma) dgamma[c] += dsum[C + c];
-        if (dbeta) dbeta[c] += dsum[c];
+        if (dgamma) dgamma[c] += d1;
+        if (dbeta) dbeta[c] += d0;
       }
     } else {
       tab[c] = 1.f; tab[C + c] = 0.f; tab[2 * C + c] = 0.f; tab[3 * C + c] = 1.f; tab[4 * C + c] = 0.f; tab[5 * C + c] = 0.f;
@@ -238,7 +244,7 @@ extern "C" int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_ten
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
   int grid = (int)((M + PPB * 8 - 1) / (PPB * 8));   // >= 8 pixels per thread
-  if (grid > 2048) grid = 2048;
+  if (grid > 512) grid = 512;        // few, long-lived workgroups: the final per-channel atomics are same-address
   if (grid < 1) grid = 1;
   const size_t smem = (size_t)PPB * G * seg * 2 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
       const float a = red[t] + red[2 * BN + t] + red[4 * BN + t] + red[6 * BN + t];
       const int cl = t < BN ? t : t - BN;
       const int c = tn * BN + cl;
-      if (c < p.Cout) atomicAdd(p.stats + (t < BN ? c : p.Cout + c), a);
+      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
     }
   }
 }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
       for (int w = 0; w < WAVES; ++w) a += red[w * 2 * BN + t];
       const int cl = t < BN ? t : t - BN;
       const int c = tn * BN + cl;
-      if (c < p.Cout) atomicAdd(p.stats + (t < BN ? c : p.Cout + c), a);
+      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
     }
   }
 }

@@ -241,7 +241,7 @@ class ConvOp(Op):
             d.y = yv.desc()
             d.act = L.ACT_NONE
             if has_bn:
-                self.stats = plan.f32_fwd_zero(2 * self.cout)
+                self.stats = plan.f32_fwd_zero(L.STAT_COPIES * 2 * self.cout)
                 self.saved = torch.zeros(2 * self.cout, dtype=torch.float32, device=dev)
                 d.stats = self.stats.data_ptr()
             self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
@@ -313,7 +313,7 @@ class ConvOp(Op):
             self.grd = grd
             if has_bn:
                 bn = self.bn
-                self.dsum = plan.f32_bwd_zero(2 * self.cout)
+                self.dsum = plan.f32_bwd_zero(L.STAT_COPIES * 2 * self.cout)
                 calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
                                                               L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
                 calls.append(Call('myolo_bn_act_bwd_apply', (
@@ -734,7 +734,7 @@ class Plan:
                 tv.place(b, 0)
         for b in self.bufs:
             b.alloc(dev, self.training)
-        self._arena = [torch.zeros(1 << 18, dtype=torch.float32, device=dev) for _ in range(2)]
+        self._arena = [torch.zeros(1 << 20, dtype=torch.float32, device=dev) for _ in range(2)]
         self._used = [0, 0]
         if self.training:
             tot = sum(p.numel() for p in self.params)
