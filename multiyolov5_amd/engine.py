@@ -74,12 +74,13 @@ def null_tensor():
 
 
 class Call:
-    """One C-ABI launch: function + argument tuple (stream appended at run time)."""
-    __slots__ = ('fn', 'args', 'name', 'keep')
+    """One C-ABI launch: function + argument tuple (stream appended at run time).  `side`: may run on the plan's side HIP
+    stream (weight gradients: nothing in the backward chain depends on them)."""
+    __slots__ = ('fn', 'args', 'name', 'keep', 'side')
 
-    def __init__(self, name, args, keep=None):
+    def __init__(self, name, args, keep=None, side=False):
         self.fn = getattr(L.lib(), name)
-        self.name, self.args, self.keep = name, args, keep
+        self.name, self.args, self.keep, self.side = name, args, keep, side
 
     def __call__(self, st):
         e = self.fn(*self.args, st)
@@ -377,7 +378,7 @@ class ConvOp(Op):
         tdy, tdx, _ = taps_fwd(self.k, self.d, self.pad)
         fill_taps(wd, tdy, tdx)
         self.wd = wd
-        calls.append(Call('myolo_conv_wgrad', (C.byref(wd),)))
+        calls.append(Call('myolo_conv_wgrad', (C.byref(wd),), side=True))
 
 
 class SimpleOp(Op):
@@ -626,6 +627,7 @@ class Plan:
         self.det_grads = []
         self.params, self._pgrad = [], {}
         self._pack_jobs, self._pack_call = [], None
+        self.use_side_stream = True
         self.built = False
 
     # ---- graph construction -------------------------------------------------------------------------
@@ -789,18 +791,39 @@ class Plan:
         return self._buckets
 
     def run_bwd(self, reducer=None):
+        """backward launch list.  Weight-gradient kernels go to a side HIP stream: they only feed the optimizer, so they
+        overlap with the latency-bound dgrad / BatchNorm chain on the main stream (many of those launches fill < 1 CU wave)."""
+        main = torch.cuda.current_stream() if self.flat_grad.is_cuda else None
         st = L.stream_ptr()
         if self._used[1]:
             self._arena[1][:self._used[1]].zero_()
         if self.training:
             self.flat_grad.zero_()
+        side = side_ptr = None
+        if main is not None and self.use_side_stream:
+            if getattr(self, '_side', None) is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            side = self._side
+            side.wait_stream(main)                       # the zero fills above
+            side_ptr = C.c_void_p(side.cuda_stream)
         pending = list(self.grad_buckets(reducer)) if reducer is not None else []
         for i in range(len(self.ops) - 1, -1, -1):
             for c in self.ops[i].bwd_calls:
-                c(st)
-            while pending and pending[0][2] >= i:       # every kernel writing into this slice has been enqueued
-                lo, hi, _ = pending.pop(0)
-                reducer.reduce_slice(self.flat_grad, lo, hi)
+                if c.side and side is not None:
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    side.wait_event(ev)
+                    c(side_ptr)
+                else:
+                    c(st)
+            if pending and pending[0][2] >= i:           # every kernel writing into this slice has been enqueued
+                if side is not None:
+                    main.wait_stream(side)
+                while pending and pending[0][2] >= i:
+                    lo, hi, _ = pending.pop(0)
+                    reducer.reduce_slice(self.flat_grad, lo, hi)
+        if side is not None:
+            main.wait_stream(side)
         if reducer is not None:
             for lo, hi, _ in pending:
                 reducer.reduce_slice(self.flat_grad, lo, hi)
