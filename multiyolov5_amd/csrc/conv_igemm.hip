@@ -24,7 +24,6 @@
 
 namespace {
 
-constexpr int BM = 128;
 constexpr int THREADS = 256;
 
 struct ConvK {
@@ -34,7 +33,7 @@ struct ConvK {
   int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS], tap_w[MYOLO_MAX_TAPS];
   const float* scale; const float* shift; int act; int accumulate;
   const char* res; int64_t r_sn, r_sh, r_sw;
-  float* stats; int det_no; int M; int ntile_m; int tiles_per_xcd;
+  float* stats; int det_no; int M; int ntile_m; int tiles_per_xcd; int bm;
 };
 
 }  // namespace
@@ -60,13 +59,19 @@ template <> struct Mma<float> {
   }
 };
 
-template <typename T, int BN>
+// BM = 128 (two 16-row fragments per wave) or 64 (one): small maps get twice the workgroups, so that two latency-bound K loops
+// share each CU instead of one
+// KS = 64-byte K sub-chunks per step (1 or 2): a 128-byte step halves the per-step overhead (barrier, ~110 scalar/vector
+// address instructions) per MFMA; each sub-chunk is its own swizzled [rows][64 B] plane in LDS.
+template <typename T, int BN, int BM, int KS>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
+  constexpr int MF = BM / 64;        // 16-row fragments per wave; also A rows staged per thread
   constexpr int SEG = ET<T>::SEG;   // elements per 16 B
   constexpr int KC = ET<T>::KC;     // elements per 64 B K-chunk
   constexpr int NF = BN / 16;
   constexpr int ES = (int)sizeof(T);
-  constexpr int A_BYTES = BM * 64, B_BYTES = BN * 64;
+  constexpr int A_PLANE = BM * 64, B_PLANE = BN * 64;
+  constexpr int A_BYTES = A_PLANE * KS, B_BYTES = B_PLANE * KS;
   constexpr int CROW = BN * ES + 16;            // C staging row pitch (bytes)
   constexpr int BROWS = (BN + 63) / 64;         // B rows per thread (64 rows per pass)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -77,7 +82,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tn = blockIdx.y;
   const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3, bstride = gridDim.x >> 3;
-  const int kchunks = p.cin_pad / KC;
+  const int kchunks = p.cin_pad / (KC * KS);
   const int nsteps = p.ntaps * kchunks;
   const int HWo = p.Ho * p.Wo;
   const int Hlog = p.Hi << p.up, Wlog = p.Wi << p.up;
@@ -107,9 +112,9 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
     const int m0 = tm * BM;
 
     // decode this thread's two A rows
-    int rn[2], roy[2], rox[2]; bool rvalid[2];
+    int rn[MF], roy[MF], rox[MF]; bool rvalid[MF];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MF; ++r) {
       const int m = m0 + lrow + r * 64;
       rvalid[r] = m < p.M;
       const int mm = rvalid[r] ? m : 0;
@@ -119,85 +124,106 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
       rox[r] = rem - roy[r] * p.Wo;
     }
 
-    f4_t acc[2][NF];
+    f4_t acc[MF][NF];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MF; ++i)
 #pragma unroll
       for (int j = 0; j < NF; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
 
-    uint4 ra[2], rb[BROWS];
-    const char* arow[2] = {nullptr, nullptr};
-    int cur_tap = -1;
-
-    auto issue_loads = [&](int s) {
-      const int tap = s / kchunks, kc = s - tap * kchunks;
-      if (tap != cur_tap) {
-        cur_tap = tap;
-        const int dy = p.tap_dy[tap], dx = p.tap_dx[tap];
+    // Register ring: the global loads of K step s+RING-1 are issued while step s computes, so RING-1 steps (not one) of
+    // load latency are in flight per wave.  Small maps run ~1 workgroup per CU: with a single step of prefetch every K step
+    // exposed a full L2 round trip (~0.9 us per 64-byte step, MFMA busy ~10 %).
+    constexpr int RING = KS == 2 ? 3 : 4;
+    uint4 ra[RING][MF * KS], rb[RING][BROWS * KS];
+    const char* arow[MF];
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < MF; ++r) arow[r] = nullptr;
+    int cur_tap = -1, i_tap = 0, i_kc = 0;           // issue cursor (sequential over steps)
+
+    auto issue_loads = [&](uint4* da, uint4* db, const bool live) {
+      if (i_tap != cur_tap) {
+        cur_tap = i_tap;
+        const int tt = i_tap < p.ntaps ? i_tap : p.ntaps - 1;
+        const int dy = p.tap_dy[tt], dx = p.tap_dx[tt];
+#pragma unroll
+        for (int r = 0; r < MF; ++r) {
           int iy = roy[r] * p.stride + dy, ix = rox[r] * p.stride + dx;
           const bool ok = rvalid[r] && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
           iy >>= p.up; ix >>= p.up;
           arow[r] = ok ? p.x + ((int64_t)rn[r] * p.x_sn + (int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * ES : nullptr;
         }
       }
-      const int c0 = kc * KC + lseg * SEG;
-      // unconditional loads, out-of-image / padded-channel lanes read the zero page (see myolo_dev.h: a `cond ? load : 0`
-      // select would make hipcc wait vmcnt(0) per element and serialise the prefetch)
+      const int wt = p.tap_w[i_tap < p.ntaps ? i_tap : p.ntaps - 1];
 #pragma unroll
-      for (int r = 0; r < 2; ++r) {
-        const char* ap = (arow[r] != nullptr && c0 < p.Cin) ? arow[r] + (int64_t)c0 * ES : zero_page();
-        ra[r] = ldg16(ap);
-      }
-      const int wt = p.tap_w[tap];
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c0 = (i_kc * KS + ks) * KC + lseg * SEG;
+        // unconditional loads, out-of-image / padded-channel / past-the-end lanes read the zero page (myolo_dev.h)
 #pragma unroll
-      for (int r = 0; r < BROWS; ++r) {
-        int brow = lrow + r * 64;
-        if (BN < 64) brow &= (BN - 1);                 // BN = 32: the upper half of the threads reloads a valid row (unused)
-        rb[r] = ldg16(wbase + ((int64_t)(brow * p.wtaps + wt) * p.cin_pad + c0) * ES);
+        for (int r = 0; r < MF; ++r) {
+          const char* ap = (live && arow[r] != nullptr && c0 < p.Cin) ? arow[r] + (int64_t)c0 * ES : zero_page();
+          da[ks * MF + r] = ldg16(ap);
+        }
+#pragma unroll
+        for (int r = 0; r < BROWS; ++r) {
+          int brow = lrow + r * 64;
+          if (BN < 64) brow &= (BN - 1);               // BN = 32: the upper half of the threads reloads a valid row (unused)
+          db[ks * BROWS + r] = ldg16(wbase + ((int64_t)(brow * p.wtaps + wt) * p.cin_pad + c0) * ES);
+        }
       }
+      if (++i_kc == kchunks) { i_kc = 0; ++i_tap; }
     };
-    auto store_lds = [&](int buf) {
+    auto store_lds = [&](int buf, const uint4* sa, const uint4* sb) {
 #pragma unroll
-      for (int r = 0; r < 2; ++r)
-        *reinterpret_cast<uint4*>(sA + buf * A_BYTES + lds_off2(lrow + r * 64, lseg)) = ra[r];
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-      for (int r = 0; r < BROWS; ++r) {
-        const int brow = lrow + r * 64;
-        if (BN >= 64 || brow < BN)
-          *reinterpret_cast<uint4*>(sB + buf * B_BYTES + lds_off2(brow, lseg)) = rb[r];
+        for (int r = 0; r < MF; ++r)
+          *reinterpret_cast<uint4*>(sA + buf * A_BYTES + ks * A_PLANE + lds_off2(lrow + r * 64, lseg)) = sa[ks * MF + r];
+#pragma unroll
+        for (int r = 0; r < BROWS; ++r) {
+          const int brow = lrow + r * 64;
+          if (BN >= 64 || brow < BN)
+            *reinterpret_cast<uint4*>(sB + buf * B_BYTES + ks * B_PLANE + lds_off2(brow, lseg)) = sb[ks * BROWS + r];
+        }
       }
     };
 
-    issue_loads(0);
-    store_lds(0);
+#pragma unroll
+    for (int j = 0; j < RING - 1; ++j) issue_loads(ra[j], rb[j], j < nsteps);
+    store_lds(0, ra[0], rb[0]);
     __syncthreads();
 
-    for (int s = 0; s < nsteps; ++s) {
-      const int buf = s & 1;
-      if (s + 1 < nsteps) issue_loads(s + 1);
-      // fragments
-      uint4 fa[2], fb[NF];
-      const int frow = lane & 15, fseg = lane >> 4;
+    for (int s0 = 0; s0 < nsteps; s0 += RING) {
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
-        fa[mf] = *reinterpret_cast<const uint4*>(sA + buf * A_BYTES + lds_off2(wave * 32 + mf * 16 + frow, fseg));
+      for (int j = 0; j < RING; ++j) {
+        const int s = s0 + j;
+        if (s < nsteps) {                               // uniform
+          const int buf = s & 1;
+          issue_loads(ra[(j + RING - 1) % RING], rb[(j + RING - 1) % RING], s + RING - 1 < nsteps);
+          const int frow = lane & 15, fseg = lane >> 4;
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
-        fb[nf] = *reinterpret_cast<const uint4*>(sB + buf * B_BYTES + lds_off2(nf * 16 + frow, fseg));
+          for (int ks = 0; ks < KS; ++ks) {
+            uint4 fa[MF], fb[NF];
 #pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
+            for (int mf = 0; mf < MF; ++mf)
+              fa[mf] = *reinterpret_cast<const uint4*>(sA + buf * A_BYTES + ks * A_PLANE + lds_off2(wave * (16 * MF) + mf * 16 + frow, fseg));
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[mf], fb[nf], acc[mf][nf]);
-      if (s + 1 < nsteps) store_lds(buf ^ 1);
-      __syncthreads();
+            for (int nf = 0; nf < NF; ++nf)
+              fb[nf] = *reinterpret_cast<const uint4*>(sB + buf * B_BYTES + ks * B_PLANE + lds_off2(nf * 16 + frow, fseg));
+#pragma unroll
+            for (int mf = 0; mf < MF; ++mf)
+#pragma unroll
+              for (int nf = 0; nf < NF; ++nf) Mma<T>::run(fa[mf], fb[nf], acc[mf][nf]);
+          }
+          if (s + 1 < nsteps) store_lds(buf ^ 1, ra[(j + 1) % RING], rb[(j + 1) % RING]);
+          __syncthreads();
+        }
+      }
     }
 
     // ---- epilogue ----
-    // acc[mf][nf][r] = D[row = wave*32+mf*16+4*(lane>>4)+r][col = nf*16+(lane&15)]
+    // acc[mf][nf][r] = D[row = wave*16*MF+mf*16+4*(lane>>4)+r][col = nf*16+(lane&15)]
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < MF; ++mf)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
           st_q[nf] += v0 * v0;
           float v = v0 * e_scale[nf] + e_shift[nf];
           v = act_f(v, p.act);
-          const int row = wave * 32 + mf * 16 + 4 * (lane >> 4) + r;
+          const int row = wave * (16 * MF) + mf * 16 + 4 * (lane >> 4) + r;
           const int col = nf * 16 + (lane & 15);
           *reinterpret_cast<T*>(sC + row * CROW + col * ES) = (T)v;
         }
@@ -283,13 +309,14 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
   }
 }
 
-template <typename T, int BN>
-int launch_conv(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
+template <typename T, int BN, int BM, int KS>
+int launch_conv3(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
   constexpr int ES = (int)sizeof(T);
-  constexpr int AB = 2 * (BM * 64 + BN * 64);
+  constexpr int AB = 2 * KS * (BM * 64 + BN * 64);
   constexpr int CB = BM * (BN * ES + 16);
-  const int smem = AB > CB ? AB : CB;
-  auto kern = conv_igemm_kernel<T, BN>;
+  constexpr int SB = 4 * 2 * BN * 4;             // statistics reduction [4 waves][2*BN] floats
+  const int smem = (AB > CB ? AB : CB) > SB ? (AB > CB ? AB : CB) : SB;
+  auto kern = conv_igemm_kernel<T, BN, BM, KS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -297,6 +324,18 @@ int launch_conv(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;
+}
+
+template <typename T, int BN, int BM>
+int launch_conv2(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
+  constexpr int KC = ET<T>::KC;
+  // 128-byte K steps for the small-map tiles only: with BM = 128 the extra ring registers cost a wave per SIMD
+  const bool wide = BM == 64 && (k.cin_pad % (2 * KC)) == 0 && k.ntaps * (k.cin_pad / (2 * KC)) >= 4;
+  return wide ? launch_conv3<T, BN, BM, 2>(k, grid_x, ntile_n, st) : launch_conv3<T, BN, BM, 1>(k, grid_x, ntile_n, st);
+}
+template <typename T, int BN>
+int launch_conv(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
+  return k.bm == 64 ? launch_conv2<T, BN, 64>(k, grid_x, ntile_n, st) : launch_conv2<T, BN, 128>(k, grid_x, ntile_n, st);
 }
 
 }  // namespace
@@ -329,10 +368,11 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
   if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
   k.M = (int)M;
-  k.ntile_m = (int)((M + BM - 1) / BM);
-  k.tiles_per_xcd = (k.ntile_m + 7) / 8;
   const int bn = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
   const int ntile_n = d->cout_pad / bn;
+  k.bm = ((M + 127) / 128) * ntile_n < 768 ? 64 : 128;      // small maps: 64-row tiles = twice the workgroups
+  k.ntile_m = (int)((M + k.bm - 1) / k.bm);
+  k.tiles_per_xcd = (k.ntile_m + 7) / 8;
   // persistent grid: ~3 workgroups per CU in total, multiple of 8 (one slot range per XCD)
   int per_xcd = (768 / ntile_n + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;

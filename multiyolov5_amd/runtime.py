@@ -146,7 +146,7 @@ class PlanHolder:
         plan.register_params([p for p in module.parameters()])
         plan.build()
         self.pending_bwd = False
-        self.sig = self.param_sig(module)
+        self.sig = None
 
     @staticmethod
     def param_sig(module):
@@ -173,7 +173,21 @@ class PlanHolder:
 
 
 class PlannedModule(nn.Module):
-    """nn.Module whose forward is a libmyolo launch plan.  Subclasses implement emit(plan, x)."""
+    """nn.Module whose forward is a libmyolo launch plan.  Subclasses implement emit(plan, x).
+
+    Host cost matters (a training step is ~700 launches): the parameter / buffer tensors are listed once per module and a
+    forward only re-reads their data pointers (re-allocation by .to()/.half()/load_state_dict is detected) and, in eval mode,
+    their version counters (in-place weight edits re-run the one-off epilogue constant preparation).  Replacing a Parameter
+    OBJECT after the first forward is not detected: call invalidate_plans() (Model.fuse() does)."""
+
+    def _tensors(self):
+        ts = self.__dict__.get('_tensor_list')
+        if ts is None:
+            ts = self.__dict__['_tensor_list'] = list(self.parameters()) + list(self.buffers())
+        return ts
+
+    def _sig(self):
+        return tuple(t.data_ptr() for t in self._tensors())
 
     def _holder(self, tensors, spec):
         for t in tensors:
@@ -184,21 +198,25 @@ class PlannedModule(nn.Module):
                str(spec), dtype, bool(self.training), grad)
         plans = self.__dict__.setdefault('_plans', {})
         h = plans.get(key)
-        sig = PlanHolder.param_sig(self)
+        sig = self._sig()
         if h is None or h.sig != sig:
             # module.training decides BatchNorm batch statistics (and builds the backward launch list);
             # `grad` only decides whether autograd is wired through PlanFn
+            self.__dict__.pop('_tensor_list', None)
+            sig = self._sig()
             h = PlanHolder(self, tensors, spec, dtype, bool(self.training))
             h.sig = sig
             plans[key] = h
+            self.__dict__['_prepared_version'] = self._param_version()
         elif not self.training:
-            if self.__dict__.get('_prepared_version') != self._param_version():
+            v = self._param_version()
+            if self.__dict__.get('_prepared_version') != v:
                 h.plan.prepare()
-        self.__dict__['_prepared_version'] = self._param_version()
+                self.__dict__['_prepared_version'] = v
         return h, grad
 
     def _param_version(self):
-        return sum(p._version for p in self.parameters()) + sum(b._version for b in self.buffers())
+        return sum(t._version for t in self._tensors())
 
     def forward(self, x):
         tensors = []
@@ -214,9 +232,11 @@ class PlannedModule(nn.Module):
 
     def invalidate_plans(self):
         self.__dict__.pop('_plans', None)
+        self.__dict__.pop('_tensor_list', None)
 
     def __getstate__(self):       # plans hold device pointers: never pickled (train.py:485 pickles whole modules)
         d = dict(self.__dict__)
         d.pop('_plans', None)
         d.pop('_prepared_version', None)
+        d.pop('_tensor_list', None)
         return d

@@ -163,22 +163,23 @@ _EMA_TABLES = {}
 
 
 @torch.no_grad()
-def ema_update(ema_sd, model_sd, d):
-    """v = d*v + (1-d)*m for every floating tensor of the EMA state_dict (buffers included), one launch."""
-    keys = [k for k, v in ema_sd.items() if v.dtype.is_floating_point]
-    if not keys:
+def ema_update(pairs, d, model_sd=None):
+    """v = d*v + (1-d)*m for every (ema tensor, model tensor) pair (floating state_dict entries, buffers included), one
+    launch.  `pairs` may also be the EMA state_dict with `model_sd` the model's (torch_utils.py:296-300 call shape)."""
+    if model_sd is not None:
+        pairs = [(v, model_sd[k]) for k, v in pairs.items() if v.dtype.is_floating_point]
+    if not pairs:
         return
     ptrs, numels = [], []
-    for k in keys:
-        v, m = ema_sd[k], model_sd[k]
-        _f32_cuda(v, 'ema_update')
-        _f32_cuda(m, 'ema_update')
+    for v, m in pairs:
         ptrs.append((v.data_ptr(), m.data_ptr(), 0))
         numels.append(v.numel())
-    dev = ema_sd[keys[0]].device
     tab = _EMA_TABLES.get(ptrs[0][0])
     if tab is None:
-        tab = _EMA_TABLES[ptrs[0][0]] = _Table(dev)
+        for v, m in pairs:
+            _f32_cuda(v, 'ema_update')
+            _f32_cuda(m, 'ema_update')
+        tab = _EMA_TABLES[ptrs[0][0]] = _Table(pairs[0][0].device)
     tab.update(ptrs, numels, [0] * len(ptrs))
     L.check(L.lib().myolo_mt_ema(L.ptr(tab.table), L.ptr(tab.chunks), tab.nchunks, CHUNK, C.c_float(d), L.stream_ptr()),
             'myolo_mt_ema')

@@ -68,8 +68,15 @@ class ModelEMA:
         from .optim import ema_update
         self.updates += 1
         d = self.decay(self.updates)
-        msd = model.module.state_dict() if is_parallel(model) else model.state_dict()
-        ema_update(self.ema.state_dict(), msd, d)
+        m = model.module if is_parallel(model) else model
+        first = next(m.parameters(), None)
+        stale = getattr(self, '_pairs_of', None) is not m or (first is not None and self._first_ptr != first.data_ptr())
+        if stale:                                              # state_dict() walks ~360 modules: pair the tensors once
+            msd, esd = m.state_dict(), self.ema.state_dict()
+            self._pairs = [(esd[k], msd[k]) for k in esd if esd[k].dtype.is_floating_point]
+            self._pairs_of = m
+            self._first_ptr = first.data_ptr() if first is not None else 0
+        ema_update(self._pairs, d)
 
     def update_attr(self, model, include=(), exclude=('process_group', 'reducer')):
         copy_attr(self.ema, model, include, exclude)
