@@ -175,10 +175,39 @@ __global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, i
   xlo = xlo / xalign * xalign;
   const int npix = xhi - xlo + 1;
   constexpr int MAXP = 3;                       // (lx, c) pairs per thread: LXP*MAXC/256 = 4 > 32*19/256 = 2.4
+  constexpr int MAXF = 20;                      // x footprint of one low-res pixel (2*scale + slack) -- host checks scale <= 8
   float a[MAXP + 1];
-#pragma unroll
-  for (int q = 0; q <= MAXP; ++q) a[q] = 0.f;
+  float wxs[MAXP + 1][MAXF];                    // bilinear x weights of each pair's footprint, computed once (not per row)
+  int pbase[MAXP + 1], pcnt[MAXP + 1];          // LDS element offset of the footprint's first pixel (+c), footprint length
   const int npairs = nlx * C;
+#pragma unroll
+  for (int q = 0; q <= MAXP; ++q) {
+    a[q] = 0.f; pbase[q] = 0; pcnt[q] = 0;
+#pragma unroll
+    for (int f = 0; f < MAXF; ++f) wxs[q][f] = 0.f;
+    const int p = threadIdx.x + q * 256;
+    if (p < npairs) {
+      const int li = p / C, c = p - li * C;
+      const int ix = lx0 + li;
+      int pxlo, pxhi;
+      out_range(ix, glow.w, W, sx, pxlo, pxhi);
+      if (pxhi - pxlo + 1 > MAXF) pxhi = pxlo + MAXF - 1;
+      pbase[q] = (pxlo - xlo) * C + c;
+      pcnt[q] = pxhi - pxlo + 1;
+#pragma unroll
+      for (int f = 0; f < MAXF; ++f) {
+        const int ox = pxlo + f;
+        if (ox <= pxhi) {
+          const float fx = sx * (float)ox; const int x0 = (int)fx; const int x1 = x0 + 1 < glow.w ? x0 + 1 : glow.w - 1;
+          const float lx = fx - (float)x0;
+          float wx = 0.f;
+          if (x0 == ix) wx += 1.f - lx;
+          if (x1 == ix) wx += lx;
+          wxs[q][f] = wx;
+        }
+      }
+    }
+  }
   for (int oy = ylo; oy <= yhi; ++oy) {
     const float fy = sy * (float)oy; const int y0 = (int)fy; const int y1 = y0 + 1 < glow.h ? y0 + 1 : glow.h - 1;
     const float ly = fy - (float)y0;
@@ -191,21 +220,12 @@ __global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, i
     __syncthreads();
 #pragma unroll
     for (int q = 0; q <= MAXP; ++q) {
-      const int p = threadIdx.x + q * 256;
-      if (p >= npairs) break;
-      const int li = p / C, c = p - li * C;
-      const int ix = lx0 + li;
-      int pxlo, pxhi;
-      out_range(ix, glow.w, W, sx, pxlo, pxhi);
+      if (pcnt[q] == 0) continue;
       float s = 0.f;
-      for (int ox = pxlo; ox <= pxhi; ++ox) {
-        const float fx = sx * (float)ox; const int x0 = (int)fx; const int x1 = x0 + 1 < glow.w ? x0 + 1 : glow.w - 1;
-        const float lx = fx - (float)x0;
-        float wx = 0.f;
-        if (x0 == ix) wx += 1.f - lx;
-        if (x1 == ix) wx += lx;
-        if (wx != 0.f) s += wx * (float)buf[(ox - xlo) * C + c];
-      }
+      const T* bp = buf + pbase[q];
+#pragma unroll
+      for (int f = 0; f < MAXF; ++f)
+        if (f < pcnt[q]) s += wxs[q][f] * (float)bp[f * C];
       a[q] += wy * s;
     }
   }
@@ -295,7 +315,8 @@ extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, 
   if (!glow || !glow->ptr || !g) return MYOLO_EINVAL;
   Strided4 gg{const_cast<void*>(g), sn, sc, sh, sw, g_dtype};
   const float sy = H > 1 ? (float)(glow->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(glow->w - 1) / (float)(W - 1) : 0.f;
-  if (!getenv("MYOLO_NO_FAST_UPB") && g_dtype == glow->dtype && dense_cl(g, g_dtype, glow->c, H, W, sn, sc, sh, sw) && H >= 2 * glow->h && W >= 2 * glow->w) {
+  if (!getenv("MYOLO_NO_FAST_UPB") && g_dtype == glow->dtype && dense_cl(g, g_dtype, glow->c, H, W, sn, sc, sh, sw) && H >= 2 * glow->h && W >= 2 * glow->w &&
+      W <= 8 * glow->w) {
     const int es = g_dtype == MYOLO_F16 ? 2 : 4;
     int gcd = 16, t = glow->c * es;
     while (t) { const int r = gcd % t; gcd = t; t = r; }
