@@ -252,9 +252,15 @@ def main():
     if rank == 0 and world == 1:
         if not args.no_kernel_timing:
             b, f, t, n = conv_kernel_timing(tr)
+            traffic, tsrc = None, None
+            pmc = os.path.join(ROOT, 'profiles', 'r1_pmc.json')        # separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh)
+            if os.path.exists(pmc) and args.batch == 16 and tuple(args.img) == (512, 1024) and args.dtype == 'f16':
+                rec = json.load(open(pmc))
+                traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/r1_pmc.json: ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                               'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': None,
-                               'kernel': 'conv_igemm_kernel (fwd + dgrad launches)', 'launches_per_step': n,
+                               'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
+                               'kernel': 'myolo_conv launches of one step: conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad)',
+                               'launches_per_step': n,
                                'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
                                'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,
                                'conv_time_frac_of_step': t / (ms * 1e-3)}
