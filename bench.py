@@ -51,11 +51,15 @@ def setup_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group(backend='nccl', init_method='env://', device_id=torch.device('cuda', local))
+        backend = os.environ.get('MYOLO_DIST_BACKEND', 'nccl')       # 'gloo' only for single-GPU smoke tests of the N>1 path
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', init_method='env://', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend=backend, init_method='env://')
     return world, rank, local
 
 
@@ -213,7 +217,7 @@ def cpu_baseline(args):
 def main():
     args = parse()
     world, rank, local = setup_dist(args)
-    dev = torch.device('cuda', local)
+    dev = torch.device('cuda', local if local < torch.cuda.device_count() else 0)
     from multiyolov5_amd import _lib
     _lib.lib()                                           # fail loudly if the HIP library is missing
     out = {}

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
   auto issue = [&](uint4* dst) {
     // branch-free: every load is issued unconditionally, dead lanes / padded channels / finished waves read the zero page
     const bool live = i_left > 0;
+    const bool ld = live && !(p.dbg & 2);
     const char* zp = zero_page();
     if (p.xdense) {
 #pragma unroll
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           const int c0 = i_kc * KCH + kb * 32 + lq * 8;
-          const char* ptr = (live && i_ok[mf] && c0 < p.Cin) ? i_base[mf] + c0 * 2 : zp;
+          const char* ptr = (ld && i_ok[mf] && c0 < p.Cin) ? i_base[mf] + c0 * 2 : zp;
           dst[mf * KB + kb] = ldg16(ptr);
         }
     } else {
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
         int iy = i_y0[mf] + dy, ix = i_x0[mf] + dx;
-        const bool ok = live && i_ok[mf] && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
+        const bool ok = ld && i_ok[mf] && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
         iy >>= p.up; ix >>= p.up;
         const char* rp = i_base[mf] + ((int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * 2;
 #pragma unroll
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
             v[r] = act_f(v0 * sT[cl] + sT[BN + cl], p.act);
           }
         }
-        if (!mok || c0 >= p.Cout) continue;            // Cout % 4 == 0 (checked on the host): whole 8-byte groups only
+        if (!mok || c0 >= p.Cout || (p.dbg & 1)) continue;   // Cout % 4 == 0 (checked on the host): whole 8-byte groups only
         half_t* yp = reinterpret_cast<half_t*>(p.y) + yoff + c0;
         if (EXTRA) {                                   // residual / accumulate: loads inside the epilogue (drain the prefetch queue)
           if (p.res) {

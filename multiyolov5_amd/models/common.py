@@ -316,6 +316,40 @@ class ASPP(PlannedModule):
         return self.ConvLinear.emit(plan, plan.cat(parts))
 
 
+class _ConvThenBare(nn.Sequential):
+    """nn.Sequential(Conv(c1,hid,1), Conv2d(k3,dilated,bias=False), BatchNorm2d, SiLU) of ASPPs (common.py:288-305)."""
+
+    def __init__(self, c1, c2, d):
+        super().__init__(Conv(c1, c2, k=1), nn.Conv2d(c2, c2, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
+                         nn.BatchNorm2d(c2), nn.SiLU())
+
+    def emit(self, plan, x):
+        return emit_conv(plan, self[0].emit(plan, x), self[1], self[2], L.ACT_SILU)[0]
+
+
+class ASPPs(PlannedModule):
+    """ASPP with a private 1x1 channel reduction in front of every branch (common.py:278-324)."""
+
+    def __init__(self, in_planes, out_planes, d=[3, 6, 9], has_globel=True, map_reduce=4):
+        super().__init__()
+        self.has_globel = has_globel
+        self.hid = in_planes // map_reduce
+        self.branch0 = nn.Sequential(Conv(in_planes, self.hid, k=1), Conv(self.hid, self.hid, k=3, s=1))
+        self.branch1 = _ConvThenBare(in_planes, self.hid, d[0])
+        self.branch2 = _ConvThenBare(in_planes, self.hid, d[1])
+        self.branch3 = _ConvThenBare(in_planes, self.hid, d[2])
+        if self.has_globel:
+            self.branch4 = _GlobalBranch(in_planes, self.hid)
+        self.ConvLinear = Conv(int(5 * self.hid) if has_globel else int(4 * self.hid), out_planes, k=1, s=1)
+
+    def emit(self, plan, x):
+        parts = [_emit_seq(plan, self.branch0, x), self.branch1.emit(plan, x), self.branch2.emit(plan, x),
+                 self.branch3.emit(plan, x)]
+        if self.has_globel:
+            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x), x.h, x.w))
+        return self.ConvLinear.emit(plan, plan.cat(parts))
+
+
 class PyramidPooling(PlannedModule):
     """AdaptiveAvgPool(1,2,3,6) -> 1x1 -> bilinear up -> cat with x (common.py:514-539)."""
 

@@ -56,7 +56,11 @@ class GradReducer:
             ev.record()
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                if dist.get_backend(self.group) == 'nccl':           # RCCL
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                else:                                                # gloo on device tensors (single-GPU smoke tests): no AVG
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                    view.div_(self.world)
         else:                                           # gloo (CPU tests): no AVG
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
             view.div_(self.world)

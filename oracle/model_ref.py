@@ -115,6 +115,18 @@ def aspp(ctx, p, x, d=(3, 6, 9), has_globel=True):  # common.py:233-275
     return conv_block(ctx, p + '.ConvLinear', torch.cat(parts, 1))
 
 
+def aspps(ctx, p, x, d=(3, 6, 9), has_globel=True):  # common.py:278-324
+    parts = [conv_block(ctx, p + '.branch0.1', conv_block(ctx, p + '.branch0.0', x), 3)]
+    for i in range(3):
+        h = conv_block(ctx, f'{p}.branch{i + 1}.0', x)
+        y = F.conv2d(h, ctx.sd[f'{p}.branch{i + 1}.1.weight'], None, 1, d[i], d[i])
+        parts.append(F.silu(_bn(ctx, f'{p}.branch{i + 1}.2', y)))
+    if has_globel:
+        g = conv_block(ctx, p + '.branch4.1', F.adaptive_avg_pool2d(x, 1))
+        parts.append(g.expand(-1, -1, x.shape[2], x.shape[3]))
+    return conv_block(ctx, p + '.ConvLinear', torch.cat(parts, 1))
+
+
 def pyramid_pooling(ctx, p, x, ks=(1, 2, 3, 6)):  # common.py:514-539
     h, w = x.shape[2:]
     feats = [x]

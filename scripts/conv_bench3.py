@@ -1,10 +1,9 @@
-"""run a few conv layer shapes (eval / train mode) many times; time comes from rocprofv3 kernel stats."""
 import sys, ctypes, torch
 sys.path.insert(0, '.')
 from multiyolov5_amd.models import common as C
 B=16; dt=torch.float16
 mode=sys.argv[1]
-SHAPES=[(128,128,3,1,32,64),(256,256,3,1,16,32),(512,256,1,1,16,32),(256,128,3,1,64,128),(128,128,1,1,32,64)]
+SHAPES=[(64,64,1,1,128,256),(128,128,1,1,64,128),(64,64,3,1,64,128)]
 for cin,cout,k,s,H,W in SHAPES:
     m=C.Conv(cin,cout,k,s).to('cuda')
     m.train(mode=='train')

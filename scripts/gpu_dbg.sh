@@ -9,11 +9,12 @@ f=glob.glob('gpurun_out/dbg/$name/**/x_kernel_trace.csv',recursive=True)+glob.gl
 rows=list(csv.DictReader(open(f[0])))
 c=[r for r in rows if 'conv_stream' in r['Kernel_Name'] or 'conv_igemm' in r['Kernel_Name']]
 d=[(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3 for r in c]
-print('$name $MODE', ' | '.join('%.1f us (%s,%s)' % (statistics.median(d[i*15+5:i*15+15]), int(c[i*15+6]['Grid_Size_X'])//256, c[i*15+6]['Grid_Size_Y']) for i in range(len(d)//15)))
+print('$name $MODE', ' | '.join('%.1f us (%s,%s)' % (statistics.median(d[i*15+5:i*15+15]), int(c[i*15+6]['Grid_Size_X'])//int(c[i*15+6]['Workgroup_Size_X']), c[i*15+6]['Grid_Size_Y']) for i in range(len(d)//15)))
 PY
 }
-MODE=eval
+MODE=train
 export MODE
-run base A=1
-timeout 900 python -m pytest tests -m gpu -q --timeout 200 2>&1 | tail -3 | cut -c1-300
-echo "--- bench"; timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(j['value'], j['ms_per_step'], j['roofline']['achieved'], j.get('detect_fps'))"
+run full A=1
+run nostore MYOLO_STREAM_DBG=1
+run noload MYOLO_STREAM_DBG=2
+run neither MYOLO_STREAM_DBG=3

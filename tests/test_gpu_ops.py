@@ -56,6 +56,7 @@ CASES = {
     'rfb2': (lambda C: C.RFB2(96, 64, map_reduce=6), lambda c, p, x: model_ref.rfb2(c, p, x, (2, 3), False), [(2, 96, 12, 20)]),
     'rfb2_global': (lambda C: C.RFB2(128, 64, map_reduce=8, has_globel=True), lambda c, p, x: model_ref.rfb2(c, p, x, (2, 3), True), [(2, 128, 6, 10)]),
     'aspp': (lambda C: C.ASPP(64, 64, d=[3, 6, 9], has_globel=False, map_reduce=4), lambda c, p, x: model_ref.aspp(c, p, x, (3, 6, 9), False), [(2, 64, 12, 20)]),
+    'aspps': (lambda C: C.ASPPs(64, 64, d=[3, 6, 9], has_globel=True, map_reduce=4), lambda c, p, x: model_ref.aspps(c, p, x, (3, 6, 9), True), [(2, 64, 12, 20)]),
     'pyramid': (lambda C: C.PyramidPooling(64), lambda c, p, x: model_ref.pyramid_pooling(c, p, x), [(2, 64, 8, 16)]),
     'pyramid_big': (lambda C: C.PyramidPooling(64), lambda c, p, x: model_ref.pyramid_pooling(c, p, x), [(2, 64, 32, 48)]),
     'ffm_k3': (lambda C: C.FFM(64, 32, k=3, is_cat=False), lambda c, p, x: model_ref.ffm(c, p, x, 3), [(2, 64, 8, 16)]),
