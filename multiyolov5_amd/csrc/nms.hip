@@ -93,21 +93,27 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, const 
 
 __device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2, float by2,
                                        float thr) {
+  // disjoint boxes (in particular boxes of different classes: their offsets differ by >= max_wh) have IoU exactly 0:
+  // four compares instead of the division.  Overlapping ones use torchvision's formula inter/(a+b-inter), strict '>'.
+  const float w = fminf(ax2, bx2) - fmaxf(ax1, bx1), h = fminf(ay2, by2) - fmaxf(ay1, by1);
+  if (w <= 0.f || h <= 0.f) return 0.f > thr;
   const float aa = (ax2 - ax1) * (ay2 - ay1), ab = (bx2 - bx1) * (by2 - by1);
-  const float w = fmaxf(fminf(ax2, bx2) - fmaxf(ax1, bx1), 0.f), h = fmaxf(fminf(ay2, by2) - fmaxf(ay1, by1), 0.f);
   const float inter = w * h;
   return inter / (aa + ab - inter) > thr;
 }
 
 constexpr int SCAN_THREADS = 1024;
 constexpr int MAXW = 1024;            // removed-bit words: up to 65536 sorted candidates per image
+constexpr int LDS_BOXES = 6144;       // class-offset boxes cached in LDS (96 KB); later ones are re-read from L2
 
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* counts, const float* sorted, int cap, int max_nms,
                                                                 int max_det, float iou_thr, float max_wh, int agnostic,
                                                                 float* out, int* nkeep) {
-  __shared__ unsigned long long removed[MAXW];
-  __shared__ float cbox[64][4];
-  __shared__ float kbox[64][4];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem);              // [MAXW]
+  unsigned long long* cmask = removed + MAXW;                                              // [64] intra-chunk masks
+  f4_t* kbox = reinterpret_cast<f4_t*>(cmask + 64);                                        // [64] survivors of the chunk
+  f4_t* lbox = kbox + 64;                                                                  // [LDS_BOXES] offset boxes
   __shared__ int s_nk, s_total;
   const int b = blockIdx.x;
   int m = counts[b];
@@ -116,34 +122,40 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
   const float* sb = sorted + (int64_t)b * max_nms * 6;
   const int tid = threadIdx.x;
   const int words = (m + 63) >> 6;
+  const float off = agnostic ? 0.f : max_wh;
   for (int i = tid; i < words; i += SCAN_THREADS) removed[i] = 0ull;
+  for (int i = tid; i < m && i < LDS_BOXES; i += SCAN_THREADS) {
+    const float o = sb[(int64_t)i * 6 + 5] * off;                     // class offset (general.py:491-492), fp32 like the reference
+    lbox[i] = f4_t{sb[(int64_t)i * 6] + o, sb[(int64_t)i * 6 + 1] + o, sb[(int64_t)i * 6 + 2] + o, sb[(int64_t)i * 6 + 3] + o};
+  }
   if (tid == 0) s_total = 0;
   __syncthreads();
-  const float off = agnostic ? 0.f : max_wh;
+  auto obox = [&](int i) -> f4_t {
+    if (i < LDS_BOXES) return lbox[i];
+    const float o = sb[(int64_t)i * 6 + 5] * off;
+    return f4_t{sb[(int64_t)i * 6] + o, sb[(int64_t)i * 6 + 1] + o, sb[(int64_t)i * 6 + 2] + o, sb[(int64_t)i * 6 + 3] + o};
+  };
   for (int c = 0; c < words; ++c) {
     const int base = c << 6;
-    if (tid < 64) {
-      const int i = base + tid;
-      float x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-      if (i < m) {
-        const float o = sb[(int64_t)i * 6 + 5] * off;                 // class offset (general.py:491-492)
-        x1 = sb[(int64_t)i * 6] + o; y1 = sb[(int64_t)i * 6 + 1] + o; x2 = sb[(int64_t)i * 6 + 2] + o; y2 = sb[(int64_t)i * 6 + 3] + o;
+    const int lim = m - base < 64 ? m - base : 64;
+    const unsigned long long limmask = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+    if ((~removed[c] & limmask) == 0ull) continue;     // every box of the chunk is already suppressed (uniform: read after a barrier)
+    if (tid < 64) cmask[tid] = 0ull;
+    __syncthreads();
+    // (a) the chunk's 64x64 suppression bits, all threads: pair (i, j > i)
+    for (int pr = tid; pr < 64 * 64; pr += SCAN_THREADS) {
+      const int i = pr >> 6, j = pr & 63;
+      if (j > i && j < lim) {
+        const f4_t a = obox(base + i), bb = obox(base + j);
+        if (iou_gt(a[0], a[1], a[2], a[3], bb[0], bb[1], bb[2], bb[3], iou_thr)) atomicOr(&cmask[i], 1ull << j);
       }
-      cbox[tid][0] = x1; cbox[tid][1] = y1; cbox[tid][2] = x2; cbox[tid][3] = y2;
     }
     __syncthreads();
+    // (b) wave 0 resolves the chunk serially with lane-held masks
     if (tid < 64) {
-      // lane i: mask of the chunk's later boxes it suppresses
-      const int i = base + tid;
-      unsigned long long mask = 0ull;
-      if (i < m) {
-        const float x1 = cbox[tid][0], y1 = cbox[tid][1], x2 = cbox[tid][2], y2 = cbox[tid][3];
-        for (int j = tid + 1; j < 64 && base + j < m; ++j)
-          if (iou_gt(x1, y1, x2, y2, cbox[j][0], cbox[j][1], cbox[j][2], cbox[j][3], iou_thr)) mask |= 1ull << j;
-      }
+      const unsigned long long mask = cmask[tid];
       unsigned long long rem = removed[c];
       unsigned long long keepbits = 0ull;
-      const int lim = m - base < 64 ? m - base : 64;
       for (int i2 = 0; i2 < lim; ++i2) {
         const unsigned int lo = __shfl((unsigned int)mask, i2, 64), hi = __shfl((unsigned int)(mask >> 32), i2, 64);
         if (!((rem >> i2) & 1ull)) {
@@ -151,12 +163,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
           rem |= ((unsigned long long)hi << 32) | lo;
         }
       }
-      // survivors of this chunk -> kbox (in order) and the output rows
       const bool mine = (keepbits >> tid) & 1ull;
       const int pos = __popcll(keepbits & ((1ull << tid) - 1ull));
       const int total = s_total;
       if (mine) {
-        kbox[pos][0] = cbox[tid][0]; kbox[pos][1] = cbox[tid][1]; kbox[pos][2] = cbox[tid][2]; kbox[pos][3] = cbox[tid][3];
+        kbox[pos] = obox(base + tid);
         const int o = total + pos;
         if (o < max_det) {
           float* d = out + ((int64_t)b * max_det + o) * 6;
@@ -169,13 +180,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
     __syncthreads();
     const int nk = s_nk;
     if (s_total >= max_det) break;
-    // later boxes suppressed by this chunk's survivors
+    // (c) later boxes suppressed by this chunk's survivors
     for (int j = base + 64 + tid; j < m; j += SCAN_THREADS) {
       if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
-      const float o = sb[(int64_t)j * 6 + 5] * off;
-      const float x1 = sb[(int64_t)j * 6] + o, y1 = sb[(int64_t)j * 6 + 1] + o, x2 = sb[(int64_t)j * 6 + 2] + o, y2 = sb[(int64_t)j * 6 + 3] + o;
+      const f4_t bj = obox(j);
       bool dead = false;
-      for (int q = 0; q < nk && !dead; ++q) dead = iou_gt(kbox[q][0], kbox[q][1], kbox[q][2], kbox[q][3], x1, y1, x2, y2, iou_thr);
+      for (int q = 0; q < nk && !dead; ++q) {
+        const f4_t kq = kbox[q];
+        dead = iou_gt(kq[0], kq[1], kq[2], kq[3], bj[0], bj[1], bj[2], bj[3], iou_thr);
+      }
       if (dead) atomicOr(&removed[j >> 6], 1ull << (j & 63));
     }
     __syncthreads();
@@ -197,7 +210,14 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), 0, st, pred, dtype, A, no, conf_thres,
                      multi_label, cap, counts, cand, cand_idx);
   hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted);
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), 0, st, counts, sorted, cap, max_nms, max_det, iou_thres,
+  const int scan_smem = MAXW * 8 + 64 * 8 + 64 * 16 + LDS_BOXES * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, scan_smem);
+    if (ea != hipSuccess) return (int)ea;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), scan_smem, st, counts, sorted, cap, max_nms, max_det, iou_thres,
                      max_wh, agnostic, out, nkeep);
   MYOLO_CHECK_LAUNCH();
   return 0;

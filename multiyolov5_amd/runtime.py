@@ -117,6 +117,13 @@ class PlanFn(torch.autograd.Function):
         return (None, *in_grads, *pg)
 
 
+# eval-mode forwards (detect.py path) replay the launch list as ONE hipGraph (torch.cuda.graph == hipGraph on ROCm): the
+# reference turns on cudnn.benchmark for streams (detect.py:115-124); here the static launch plan is captured instead.
+# MYOLO_GRAPH=0 disables it; any capture failure falls back to the eager launch list.
+import os as _os
+GRAPH_EVAL = _os.environ.get('MYOLO_GRAPH', '1') != '0'
+
+
 class PlanHolder:
     """a built plan + its input/output binding for one (module, signature)."""
 
@@ -152,6 +159,41 @@ class PlanHolder:
     def param_sig(module):
         return tuple((p.data_ptr(), p.dtype) for p in module.parameters()) + \
             tuple((b.data_ptr(), b.dtype) for b in module.buffers())
+
+    def run_graphed(self, tensors):
+        """eval forward through a captured hipGraph: inputs are copied into static buffers, outputs are the plan's own."""
+        st = self.__dict__
+        if st.get('_graph_failed'):
+            self.bind_inputs(tensors)
+            self.plan.run_fwd()
+            return self.output_tensors()
+        if st.get('_graph') is None:
+            n = st.get('_graph_warm', 0)
+            if n < 2:                                            # two eager runs first (lazy allocations, prepare())
+                st['_graph_warm'] = n + 1
+                self.bind_inputs(tensors)
+                self.plan.run_fwd()
+                return self.output_tensors()
+            try:
+                self._static_in = [torch.empty_strided(t.shape, t.stride(), dtype=t.dtype, device=t.device) for t in tensors]
+                for s_, t in zip(self._static_in, tensors):
+                    s_.copy_(t)
+                self.bind_inputs(self._static_in)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self.plan.run_fwd()
+                st['_graph'] = g
+            except Exception:                                    # noqa: BLE001 -- capture is an optimisation only
+                st['_graph_failed'] = True
+                self.bind_inputs(tensors)
+                self.plan.run_fwd()
+                return self.output_tensors()
+        for s_, t in zip(self._static_in, tensors):
+            if s_.data_ptr() != t.data_ptr():
+                s_.copy_(t)
+        st['_graph'].replay()
+        return self.output_tensors()
 
     def bind_inputs(self, tensors):
         for i, t in enumerate(tensors):
@@ -224,6 +266,8 @@ class PlannedModule(nn.Module):
         h, grad = self._holder(tensors, spec)
         if grad:
             outs = PlanFn.apply(h, *tensors, *h.plan.params)
+        elif not self.training and GRAPH_EVAL:
+            outs = h.run_graphed(tensors)
         else:
             h.bind_inputs(tensors)
             h.plan.run_fwd()
