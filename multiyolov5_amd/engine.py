@@ -584,6 +584,7 @@ class SegOutOp(Op):
         if plan.training:
             g = torch.zeros_like(store).permute(0, 3, 1, 2)
             plan.output_grads[self.slot] = g
+            out._myolo_grad_buf = g                     # utils.loss writes d(loss)/d(logits) straight into the plan's buffer
             self.gld = lw.desc(grad=True)
             self.bwd_calls.append(Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], H, W, *g.stride(), C.byref(self.gld),
                                                                   self.acc), keep=g))

@@ -88,7 +88,14 @@ class PlanFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         holder.bind_inputs(tensors[:holder.n_in])
         plan.run_fwd()
-        outs = tuple(o.detach() for o in holder.output_tensors())
+        outs = []
+        for o in holder.output_tensors():
+            d = o.detach()
+            for attr in ('_myolo_low', '_myolo_grad_buf'):          # side channels of the fused loss / argmax kernels
+                if hasattr(o, attr):
+                    setattr(d, attr, getattr(o, attr))
+            outs.append(d)
+        outs = tuple(outs)
         holder.pending_bwd = True
         return outs
 
@@ -103,8 +110,8 @@ class PlanFn(torch.autograd.Function):
             dst = holder.output_grad_tensor(s)
             if g is None:
                 dst.zero_()
-            else:
-                dst.copy_(g)
+            elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
+                dst.copy_(g)                              # (the fused losses already wrote into dst: nothing to move)
         plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
         holder.pending_bwd = False
         in_grads = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]

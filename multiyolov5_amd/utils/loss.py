@@ -60,13 +60,20 @@ class _SegCE(torch.autograd.Function):
                                           L.ptr(loss), L.ptr(sel), st), 'myolo_ohem_select')
         ctx.save_for_backward(logits, target, acc)
         ctx.pix, ctx.sel, ctx.ignore, ctx.thresh = pix, sel, int(ignore_index), ohem_thresh
+        # the producing plan's gradient buffer (saves a 2nd 300 MB tensor + copy); one loss per forward may claim it
+        ctx.grad_buf = None
+        if getattr(logits, '_myolo_grad_buf', None) is not None and not getattr(logits, '_myolo_grad_claimed', False):
+            ctx.grad_buf = logits._myolo_grad_buf
+            logits._myolo_grad_claimed = True
         return loss.view(())
 
     @staticmethod
     def backward(ctx, go):
         logits, target, acc = ctx.saved_tensors
         n, c, h, w = logits.shape
-        grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
+        grad = ctx.grad_buf
+        if grad is None or grad.shape != logits.shape or grad.stride() != logits.stride() or grad.dtype != logits.dtype:
+            grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
         gout = go.detach().to(torch.float32).reshape(1).contiguous()
         L.check(L.lib().myolo_seg_ce_bwd(L.ptr(logits), L.ptr(grad), L.DT[logits.dtype], n, c, h, w, *logits.stride(),
                                          *grad.stride(), L.ptr(target), ctx.ignore, L.ptr(acc), L.ptr(gout), L.ptr(ctx.pix),
