@@ -181,6 +181,11 @@ int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, int64_t sn,
                            const myolo_tensor* glow, int accumulate, void* stream);
 /* detect.py:191-193 fused: bilinear resize of the logits to (H,W) + argmax over classes -> labels [N,H,W] (u8|i64) */
 int myolo_seg_argmax(const myolo_tensor* low, void* labels, int label_dtype, int H, int W, void* stream);
+/* seg_validation counters (utils/metrics.py:234-275 batch_pix_accuracy + batch_intersection_union, test.py:31-65) from predicted
+ * labels (u8|i64, e.g. myolo_seg_argmax) and int64 targets (-1 = ignore): counts (device uint64[2+3*nclass], zeroed here) =
+ * {pixel_correct, pixel_labeled, area_inter[nclass], area_pred[nclass], area_lab[nclass]}; union = pred + lab - inter. */
+int myolo_seg_metrics(const void* pred, int pred_dtype, const int64_t* target, int64_t total, int nclass, uint64_t* counts,
+                      void* stream);
 /* gradient of Detect's view/permute (yolo.py:214): dense [N,na,ny,nx,no] -> NHWC view [N,ny,nx,>=na*no] */
 int myolo_detect_unpermute(const void* g, int g_dtype, int na, int no, const myolo_tensor* out, void* stream);
 /* Detect eval decode (yolo.py:216-223) of one level: raw dense [N,na,ny,nx,no] -> rows [row0, row0+na*ny*nx) of

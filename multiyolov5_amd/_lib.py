@@ -89,6 +89,7 @@ _PROTOS = {
     'myolo_seg_upsample_fwd': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, P]),
     'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P]),
     'myolo_seg_argmax': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, P]),
+    'myolo_seg_metrics': (C.c_int, [P, C.c_int, P, C.c_int64, C.c_int, P, P]),
     'myolo_detect_unpermute': (C.c_int, [P, C.c_int, C.c_int, C.c_int, TP, P]),
     'myolo_detect_decode': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                       C.POINTER(C.c_float), P, C.c_int64, C.c_int64, P]),

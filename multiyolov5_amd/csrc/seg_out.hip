@@ -247,6 +247,31 @@ inline bool dense_cl(const void* p, int dt, int C, int H, int W, int64_t sn, int
          ((int64_t)W * C * es) % 16 == 0 && ((uintptr_t)p & 15) == 0 && C <= MAXC;
 }
 
+
+// ---- evaluation counters (reference utils/metrics.py:234-275, called per batch by test.py:31-65 seg_validation) ---------
+// counts[0] = pixel_correct, counts[1] = pixel_labeled, then area_inter[n], area_pred[n], area_lab[n] (all over target >= 0;
+// np.histogram(x, bins=n, range=(1, n)) of the 1-based labels is the identity binning).  Bit-exact integer work.
+__global__ __launch_bounds__(256) void seg_metrics_kernel(const void* pred, int pdt, const int64_t* tgt, int64_t total, int ncls,
+                                                          unsigned long long* counts) {
+  __shared__ unsigned int h[3 * MAXC + 2];
+  for (int i = threadIdx.x; i < 3 * MAXC + 2; i += 256) h[i] = 0;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = tgt[i];
+    if (t < 0) continue;                                            // target + 1 > 0 (metrics.py:241,243 / 265)
+    const int pr = pdt == MYOLO_I64 ? (int)((const int64_t*)pred)[i] : (int)((const uint8_t*)pred)[i];
+    atomicAdd(&h[1], 1u);
+    if (pr == (int)t) { atomicAdd(&h[0], 1u); if (pr < ncls) atomicAdd(&h[2 + pr], 1u); }
+    if (pr >= 0 && pr < ncls) atomicAdd(&h[2 + MAXC + pr], 1u);
+    if (t < ncls) atomicAdd(&h[2 + 2 * MAXC + (int)t], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 + 3 * ncls; i += 256) {
+    const int src = i < 2 ? i : 2 + ((i - 2) / ncls) * MAXC + (i - 2) % ncls;
+    if (h[src]) atomicAdd(counts + i, (unsigned long long)h[src]);
+  }
+}
+
 // g: dense [N,na,ny,nx,no] (dtype gdt) -> out NHWC view [N,ny,nx,na*no] (padded channels untouched)
 __global__ __launch_bounds__(256) void detect_unpermute_kernel(const void* g, int gdt, int na, int no, myolo_tensor out) {
   const int C = na * no;
@@ -361,6 +386,19 @@ extern "C" int myolo_detect_decode(const void* raw, int dtype, int n, int na, in
   hipLaunchKernelGGL(detect_decode_kernel, dim3(grid_for((int64_t)n * na * ny * nx, 256)), dim3(256), 0,
                      (hipStream_t)stream, raw, dtype, n, na, ny, nx, no, stride, anchor_wh_px[0], anchor_wh_px[1],
                      anchor_wh_px[2], anchor_wh_px[3], anchor_wh_px[4], anchor_wh_px[5], z, a_total, row0);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_seg_metrics(const void* pred, int pred_dtype, const int64_t* target, int64_t total, int nclass,
+                                 uint64_t* counts, void* stream) {
+  if (!pred || !target || !counts || total < 1 || nclass < 1 || nclass > MAXC || (pred_dtype != MYOLO_U8 && pred_dtype != MYOLO_I64))
+    return MYOLO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(counts, 0, (2 + 3 * nclass) * sizeof(uint64_t), st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(seg_metrics_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), 0, st, pred, pred_dtype, target, total, nclass,
+                     reinterpret_cast<unsigned long long*>(counts));
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

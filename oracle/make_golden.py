@@ -189,11 +189,26 @@ def nms_case(ref):
     print('wrote nms', {k: v.shape for k, v in out.items()})
 
 
+def metrics_case(ref):
+    import utils.metrics as rmetrics          # the reference's own module (matplotlib is importable here)
+    rs = np.random.RandomState(11)
+    logits = torch.from_numpy(rs.normal(0, 2.0, (2, 19, 48, 80)).astype(np.float32))
+    mask = synth.synth_seg_targets(2, 48, 80, 19, seed=6, blocky=4)
+    with torch.no_grad():                      # make ~60 % of the pixels correct so that every counter is exercised
+        good = torch.from_numpy(rs.uniform(size=(2, 48, 80)) < 0.6)
+        logits += torch.zeros_like(logits).scatter_(1, mask.clamp(0)[:, None], 9.0) * good[:, None]
+    correct, labeled = rmetrics.batch_pix_accuracy(logits, mask)
+    inter, union = rmetrics.batch_intersection_union(logits, mask, 19)
+    np.savez_compressed(os.path.join(GOLD, 'metrics.npz'), logits=logits.numpy(), mask=mask.numpy().astype(np.int16),
+                        correct=np.array(correct), labeled=np.array(labeled), inter=inter, union=union)
+    print('wrote metrics', int(correct), int(labeled))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['models', 'losses', 'nms']
+    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics']
     if 'models' in which:
         model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
         model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
@@ -204,6 +219,8 @@ def main():
         loss_case(ref)
     if 'nms' in which:
         nms_case(ref)
+    if 'metrics' in which:
+        metrics_case(ref)
 
 
 if __name__ == '__main__':

@@ -96,3 +96,29 @@ def test_seg_argmax_fused_matches_oracle_and_model_output():
     lab2 = seg_argmax(seg, 100, 180, out_dtype=torch.uint8)
     ref2 = nms_ref.seg_argmax(seg[0].float().cpu().numpy(), 100, 180)
     assert (lab2[0].cpu().numpy() != ref2).mean() < 2e-3
+
+
+def test_seg_metrics_match_reference_golden_and_oracle():
+    """test.py:31-65 counters (batch_pix_accuracy / batch_intersection_union) on the device: bit-exact integers."""
+    from multiyolov5_amd.utils.metrics import batch_intersection_union, batch_pix_accuracy
+    from oracle import metrics_ref
+    g = golden('metrics')
+    logits = torch.from_numpy(g['logits']).to(DEV)
+    mask = torch.from_numpy(g['mask'].astype(np.int64)).to(DEV)
+    c, l = batch_pix_accuracy(logits, mask)
+    i, u = batch_intersection_union(logits, mask, 19)
+    assert int(c) == int(g['correct']) and int(l) == int(g['labeled'])
+    np.testing.assert_array_equal(i, g['inter'])
+    np.testing.assert_array_equal(u, g['union'])
+    # full-size labels [2,1024,2048], all-ignored image, class 18 present
+    rs = np.random.RandomState(3)
+    x = torch.from_numpy(rs.normal(0, 1, (2, 19, 128, 256)).astype(np.float32))
+    m = synth.synth_seg_targets(2, 128, 256, 19, seed=9)
+    m[1] = -1
+    c2, l2 = batch_pix_accuracy(x.to(DEV), m.to(DEV))
+    i2, u2 = batch_intersection_union(x.to(DEV), m.to(DEV), 19)
+    rc, rl = metrics_ref.batch_pix_accuracy(x.numpy(), m.numpy())
+    ri, ru = metrics_ref.batch_intersection_union(x.numpy(), m.numpy(), 19)
+    assert (int(c2), int(l2)) == (int(rc), int(rl))
+    np.testing.assert_array_equal(i2, ri)
+    np.testing.assert_array_equal(u2, ru)

@@ -137,3 +137,14 @@ def test_bilinear_restatement_matches_aten():
     x = torch.randn(5, 8, 16)
     ref = torch.nn.functional.interpolate(x[None], size=(64, 128), mode='bilinear', align_corners=True)[0]
     np.testing.assert_allclose(nms_ref.bilinear_ac(x.numpy(), 64, 128), ref.numpy(), rtol=1e-5, atol=1e-6)
+
+
+def test_metrics_restatement_matches_reference_golden():
+    from oracle import metrics_ref
+    g = golden('metrics')
+    mask = g['mask'].astype(np.int64)
+    c, l = metrics_ref.batch_pix_accuracy(g['logits'], mask)
+    i, u = metrics_ref.batch_intersection_union(g['logits'], mask, 19)
+    assert int(c) == int(g['correct']) and int(l) == int(g['labeled'])
+    np.testing.assert_array_equal(i, g['inter'])
+    np.testing.assert_array_equal(u, g['union'])
