@@ -49,6 +49,10 @@ typedef struct myolo_tensor {
 int myolo_version(void);                 /* ABI version of this header */
 const char* myolo_arch(void);            /* "gfx950" */
 
+/* tuning / test knobs: "stream_min_tiles" (minimum number of 32-pixel row tiles for the streaming conv kernel, default 2048; the
+ * parity tests set 1 so that small shapes exercise it), "stream_off" (1: always use the LDS-tiled kernel).  Returns 0 or MYOLO_EINVAL. */
+int myolo_set_option(const char* name, int value);
+
 /* ---- weights ------------------------------------------------------------------------------- */
 /* OIHW master weights (nn.Conv2d.weight, common.py:38) -> MFMA-friendly packed layout
  *   transpose=0: dst[rows=cout_pad][ntaps][cols=cin_pad]   (forward operand, K = tap*cin contiguous)

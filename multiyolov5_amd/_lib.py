@@ -63,6 +63,7 @@ TP = C.POINTER(Tensor)
 _PROTOS = {
     'myolo_version': (C.c_int, []),
     'myolo_arch': (C.c_char_p, []),
+    'myolo_set_option': (C.c_int, [C.c_char_p, C.c_int]),
     'myolo_pack_weight': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     'myolo_pack_weights_mt': (C.c_int, [P, P, C.c_int, C.c_int, P]),
     'myolo_focus_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, TP, P]),

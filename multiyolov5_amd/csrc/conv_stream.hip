@@ -15,6 +15,7 @@
 // Same contract as myolo_conv (include/myolo.h); selected by myolo_conv when the layer qualifies (conv_igemm.hip).
 #include "myolo_dev.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace stream {
 
@@ -311,10 +312,22 @@ static inline int panel_pitch(int K) {                    // bytes; multiple of 
 }
 
 // returns -1 when the layer does not qualify (caller falls back to the LDS-tiled kernel), else a hipError_t / 0
+static int g_stream_min_tiles = -1;      // -1: from the environment (MYOLO_STREAM_MIN_TILES) or 2048
+static int g_stream_off = -1;
+
+extern "C" int myolo_set_option(const char* name, int value) {
+  if (!name) return MYOLO_EINVAL;
+  if (!strcmp(name, "stream_min_tiles")) { g_stream_min_tiles = value; return 0; }
+  if (!strcmp(name, "stream_off")) { g_stream_off = value; return 0; }
+  return MYOLO_EINVAL;
+}
+
 int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   using namespace stream;
-  static const int min_tiles = getenv("MYOLO_STREAM_MIN_TILES") ? atoi(getenv("MYOLO_STREAM_MIN_TILES")) : 2048;
-  static const bool off = getenv("MYOLO_NO_STREAM") != nullptr;
+  if (g_stream_min_tiles < 0) g_stream_min_tiles = getenv("MYOLO_STREAM_MIN_TILES") ? atoi(getenv("MYOLO_STREAM_MIN_TILES")) : 2048;
+  if (g_stream_off < 0) g_stream_off = getenv("MYOLO_NO_STREAM") != nullptr;
+  const int min_tiles = g_stream_min_tiles;
+  const bool off = g_stream_off != 0;
   if (off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
   if (d->cin_pad % 32) return -1;
   // N tile: the weight panel [BN][ntaps*cin_pad] (+16 B row padding) must fit beside the 8 wave-private staging areas

@@ -109,3 +109,40 @@ def test_train_forward_backward_vs_oracle(tag, dtype):
         if 'running' in k:
             check(f'{tag}/{k}', b, sdt[k], tol, collect=bad)
     assert not bad, '\n'.join(bad[:20])
+
+
+def test_amp_training_steps_run_and_learn():
+    """three loss-scaled fp16 joint steps (the bench.py step: forward, ComputeLoss + seg CE, backward with the weight gradients
+    on the side stream, fused SGD + EMA) at 2x3x256x512: finite losses, no skipped update, parameters move, EMA follows"""
+    from multiyolov5_amd import synth as psynth
+    from multiyolov5_amd.models.yolo import Model
+    from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
+    from multiyolov5_amd.utils.optim import FusedSGD, GradScaler
+    from multiyolov5_amd.utils.torch_utils import ModelEMA
+    m = Model(os.path.join(CFG, TAGS['s_psp']))
+    psynth.randomize_(m, seed=0)
+    m = m.to(DEV).train()
+    m.nc, m.gr = 10, 1.0
+    m.hyp = loss_ref.scaled_hyp(512, 10, 3)
+    x = psynth.images(2, 256, 512, seed=1).to(DEV, torch.float16)
+    t = psynth.det_targets(2, 8, 10, seed=1).to(DEV)
+    mask = psynth.seg_targets(2, 256, 512, 19, seed=1).to(DEV)
+    cl, sl = ComputeLoss(m), SegmentationLosses()
+    opt = FusedSGD(m.parameters(), lr=0.01, momentum=0.9, nesterov=True)
+    scaler, ema = GradScaler(init_scale=1024.0), ModelEMA(m)
+    w0 = m.model[1].conv.weight.detach().clone()
+    e0 = ema.ema.model[1].conv.weight.detach().clone()
+    seg_losses = []
+    for _ in range(3):
+        det, seg = m(x)
+        loss, items = cl(det, t)
+        sloss = sl(seg, mask)
+        scaler.scale(loss * 0.6 + sloss * 2 * 0.35).backward()
+        assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+        scaler.step(opt); scaler.update(); opt.zero_grad(); ema.update(m)
+        assert torch.isfinite(loss).all() and torch.isfinite(sloss)
+        seg_losses.append(float(sloss.detach()))
+    assert scaler.get_scale() == 1024.0                      # no inf/nan step was skipped
+    assert float((m.model[1].conv.weight - w0).abs().max()) > 0
+    assert float((ema.ema.model[1].conv.weight - e0).abs().max()) > 0
+    assert seg_losses[-1] < seg_losses[0]                    # the same batch three times: the loss goes down

@@ -111,3 +111,48 @@ def test_focus_f32_and_f16():
         ref_out, *_ = _oracle(lambda c, p, xx: model_ref.focus(c, p, xx), mod, [x.to(dtype)], False)
         out = mod(x.to(DEV, dtype))
         check(f'focus/{dtype}', out, ref_out, TOL[dtype])
+
+
+@pytest.fixture
+def force_stream_kernel():
+    """route every qualifying fp16 conv through the streaming kernel (conv_stream.hip), whatever the map size"""
+    from multiyolov5_amd import _lib
+    _lib.check(_lib.lib().myolo_set_option(b'stream_min_tiles', 1))
+    yield
+    _lib.check(_lib.lib().myolo_set_option(b'stream_min_tiles', 2048))
+
+
+@pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
+@pytest.mark.parametrize('name', ['conv1x1', 'conv3x3', 'conv3x3s2', 'conv3x3s2_odd', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'aspp', 'ffm_k3'])
+def test_block_streaming_kernel(name, training, force_stream_kernel):
+    """the same block parity cases with the streaming conv kernel forced on (ragged M, stride 2, dilation, residual,
+    accumulate, BatchNorm statistics) -- at the default threshold it only serves maps of >= 65536 pixels"""
+    test_block(name, training, torch.float16)
+
+
+def test_full_resolution_eval_forward_vs_oracle():
+    """1x3x512x1024 (the benchmark resolution): fused eval forward in fp16 -- streaming kernel at its real tile counts -- and fp32,
+    against the CPU oracle"""
+    import os
+    from multiyolov5_amd.models.yolo import Model
+    from oracle import synth
+    from tests.util import CFG, TAGS, load_cfg, synth_sd
+    tag = 's_psp'
+    sd = synth_sd(tag)
+    x = synth.synth_images(1, 512, 1024, seed=3)
+    fsd = model_ref.fuse_state_dict({k: v.clone() for k, v in sd.items()})
+    with torch.no_grad():
+        (rpred, _), rseg = model_ref.forward(load_cfg(tag), fsd, x, training=False)
+    for dtype, tol in ((torch.float32, 2e-4), (torch.float16, 3e-2)):
+        m = Model(os.path.join(CFG, TAGS[tag]))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(DEV)
+        if dtype == torch.float16:
+            m = m.half()
+        m.fuse().eval()
+        with torch.no_grad():
+            (pred, raw), seg = m(x.to(DEV, dtype))
+        check(f'fullres/{dtype}/pred', pred, rpred, tol)
+        check(f'fullres/{dtype}/seg', seg, rseg, tol)
+        if dtype == torch.float32:
+            assert (seg.argmax(1).cpu() != rseg.argmax(1)).float().mean() < 1e-3
