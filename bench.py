@@ -247,8 +247,9 @@ def main():
         'value': ips, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': args.dtype, 'data': 'synthetic',
-        'config': {'workload': f'{args.cfg} psp head bs={args.batch}/GPU {W}x{H} fp16 joint train step (BASELINE configs[1])'
-                   if args.dtype == 'f16' else f'{args.cfg} bs={args.batch}/GPU {W}x{H} fp32 parity mode',
+        'config': {'workload': (f'{args.cfg} bs={args.batch}/GPU {W}x{H} {args.dtype} joint train step'
+                                + (' (psp head; BASELINE configs[1])' if args.cfg == 'yolov5s_city_seg.yaml' and args.batch == 16
+                                   and args.dtype == 'f16' else '')),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'stage': args.stage},
     }
     if args.stage != 'train':
