@@ -31,6 +31,7 @@ struct ConvS {
   const float* scale; const float* shift; int act; int accumulate;
   const char* res; int64_t r_sn, r_sh, r_sw;
   float* stats; int M; int ntiles; int tiles_per_xcd; int pitchB; int xdense, ydense; int dbg;
+  int x_bytes, y_bytes, r_bytes;     // byte spans of the views (buffer descriptors)
 };
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // H = {0,2,3,1}
@@ -96,58 +97,66 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { st_s[nf][r] = 0.f; st_q[nf][r] = 0.f; }
 
+  // ---- buffer descriptors: hardware bounds checking does the masking -- an out-of-range voffset loads zeros and drops stores, so
+  // neither loads nor stores need branches or a zero page, and addressing is one 32-bit add per access (wave-uniform base) ----
+  constexpr int OOB = 0x7fff0000;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.res ? p.res : p.y), 0, p.res ? p.r_bytes : 0, 0x00020000);
+
   // ---- issue cursor ----
   int i_tile = my_first, i_tap = 0, i_kc = 0, i_left = nchunks;
-  const char* i_base[2] = {nullptr, nullptr};
-  int i_y0[2], i_x0[2]; bool i_ok[2];
+  int i_off[2];                        // byte offset of the tile row's centre pixel (or OOB)
+  int i_y0[2], i_x0[2];
   auto decode_issue = [&]() {
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
       const int m = i_tile * 32 + mf * 16 + l15;
-      i_ok[mf] = m < p.M;
-      const int mm = i_ok[mf] ? m : 0;
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
       if (p.xdense) {                       // 1x1 stride 1 over a pixel-dense view: pixel m is at base + m*sw
-        i_base[mf] = p.x + (int64_t)mm * p.x_sw * 2;
+        i_off[mf] = ok ? mm * (int)p.x_sw * 2 : OOB;
         i_y0[mf] = 0; i_x0[mf] = 0;
       } else {
         const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
-        i_base[mf] = p.x + (int64_t)n * p.x_sn * 2;
+        i_off[mf] = ok ? n * (int)p.x_sn * 2 : OOB;
         i_y0[mf] = oy * p.stride; i_x0[mf] = ox * p.stride;
       }
     }
   };
   if (i_left > 0) decode_issue();
   uint4 ring[RING][2 * KB];
+  auto bload = [&](int off) -> uint4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+    return uint4{v.x, v.y, v.z, v.w};
+  };
   auto issue = [&](uint4* dst) {
-    // branch-free: every load is issued unconditionally, dead lanes / padded channels / finished waves read the zero page
+    // branch-free: every load is issued unconditionally; dead lanes / padded channels / finished waves use an out-of-range offset
     const bool live = i_left > 0;
     const bool ld = live && !(p.dbg & 2);
-    const char* zp = zero_page();
     if (p.xdense) {
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           const int c0 = i_kc * KCH + kb * 32 + lq * 8;
-          const char* ptr = (ld && i_ok[mf] && c0 < p.Cin) ? i_base[mf] + c0 * 2 : zp;
-          dst[mf * KB + kb] = ldg16(ptr);
+          dst[mf * KB + kb] = bload((ld && c0 < p.Cin) ? i_off[mf] + c0 * 2 : OOB);
         }
     } else {
-      // wave-uniform tap index -> scalar loads of the tap table (a VGPR-indexed table read is a global_load that would
+      // wave-uniform tap index -> LDS broadcast read of the tap table (a VGPR-indexed kernarg read is a global_load that would
       // queue BEHIND the prefetched activations in the in-order vmcnt queue)
       const int ut = __builtin_amdgcn_readfirstlane(i_tap);
       const int dy = sTap[ut], dx = sTap[MYOLO_MAX_TAPS + ut];
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf) {
         int iy = i_y0[mf] + dy, ix = i_x0[mf] + dx;
-        const bool ok = ld && i_ok[mf] && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
+        const bool ok = ld && (unsigned)iy < (unsigned)Hlog && (unsigned)ix < (unsigned)Wlog;
         iy >>= p.up; ix >>= p.up;
-        const char* rp = i_base[mf] + ((int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * 2;
+        const int ro = i_off[mf] + (iy * (int)p.x_sh + ix * (int)p.x_sw) * 2;
 #pragma unroll
         for (int kb = 0; kb < KB; ++kb) {
           const int c0 = i_kc * KCH + kb * 32 + lq * 8;
-          const char* ptr = (ok && c0 < p.Cin) ? rp + c0 * 2 : zp;
-          dst[mf * KB + kb] = ldg16(ptr);
+          dst[mf * KB + kb] = bload((ok && c0 < p.Cin) ? ro + c0 * 2 : OOB);
         }
       }
     }
@@ -172,49 +181,48 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
       const int m = tile * 32 + mf * 16 + l15;
-      const bool mok = m < p.M;
-      int64_t yoff, roff = 0;
+      const bool mok = m < p.M && !(p.dbg & 1);
+      int yoff, roff = 0;                      // byte offsets (buffer addressing; out-of-range -> the store is dropped)
       if (p.ydense) {
-        yoff = (int64_t)m * p.y_sw;
-        if (p.res) roff = (int64_t)m * p.r_sw;
+        yoff = m * (int)p.y_sw * 2;
+        if (EXTRA) roff = m * (int)p.r_sw * 2;
       } else {
         const int mm = mok ? m : 0;
         const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
-        yoff = (int64_t)n * p.y_sn + (int64_t)oy * p.y_sh + (int64_t)ox * p.y_sw;
-        if (p.res) roff = (int64_t)n * p.r_sn + (int64_t)oy * p.r_sh + (int64_t)ox * p.r_sw;
+        yoff = (n * (int)p.y_sn + oy * (int)p.y_sh + ox * (int)p.y_sw) * 2;
+        if (EXTRA) roff = (n * (int)p.r_sn + oy * (int)p.r_sh + ox * (int)p.r_sw) * 2;
       }
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        const int c0 = tn * BN + nf * 16 + 4 * lq;
+        const int cl = nf * 16 + 4 * lq;
+        const int c0 = tn * BN + cl;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v0 = acc[mf][nf][r];
           acc[mf][nf][r] = 0.f;
           if (EPI == 0) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; v[r] = v0; }
-          else {
-            const int cl = nf * 16 + 4 * lq + r;
-            v[r] = act_f(v0 * sT[cl] + sT[BN + cl], p.act);
-          }
+          else v[r] = act_f(v0 * sT[cl + r] + sT[BN + cl + r], p.act);
         }
-        if (!mok || c0 >= p.Cout || (p.dbg & 1)) continue;   // Cout % 4 == 0 (checked on the host): whole 8-byte groups only
-        half_t* yp = reinterpret_cast<half_t*>(p.y) + yoff + c0;
-        if (EXTRA) {                                   // residual / accumulate: loads inside the epilogue (drain the prefetch queue)
+        const bool ok = mok && c0 < p.Cout;       // Cout % 4 == 0 (checked on the host): whole 8-byte groups only
+        if (EXTRA) {                           // residual / accumulate: loads inside the epilogue (they drain the prefetch queue)
           if (p.res) {
-            const h4_t g = *reinterpret_cast<const h4_t*>(reinterpret_cast<const half_t*>(p.res) + roff + c0);
+            const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(rr, ok ? roff + c0 * 2 : OOB, 0, 0);
+            const h4_t gh = *reinterpret_cast<const h4_t*>(&g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)g[r];
+            for (int r = 0; r < 4; ++r) v[r] += (float)gh[r];
           }
           if (p.accumulate) {
-            const h4_t g = *reinterpret_cast<const h4_t*>(yp);
+            const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
+            const h4_t gh = *reinterpret_cast<const h4_t*>(&g);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)g[r];
+            for (int r = 0; r < 4; ++r) v[r] += (float)gh[r];
           }
         }
         h4_t o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-        *reinterpret_cast<h4_t*>(yp) = o;
+        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2_t*>(&o), ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
       }
     }
   };
@@ -366,6 +374,12 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   static const int dbg = getenv("MYOLO_STREAM_DBG") ? atoi(getenv("MYOLO_STREAM_DBG")) : 0;
   k.dbg = dbg;
   if (k.stats && (k.scale || k.shift || k.act != MYOLO_ACT_NONE)) return -1;   // statistics only with the raw epilogue
+  auto span = [](const myolo_tensor& t) -> int64_t {
+    return (((int64_t)t.n - 1) * t.sn + ((int64_t)t.h - 1) * t.sh + ((int64_t)t.w - 1) * t.sw + t.c) * 2;
+  };
+  const int64_t xb = span(d->x), yb = span(d->y), rb = d->res.ptr ? span(d->res) : 0;
+  if (xb >= 0x7ffe0000LL || yb >= 0x7ffe0000LL || rb >= 0x7ffe0000LL) return -1;      // 32-bit buffer offsets
+  k.x_bytes = (int)xb; k.y_bytes = (int)yb; k.r_bytes = (int)rb;
   int smem = bn * k.pitchB + 2 * bn * 4 + 2 * MYOLO_MAX_TAPS * 4;
   if (smem < WAVES * 2 * bn * 4) smem = WAVES * 2 * bn * 4;
   const int ntile_n = d->cout_pad / bn;

@@ -73,6 +73,7 @@ template <> struct Vec<float> {
 // explicit global address space: pointers that went through a select (e.g. with the zero page) would otherwise decay to
 // FLAT loads, which also count on lgkmcnt and defeat counted vmcnt waits
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) u32x4_t g_u32x4_t;
 __device__ __forceinline__ uint4 ldg16(const void* p) {
   const u32x4_t v = *(const g_u32x4_t*)(p);
