@@ -29,6 +29,7 @@ struct WgradK {
   int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
   int M, ksplit, pix_per_split, tiles_co, tiles_ci;
   int cout_w, cin_w;   // real (unpadded) weight dims: bounds of dw
+  int x_bytes, d_bytes, dense;   // buffer-descriptor spans; dense: 1x1 stride-1 over pixel-dense views (pixel m at m*sw)
   float* ws;           // split-K partials [ksplit][ntaps][tiles_co*64][tiles_ci*64] (plain stores) or NULL (atomics)
   int dbg;
 };
@@ -70,6 +71,15 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradK p) {
     for (int j = 0; j < 2; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
   float bias_part = 0.f;   // db partial: thread (tid<64) sums dy column co0+tid ; only for tci==0 && tap==0
 
+  // buffer descriptors: out-of-range offsets load zeros (rows past the split, outside the image, padded channels): no branches,
+  // 32-bit address arithmetic
+  constexpr int OOB = 0x7fff0000;
+  const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, p.d_bytes, 0x00020000);
+  auto bl = [&](const __amdgpu_buffer_rsrc_t& r, int off) -> uint4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return uint4{v.x, v.y, v.z, v.w};
+  };
   uint4 rd[LOADS], rx[LOADS];
   auto issue = [&](int s) {
 #pragma unroll
@@ -77,20 +87,25 @@ __global__ __launch_bounds__(THREADS) void wgrad_kernel(const WgradK p) {
       const int v = tid + l * THREADS;
       const int prow = v / SEGS_PER_ROW, cs = v - prow * SEGS_PER_ROW;
       const int m = m_begin + s * KP + prow;
-      // unconditional loads; rows past the split / outside the image / padded channels read the zero page (myolo_dev.h)
-      const bool live = m < m_end;
-      const int mm = live ? m : m_begin;
-      const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
-      const int cd = co0 + cs * SEG;
-      const char* dp = (live && cd < p.Cout)
-          ? p.dy + ((int64_t)n * p.d_sn + (int64_t)oy * p.d_sh + (int64_t)ox * p.d_sw + cd) * ES : zero_page();
-      rd[l] = (p.dbg & 2) ? uint4{0u, 0u, 0u, 0u} : ldg16(dp);
-      int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
-      const int cx = ci0 + cs * SEG;
-      const bool xin = live && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog && cx < p.Cin;
-      iy >>= p.up; ix >>= p.up;
-      const char* xp = xin ? p.x + ((int64_t)n * p.x_sn + (int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw + cx) * ES : zero_page();
-      rx[l] = (p.dbg & 2) ? uint4{0u, 0u, 0u, 0u} : ldg16(xp);
+      const bool live = m < m_end && !(p.dbg & 2);
+      const int cd = co0 + cs * SEG, cx = ci0 + cs * SEG;
+      int doff, xoff;
+      if (p.dense) {                                   // 1x1 stride 1: no div/mod (it cost ~60 instructions per 4 MFMAs)
+        doff = m * (int)p.d_sw + cd;
+        xoff = m * (int)p.x_sw + cx;
+        doff = (live && cd < p.Cout) ? doff * ES : OOB;
+        xoff = (live && cx < p.Cin) ? xoff * ES : OOB;
+      } else {
+        const int mm = live ? m : m_begin;
+        const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+        doff = (live && cd < p.Cout) ? (n * (int)p.d_sn + oy * (int)p.d_sh + ox * (int)p.d_sw + cd) * ES : OOB;
+        int iy = oy * p.stride + tdy, ix = ox * p.stride + tdx;
+        const bool xin = live && (unsigned)iy < (unsigned)Hlog && (unsigned)ix < (unsigned)Wlog && cx < p.Cin;
+        iy >>= p.up; ix >>= p.up;
+        xoff = xin ? (n * (int)p.x_sn + iy * (int)p.x_sh + ix * (int)p.x_sw + cx) * ES : OOB;
+      }
+      rd[l] = bl(rbd, doff);
+      rx[l] = bl(rbx, xoff);
     }
   };
   auto stage = [&](int buf) {
@@ -231,24 +246,28 @@ __global__ __launch_bounds__(THREADS) void wgrad_fused_kernel(const WgradK p) {
 
   const int prow = tid / SEGS_PER_ROW, cs = tid - prow * SEGS_PER_ROW;
   const int cd = co0 + cs * SEG, cx = ci0 + cs * SEG;
+  constexpr int OOB = 0x7fff0000;
+  const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, p.d_bytes, 0x00020000);
+  auto bl = [&](const __amdgpu_buffer_rsrc_t& r, int off) -> uint4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return uint4{v.x, v.y, v.z, v.w};
+  };
   uint4 rd, rx[NT];
   auto issue = [&](int s) {
     const int m = m_begin + s * KP + prow;
     const bool live = m < m_end;
     const int mm = live ? m : m_begin;
     const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
-    const char* dp = (live && cd < p.Cout)
-        ? p.dy + ((int64_t)n * p.d_sn + (int64_t)oy * p.d_sh + (int64_t)ox * p.d_sw + cd) * ES : zero_page();
-    rd = ldg16(dp);
-    const char* xn = p.x + ((int64_t)n * p.x_sn + cx) * ES;
+    rd = bl(rbd, (live && cd < p.Cout) ? (n * (int)p.d_sn + oy * (int)p.d_sh + ox * (int)p.d_sw + cd) * ES : OOB);
+    const int xn = n * (int)p.x_sn + cx;
     const bool cok = live && cx < p.Cin;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       int iy = oy * p.stride + p.tap_dy[t], ix = ox * p.stride + p.tap_dx[t];
-      const bool ok = cok && iy >= 0 && iy < Hlog && ix >= 0 && ix < Wlog;
+      const bool ok = cok && (unsigned)iy < (unsigned)Hlog && (unsigned)ix < (unsigned)Wlog;
       iy >>= p.up; ix >>= p.up;
-      const char* xp = ok ? xn + ((int64_t)iy * p.x_sh + (int64_t)ix * p.x_sw) * ES : zero_page();
-      rx[t] = ldg16(xp);
+      rx[t] = bl(rbx, ok ? (xn + iy * (int)p.x_sh + ix * (int)p.x_sw) * ES : OOB);
     }
   };
 
@@ -362,6 +381,17 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
   if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
   k.M = (int)M;
+  {
+    auto span = [&](const myolo_tensor& t) -> int64_t {
+      return (((int64_t)t.n - 1) * t.sn + ((int64_t)t.h - 1) * t.sh + ((int64_t)t.w - 1) * t.sw + t.c) * (dt == MYOLO_F16 ? 2 : 4);
+    };
+    const int64_t xb = span(d->x), db = span(d->dy);
+    if (xb >= 0x7ffe0000LL || db >= 0x7ffe0000LL) return MYOLO_EINVAL;          // 32-bit buffer offsets
+    k.x_bytes = (int)xb; k.d_bytes = (int)db;
+    auto pdense = [](const myolo_tensor& t) { return t.sh == (int64_t)t.w * t.sw && t.sn == (int64_t)t.h * t.sh; };
+    k.dense = d->ntaps == 1 && d->stride == 1 && d->up_shift == 0 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 &&
+              d->x.h == d->dy.h && d->x.w == d->dy.w && pdense(d->x) && pdense(d->dy);
+  }
   k.cout_w = d->cout > 0 ? d->cout : k.Cout;
   k.cin_w = d->cin > 0 ? d->cin : k.Cin;
   if (k.cout_w > k.Cout || k.cin_w > k.Cin) return MYOLO_EINVAL;
