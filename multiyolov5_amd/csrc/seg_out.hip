@@ -153,91 +153,113 @@ __global__ __launch_bounds__(STRIP) void seg_up_fwd_cl_kernel(myolo_tensor low, 
   strip_store(out + (((int64_t)n * H + y) * W + x0) * C, buf, npix * C);
 }
 
-// transpose of the above for one low-res row segment of LXP pixels: the workgroup streams the hi-res rows of the footprint
-// through LDS (16-byte loads) while each thread accumulates its (low x, class) pairs.
+// transpose of the above for RLOW low-res rows x one segment of LXP low-res pixels.  Separable: (1) every thread owns up
+// to 24 elements of the hi-res strip and streams the rows of the footprint straight from HBM into fp32 registers,
+// weighting each row into the (at most two) low rows it touches -- no LDS, no barrier, next row in flight; (2) the
+// column sums go to LDS once and each (low x, class) pair folds its x footprint.
 constexpr int LXP = 32;
+constexpr int RLOW = 2;
+constexpr int UPB_ELEMS = 24;                    // strip elements per thread
 template <typename T>
 __global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, int W, myolo_tensor glow, float sy, float sx,
-                                                            int acc, int xalign) {
+                                                            int acc, int xalign, int lds_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* buf = reinterpret_cast<T*>(smem_raw);
+  float* fbuf = reinterpret_cast<float*>(smem_raw);            // [RLOW][lds_stride]
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int PRE = UPB_ELEMS / VEC;
   const int C = glow.c;
   const int segs = (glow.w + LXP - 1) / LXP;
+  const int rgroups = (glow.h + RLOW - 1) / RLOW;
   int b = blockIdx.x;
   const int xsg = b % segs; b /= segs;
-  const int iy = b % glow.h; const int n = b / glow.h;
+  const int iy0 = (b % rgroups) * RLOW; const int n = b / rgroups;
+  const int nr = glow.h - iy0 < RLOW ? glow.h - iy0 : RLOW;
   const int lx0 = xsg * LXP;
   const int nlx = glow.w - lx0 < LXP ? glow.w - lx0 : LXP;
   int ylo, yhi, xlo, xhi, t0, t1;
-  out_range(iy, glow.h, H, sy, ylo, yhi);
+  out_range(iy0, glow.h, H, sy, ylo, t0);
+  out_range(iy0 + nr - 1, glow.h, H, sy, t1, yhi);
   out_range(lx0, glow.w, W, sx, xlo, t0);
   out_range(lx0 + nlx - 1, glow.w, W, sx, t1, xhi);
   xlo = xlo / xalign * xalign;
   const int npix = xhi - xlo + 1;
-  constexpr int MAXP = 3;                       // (lx, c) pairs per thread: LXP*MAXC/256 = 4 > 32*19/256 = 2.4
-  constexpr int MAXF = 20;                      // x footprint of one low-res pixel (2*scale + slack) -- host checks scale <= 8
-  float a[MAXP + 1];
-  float wxs[MAXP + 1][MAXF];                    // bilinear x weights of each pair's footprint, computed once (not per row)
-  int pbase[MAXP + 1], pcnt[MAXP + 1];          // LDS element offset of the footprint's first pixel (+c), footprint length
-  const int npairs = nlx * C;
+  const int nvec = (npix * C + VEC - 1) / VEC;               // rows are whole vectors, so the round-up stays inside the row
+  float av[RLOW][UPB_ELEMS];
 #pragma unroll
-  for (int q = 0; q <= MAXP; ++q) {
-    a[q] = 0.f; pbase[q] = 0; pcnt[q] = 0;
+  for (int r = 0; r < RLOW; ++r)
 #pragma unroll
-    for (int f = 0; f < MAXF; ++f) wxs[q][f] = 0.f;
-    const int p = threadIdx.x + q * 256;
-    if (p < npairs) {
-      const int li = p / C, c = p - li * C;
-      const int ix = lx0 + li;
-      int pxlo, pxhi;
-      out_range(ix, glow.w, W, sx, pxlo, pxhi);
-      if (pxhi - pxlo + 1 > MAXF) pxhi = pxlo + MAXF - 1;
-      pbase[q] = (pxlo - xlo) * C + c;
-      pcnt[q] = pxhi - pxlo + 1;
+    for (int e = 0; e < UPB_ELEMS; ++e) av[r][e] = 0.f;
+  const int64_t rowstride = (int64_t)W * C;
+  const T* base = g + ((int64_t)n * H * W + xlo) * C;
+  int vidx[PRE];
 #pragma unroll
-      for (int f = 0; f < MAXF; ++f) {
-        const int ox = pxlo + f;
-        if (ox <= pxhi) {
-          const float fx = sx * (float)ox; const int x0 = (int)fx; const int x1 = x0 + 1 < glow.w ? x0 + 1 : glow.w - 1;
-          const float lx = fx - (float)x0;
-          float wx = 0.f;
-          if (x0 == ix) wx += 1.f - lx;
-          if (x1 == ix) wx += lx;
-          wxs[q][f] = wx;
+  for (int k = 0; k < PRE; ++k) { const int v = threadIdx.x + k * 256; vidx[k] = v < nvec ? v : nvec - 1; }   // clamped: loads stay unconditional
+  uint4 cur[PRE], nxt[PRE];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) cur[k] = ldg16(reinterpret_cast<const uint4*>(base + (int64_t)ylo * rowstride) + vidx[k]);
+  for (int oy = ylo; oy <= yhi; ++oy) {
+    const int on = oy + 1 <= yhi ? oy + 1 : yhi;
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) nxt[k] = ldg16(reinterpret_cast<const uint4*>(base + (int64_t)on * rowstride) + vidx[k]);
+    const float fy = sy * (float)oy; const int y0 = (int)fy; const int y1 = y0 + 1 < glow.h ? y0 + 1 : glow.h - 1;
+    const float ly = fy - (float)y0;
+#pragma unroll
+    for (int r = 0; r < RLOW; ++r) {
+      float wy = 0.f;
+      if (y0 == iy0 + r) wy += 1.f - ly;
+      if (y1 == iy0 + r) wy += ly;
+      if (wy != 0.f) {                              // uniform over the workgroup
+#pragma unroll
+        for (int k = 0; k < PRE; ++k) {
+          const T* e = reinterpret_cast<const T*>(&cur[k]);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) av[r][k * VEC + j] += wy * (float)e[j];
         }
       }
     }
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) cur[k] = nxt[k];
   }
-  for (int oy = ylo; oy <= yhi; ++oy) {
-    const float fy = sy * (float)oy; const int y0 = (int)fy; const int y1 = y0 + 1 < glow.h ? y0 + 1 : glow.h - 1;
-    const float ly = fy - (float)y0;
-    float wy = 0.f;
-    if (y0 == iy) wy += 1.f - ly;
-    if (y1 == iy) wy += ly;
-    if (wy == 0.f) continue;                     // uniform over the workgroup
-    __syncthreads();
-    strip_load(g + (((int64_t)n * H + oy) * W + xlo) * C, buf, npix * C);
-    __syncthreads();
 #pragma unroll
-    for (int q = 0; q <= MAXP; ++q) {
-      if (pcnt[q] == 0) continue;
-      float s = 0.f;
-      const T* bp = buf + pbase[q];
+  for (int r = 0; r < RLOW; ++r)
 #pragma unroll
-      for (int f = 0; f < MAXF; ++f)
-        if (f < pcnt[q]) s += wxs[q][f] * (float)bp[f * C];
-      a[q] += wy * s;
+    for (int k = 0; k < PRE; ++k) {
+      const int v = threadIdx.x + k * 256;
+      if (v < nvec) {
+        float4* d = reinterpret_cast<float4*>(fbuf + (size_t)r * lds_stride + (size_t)v * VEC);
+#pragma unroll
+        for (int j = 0; j < VEC / 4; ++j)
+          d[j] = float4{av[r][k * VEC + j * 4], av[r][k * VEC + j * 4 + 1], av[r][k * VEC + j * 4 + 2], av[r][k * VEC + j * 4 + 3]};
+      }
     }
-  }
-#pragma unroll
-  for (int q = 0; q <= MAXP; ++q) {
-    const int p = threadIdx.x + q * 256;
-    if (p >= npairs) break;
+  __syncthreads();
+  const int npairs = nlx * C;
+  for (int p = threadIdx.x; p < npairs; p += 256) {
     const int li = p / C, c = p - li * C;
-    T* o = reinterpret_cast<T*>(glow.ptr) + (int64_t)n * glow.sn + (int64_t)iy * glow.sh + (int64_t)(lx0 + li) * glow.sw + c;
-    float v = a[q];
-    if (acc) v += (float)*o;
-    *o = (T)v;
+    const int ix = lx0 + li;
+    int pxlo, pxhi;
+    out_range(ix, glow.w, W, sx, pxlo, pxhi);
+    float s[RLOW];
+#pragma unroll
+    for (int r = 0; r < RLOW; ++r) s[r] = 0.f;
+    const float* bp = fbuf + (pxlo - xlo) * C + c;
+    for (int ox = pxlo; ox <= pxhi; ++ox, bp += C) {
+      const float fx = sx * (float)ox; const int x0 = (int)fx; const int x1 = x0 + 1 < glow.w ? x0 + 1 : glow.w - 1;
+      const float lx = fx - (float)x0;
+      float wx = 0.f;
+      if (x0 == ix) wx += 1.f - lx;
+      if (x1 == ix) wx += lx;
+#pragma unroll
+      for (int r = 0; r < RLOW; ++r) s[r] += wx * bp[(size_t)r * lds_stride];
+    }
+#pragma unroll
+    for (int r = 0; r < RLOW; ++r) {
+      if (r >= nr) break;
+      T* o = reinterpret_cast<T*>(glow.ptr) + (int64_t)n * glow.sn + (int64_t)(iy0 + r) * glow.sh + (int64_t)ix * glow.sw + c;
+      float v = s[r];
+      if (acc) v += (float)*o;
+      *o = (T)v;
+    }
   }
 }
 
@@ -348,13 +370,15 @@ extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, 
     const int xalign = 16 / gcd;                                   // pixels per 16-byte boundary of the row
     const int scale_x = (W + glow->w - 1) / glow->w;
     const int maxpix = (LXP + 3) * scale_x + xalign + 8;
-    const int smem = (maxpix * glow->c * es + 15) / 16 * 16;
-    const int64_t blocks = (int64_t)glow->n * glow->h * ((glow->w + LXP - 1) / LXP);
-    if (smem <= 64 * 1024) {
+    const int vec = 16 / es;
+    const int lds_stride = (maxpix * glow->c + vec - 1) / vec * vec;
+    const int smem = RLOW * lds_stride * (int)sizeof(float);
+    const int64_t blocks = (int64_t)glow->n * ((glow->h + RLOW - 1) / RLOW) * ((glow->w + LXP - 1) / LXP);
+    if (smem <= 64 * 1024 && lds_stride <= 256 * UPB_ELEMS) {
       if (g_dtype == MYOLO_F16)
-        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<half_t>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const half_t*)g, H, W, *glow, sy, sx, accumulate, xalign);
+        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<half_t>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const half_t*)g, H, W, *glow, sy, sx, accumulate, xalign, lds_stride);
       else
-        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<float>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const float*)g, H, W, *glow, sy, sx, accumulate, xalign);
+        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<float>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const float*)g, H, W, *glow, sy, sx, accumulate, xalign, lds_stride);
       MYOLO_CHECK_LAUNCH();
       return 0;
     }
