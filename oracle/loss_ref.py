@@ -43,12 +43,12 @@ def build_targets(p, targets, anchors, anchor_t=4.0):
     row order (offset-major, then anchor, then target) -- that order decides the duplicate-cell winner."""
     na, nt = anchors.shape[1], targets.shape[0]
     out = []
-    off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=torch.float32) * 0.5
-    ai = torch.arange(na, dtype=torch.float32).view(na, 1).repeat(1, nt)
+    off = torch.tensor([[0, 0], [1, 0], [0, 1], [-1, 0], [0, -1]], dtype=torch.float32, device=targets.device) * 0.5
+    ai = torch.arange(na, dtype=torch.float32, device=targets.device).view(na, 1).repeat(1, nt)
     t7 = torch.cat((targets.repeat(na, 1, 1), ai[:, :, None]), 2)          # [na, nt, 7]
     for i, pi in enumerate(p):
         ny, nx = pi.shape[2], pi.shape[3]
-        gain = torch.tensor([1, 1, nx, ny, nx, ny, 1], dtype=torch.float32)
+        gain = torch.tensor([1, 1, nx, ny, nx, ny, 1], dtype=torch.float32, device=targets.device)
         t = t7 * gain
         if nt:
             r = t[:, :, 4:6] / anchors[i][:, None]
@@ -80,7 +80,8 @@ def compute_loss(p, targets, anchors, hyp, gr=1.0, balance=(4.0, 1.0, 0.4)):
     Returns (loss*bs, [lbox,lobj,lcls,loss])."""
     nc = p[0].shape[-1] - 5
     cp, cn = 1.0 - 0.5 * hyp.get('label_smoothing', 0.0), 0.5 * hyp.get('label_smoothing', 0.0)
-    lcls, lbox, lobj = torch.zeros(1), torch.zeros(1), torch.zeros(1)
+    dev = targets.device
+    lcls, lbox, lobj = torch.zeros(1, device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev)
     tg = build_targets(p, targets, anchors, hyp['anchor_t'])
     for i, pi in enumerate(p):
         b, a, gj, gi, tbox, anch, tcls = tg[i]
@@ -97,7 +98,7 @@ def compute_loss(p, targets, anchors, hyp, gr=1.0, balance=(4.0, 1.0, 0.4)):
             # oracle stays deterministic when torch parallelises large scatters.
             val = (1.0 - gr) + gr * iou.detach().clamp(0).type(tobj.dtype)
             lin = ((b * pi.shape[1] + a) * pi.shape[2] + gj) * pi.shape[3] + gi
-            win = torch.full((tobj.numel(),), -1, dtype=torch.long).scatter_reduce(0, lin, torch.arange(n), 'amax')
+            win = torch.full((tobj.numel(),), -1, dtype=torch.long, device=dev).scatter_reduce(0, lin, torch.arange(n, device=dev), 'amax')
             rows = win[win >= 0]
             tobj.view(-1)[lin[rows]] = val[rows]
             if nc > 1:

@@ -212,7 +212,7 @@ def detect(ctx, p, xs, nc, stride):  # yolo.py:206-230
         y = y.view(bs, na, no, ny, nx).permute(0, 1, 3, 4, 2).contiguous()
         raw.append(y)
         if not ctx.training:
-            gy, gx = torch.meshgrid(torch.arange(ny), torch.arange(nx), indexing='ij')
+            gy, gx = torch.meshgrid(torch.arange(ny, device=y.device), torch.arange(nx, device=y.device), indexing='ij')
             grid = torch.stack((gx, gy), 2).view(1, 1, ny, nx, 2).to(y.dtype)
             s = y.sigmoid()
             xy = (s[..., 0:2] * 2. - 0.5 + grid) * stride[i]
