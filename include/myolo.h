@@ -178,11 +178,12 @@ int myolo_dropout_bwd(const myolo_tensor* gout, const uint8_t* mask, const myolo
 
 /* ---- head outputs ------------------------------------------------------------------------------ */
 /* final nn.Upsample(x8, bilinear, align_corners=True) of the class logits (yolo.py:67,118,143,163) into a
- * [N,C,H,W]-logical tensor with arbitrary element strides (sn,sc,sh,sw); bwd is its transpose. */
+ * [N,C,H,W]-logical tensor with arbitrary element strides (sn,sc,sh,sw); bwd is its transpose.
+ * scale (optional, device float[1]): the incoming gradient is g * scale[0] (see myolo_seg_ce_fwd_grad). */
 int myolo_seg_upsample_fwd(const myolo_tensor* low, void* out, int out_dtype, int H, int W,
                            int64_t sn, int64_t sc, int64_t sh, int64_t sw, void* stream);
 int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw,
-                           const myolo_tensor* glow, int accumulate, void* stream);
+                           const myolo_tensor* glow, int accumulate, const float* scale, void* stream);
 /* detect.py:191-193 fused: bilinear resize of the logits to (H,W) + argmax over classes -> labels [N,H,W] (u8|i64) */
 int myolo_seg_argmax(const myolo_tensor* low, void* labels, int label_dtype, int H, int W, void* stream);
 /* seg_validation counters (utils/metrics.py:234-275 batch_pix_accuracy + batch_intersection_union, test.py:31-65) from predicted
@@ -205,6 +206,14 @@ int myolo_detect_decode(const void* raw, int dtype, int n, int na, int ny, int n
 int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
                      int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
                      void* stream);
+/* myolo_seg_ce_fwd fused with the backward of the plain mean-CE case, for dense channels-last logits ([N,H,W,C] storage, 16-byte
+ * aligned; anything else is MYOLO_EINVAL): additionally writes grad (same layout/dtype) = softmax - onehot, 0 on ignored
+ * pixels, i.e. d(loss)/d(logits) up to the scalar gout/acc[1], which exists only after the reduction over all pixels.
+ * myolo_seg_ce_scale computes that scalar on device (scale[0] = gout[0]/acc[1]) for the gradient's consumer
+ * (myolo_seg_upsample_bwd `scale`): the logits are read once per step instead of twice and no rescaling pass is needed. */
+int myolo_seg_ce_fwd_grad(const void* logits, void* grad, int dtype, int n, int c, int h, int w, const int64_t* target,
+                          int ignore_index, double* acc, float* loss, void* stream);
+int myolo_seg_ce_scale(const double* acc, const float* gout, float* scale, void* stream);
 /* OhemCELoss.forward_once (utils/loss.py:321-328) on the per-pixel losses: mean of losses > thresh, or, if fewer than
  * n_min = acc[1]//16 qualify, mean of the n_min largest (device radix select, no host sync).
  * st: double[5] scratch, ws: uint32[2052] scratch, loss: float[1], sel: float[4] selection record for the backward. */

@@ -88,7 +88,9 @@ _PROTOS = {
     'myolo_dropout_fwd': (C.c_int, [TP, TP, P, C.c_float, P, P]),
     'myolo_dropout_bwd': (C.c_int, [TP, P, TP, C.c_float, C.c_int, P]),
     'myolo_seg_upsample_fwd': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, P]),
-    'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P]),
+    'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P, P]),
+    'myolo_seg_ce_fwd_grad': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
+    'myolo_seg_ce_scale': (C.c_int, [P, P, P, P]),
     'myolo_seg_argmax': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, P]),
     'myolo_seg_metrics': (C.c_int, [P, C.c_int, P, C.c_int64, C.c_int, P, P]),
     'myolo_detect_unpermute': (C.c_int, [P, C.c_int, C.c_int, C.c_int, TP, P]),
@@ -123,6 +125,9 @@ def lib():
             f.restype, f.argtypes = res, args
         _lib = l
     return _lib
+
+
+EINVAL = -22
 
 
 def check(err, what=''):

@@ -7,6 +7,9 @@
 //                             scatter with the CPU's "last write wins" order, BCE obj / cls, and all gradients -- no host
 //                             sync, no boolean-mask indexing.
 #include "myolo_dev.h"
+#include <map>
+#include <mutex>
+#include <utility>
 
 namespace {
 
@@ -191,44 +194,103 @@ __global__ void ce_final_kernel(const double* acc, float* loss) { loss[0] = (flo
 // ---- fast paths: dense channels-last logits ([N,H,W,C] contiguous, the layout Model.forward hands out).  A workgroup owns a
 // strip of 256 consecutive pixels = 256*C contiguous elements, moved with 16-byte accesses through LDS. -------------------
 constexpr int STRIP = 256;
-template <typename T>
-__global__ __launch_bounds__(STRIP) void seg_ce_fwd_cl_kernel(const T* x, const int64_t* tgt, int C, int64_t total, int ignore,
+// softmax pieces of one pixel row with the hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the libm expf costs ~3x the
+// issue slots and these kernels sit at the VALU/HBM balance point (19 exps per 38 bytes)
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+
+// GRAD: also leaves softmax - onehot (0 on ignored pixels) in `g` -- d(loss)/d(logits) up to the scalar gout/n_valid that
+// only exists once the whole image set is reduced; the consumer applies it (myolo_seg_ce_scale + myolo_seg_upsample_bwd).
+// The next strip (logits as 16-byte vectors + its target) is fetched into registers while the current one is reduced.
+// CC: class count known at compile time (19 = Cityscapes, the reference's only use) -> branch-free unrolled rows; 0 = runtime C
+template <typename T, bool GRAD, int CC>
+__global__ __launch_bounds__(STRIP) void seg_ce_fwd_cl_kernel(const T* x, T* g, const int64_t* tgt, int Crt, int64_t total, int ignore,
                                                               double* acc, float* pix) {
+  const int C = CC ? CC : Crt;
+  constexpr int CMAX = CC ? CC : MAXC;
   __shared__ __attribute__((aligned(16))) T buf[STRIP * MAXC];
   __shared__ double sh[4];
+  constexpr int V = 16 / (int)sizeof(T);
+  constexpr int PRE = STRIP * MAXC / V / STRIP;            // 16-byte vectors per thread per full strip, upper bound
+  const int nvec = STRIP * C / V;                           // dense_cl(): a full strip is a whole number of vectors
   double lsum = 0.0, lcnt = 0.0;
   const int64_t nstrips = (total + STRIP - 1) / STRIP;
-  for (int64_t sidx = blockIdx.x; sidx < nstrips; sidx += gridDim.x) {
+  uint4 pre[PRE];
+  int64_t tpre = ignore;
+  auto fetch = [&](int64_t sidx) {
+    const uint4* src = reinterpret_cast<const uint4*>(x + sidx * STRIP * C);
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const int v = threadIdx.x + k * STRIP;
+      if (k * STRIP < nvec) pre[k] = ldg16(src + (v < nvec ? v : nvec - 1));     // clamped: the loads stay unconditional
+    }
+    tpre = tgt[sidx * STRIP + threadIdx.x];
+  };
+  int64_t sidx = blockIdx.x;
+  bool have = sidx < nstrips && (sidx + 1) * STRIP <= total;
+  if (have) fetch(sidx);
+  for (; sidx < nstrips; sidx += gridDim.x) {
     const int64_t p0 = sidx * STRIP;
     const int npix = total - p0 < STRIP ? (int)(total - p0) : STRIP;
+    int64_t t = ignore;
     __syncthreads();
-    strip_load(x + p0 * C, buf, npix * C);
+    if (have) {
+#pragma unroll
+      for (int k = 0; k < PRE; ++k) {
+        const int v = threadIdx.x + k * STRIP;
+        if (k * STRIP < nvec && v < nvec) reinterpret_cast<uint4*>(buf)[v] = pre[k];
+      }
+      t = tpre;
+    } else {                                                // ragged last strip
+      strip_load(x + p0 * C, buf, npix * C);
+      if ((int)threadIdx.x < npix) t = tgt[p0 + threadIdx.x];
+    }
     __syncthreads();
+    const int64_t nxt = sidx + gridDim.x;
+    have = nxt < nstrips && (nxt + 1) * STRIP <= total;
+    if (have) fetch(nxt);
     if ((int)threadIdx.x < npix) {
-      const int64_t i = p0 + threadIdx.x;
-      const int64_t t = tgt[i];
+      T* row = buf + threadIdx.x * C;
       float l = 0.f;
       if (t != ignore) {
-        float v[MAXC];
+        float v[CMAX];
         float m = -INFINITY;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-          if (c < C) { v[c] = (float)buf[threadIdx.x * C + c]; m = fmaxf(m, v[c]); }
+        for (int c = 0; c < CMAX; ++c)
+          if (CC || c < C) { v[c] = (float)row[c]; m = fmaxf(m, v[c]); }
+        const float mb = -m * LOG2E;
         float sm = 0.f, xt = 0.f;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c)
-          if (c < C) { sm += expf(v[c] - m); if (c == (int)t) xt = v[c]; }
-        l = (m + logf(sm)) - xt;
+        for (int c = 0; c < CMAX; ++c)
+          if (CC || c < C) {
+            if (c == (int)t) xt = v[c];
+            v[c] = __builtin_amdgcn_exp2f(fmaf(v[c], LOG2E, mb));
+            sm += v[c];
+          }
+        l = (m + __builtin_amdgcn_logf(sm) * LN2) - xt;
         lsum += (double)l;
         lcnt += 1.0;
+        if (GRAD) {
+          const float inv = __builtin_amdgcn_rcpf(sm);
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c)
+            if (CC || c < C) row[c] = (T)(v[c] * inv - (c == (int)t ? 1.f : 0.f));
+        }
+      } else if (GRAD) {
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) if (CC || c < C) row[c] = (T)0.f;
       }
-      if (pix) pix[i] = l;
+      if (pix) pix[p0 + threadIdx.x] = l;
+    }
+    if (GRAD) {
+      __syncthreads();
+      strip_store(g + p0 * C, buf, npix * C);
     }
   }
   const double bs = block_sum256(lsum, sh);
   const double bc = block_sum256(lcnt, sh);
   if (threadIdx.x == 0) { atomicAdd(acc + 0, bs); atomicAdd(acc + 1, bc); }
 }
+__global__ void ce_scale_kernel(const double* acc, const float* gout, float* scale) { scale[0] = (float)((double)gout[0] / acc[1]); }
 
 template <typename T>
 __global__ __launch_bounds__(STRIP) void seg_ce_bwd_cl_kernel(const T* x, T* g, const int64_t* tgt, int C, int64_t total,
@@ -265,9 +327,10 @@ __global__ __launch_bounds__(STRIP) void seg_ce_bwd_cl_kernel(const T* x, T* g, 
         for (int c = 0; c < MAXC; ++c)
           if (c < C) { v[c] = (float)row[c]; m = fmaxf(m, v[c]); }
         float sm = 0.f;
+        const float mb = -m * LOG2E;
 #pragma unroll
-        for (int c = 0; c < MAXC; ++c) if (c < C) { v[c] = expf(v[c] - m); sm += v[c]; }
-        const float inv = 1.f / sm;
+        for (int c = 0; c < MAXC; ++c) if (c < C) { v[c] = __builtin_amdgcn_exp2f(fmaf(v[c], LOG2E, mb)); sm += v[c]; }
+        const float inv = __builtin_amdgcn_rcpf(sm);
 #pragma unroll
         for (int c = 0; c < MAXC; ++c)
           if (c < C) row[c] = (T)((v[c] * inv - (c == (int)t ? 1.f : 0.f)) * w);
@@ -276,6 +339,28 @@ __global__ __launch_bounds__(STRIP) void seg_ce_bwd_cl_kernel(const T* x, T* g, 
     __syncthreads();
     strip_store(g + p0 * C, buf, npix * C);
   }
+}
+
+// grid of a persistent strip loop: exactly the number of workgroups the device holds at once (no partial last wave of blocks)
+inline int persistent_grid(const void* kern, int threads, int64_t work) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> cache;       // (device, kernel) -> resident workgroups
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  int64_t g;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find({dev, kern});
+    if (it == cache.end()) {
+      int per_cu = 0, cus = 256;
+      (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+      it = cache.emplace(std::make_pair(dev, kern), cus * per_cu).first;
+    }
+    g = it->second;
+  }
+  if (g > work) g = work;
+  return g < 1 ? 1 : (int)g;
 }
 
 inline bool dense_cl(const void* p, int dt, int C, int H, int W, int64_t sn, int64_t sc, int64_t sh, int64_t sw) {
@@ -288,21 +373,31 @@ inline bool strided_ok(const void* p, int dt) { return p && (dt == MYOLO_F16 || 
 
 }  // namespace
 
-extern "C" int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
-                                int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
-                                void* stream) {
+static int seg_ce_fwd_impl(const void* logits, void* grad, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                           int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
+                           void* stream) {
   if (!strided_ok(logits, dtype) || !target || !acc || c < 1 || c > MAXC || n < 1 || h < 1 || w < 1) return MYOLO_EINVAL;
+  const bool dense = dense_cl(logits, dtype, c, h, w, sn, sc, sh, sw);
+  if (grad && (!dense || ((uintptr_t)grad & 15))) return MYOLO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
   if (e != hipSuccess) return (int)e;
   const int64_t total = (int64_t)n * h * w;
   Strided4 x{const_cast<void*>(logits), sn, sc, sh, sw, dtype};
-  if (dense_cl(logits, dtype, c, h, w, sn, sc, sh, sw)) {          // all pixels of all images are one contiguous [P][C] array
-    const int grid = grid_for(total, STRIP, 4096);
-    if (dtype == MYOLO_F16)
-      hipLaunchKernelGGL(seg_ce_fwd_cl_kernel<half_t>, dim3(grid), dim3(STRIP), 0, st, (const half_t*)logits, target, c, total, ignore_index, acc, pix);
-    else
-      hipLaunchKernelGGL(seg_ce_fwd_cl_kernel<float>, dim3(grid), dim3(STRIP), 0, st, (const float*)logits, target, c, total, ignore_index, acc, pix);
+  if (dense) {                                                     // all pixels of all images are one contiguous [P][C] array
+    auto launch = [&](auto kern, auto* xp, auto* gp) {
+      const int grid = persistent_grid(reinterpret_cast<const void*>(kern), STRIP, (total + STRIP - 1) / STRIP);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(STRIP), 0, st, xp, gp, target, c, total, ignore_index, acc, pix);
+    };
+    if (dtype == MYOLO_F16) {
+      const half_t* xp = (const half_t*)logits; half_t* gp = (half_t*)grad;
+      if (c == 19) { if (grad) launch(seg_ce_fwd_cl_kernel<half_t, true, 19>, xp, gp); else launch(seg_ce_fwd_cl_kernel<half_t, false, 19>, xp, gp); }
+      else { if (grad) launch(seg_ce_fwd_cl_kernel<half_t, true, 0>, xp, gp); else launch(seg_ce_fwd_cl_kernel<half_t, false, 0>, xp, gp); }
+    } else {
+      const float* xp = (const float*)logits; float* gp = (float*)grad;
+      if (c == 19) { if (grad) launch(seg_ce_fwd_cl_kernel<float, true, 19>, xp, gp); else launch(seg_ce_fwd_cl_kernel<float, false, 19>, xp, gp); }
+      else { if (grad) launch(seg_ce_fwd_cl_kernel<float, true, 0>, xp, gp); else launch(seg_ce_fwd_cl_kernel<float, false, 0>, xp, gp); }
+    }
   } else {
     hipLaunchKernelGGL(seg_ce_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, x, target, c, h, w, total,
                        ignore_index, acc, pix);
@@ -312,6 +407,23 @@ extern "C" int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int
     hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, st, acc, loss);
     MYOLO_CHECK_LAUNCH();
   }
+  return 0;
+}
+extern "C" int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
+                                int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
+                                void* stream) {
+  return seg_ce_fwd_impl(logits, nullptr, dtype, n, c, h, w, sn, sc, sh, sw, target, ignore_index, acc, pix, loss, stream);
+}
+extern "C" int myolo_seg_ce_fwd_grad(const void* logits, void* grad, int dtype, int n, int c, int h, int w,
+                                     const int64_t* target, int ignore_index, double* acc, float* loss, void* stream) {
+  if (!grad) return MYOLO_EINVAL;
+  return seg_ce_fwd_impl(logits, grad, dtype, n, c, h, w, (int64_t)h * w * c, 1, (int64_t)w * c, c, target, ignore_index, acc,
+                         nullptr, loss, stream);
+}
+extern "C" int myolo_seg_ce_scale(const double* acc, const float* gout, float* scale, void* stream) {
+  if (!acc || !gout || !scale) return MYOLO_EINVAL;
+  hipLaunchKernelGGL(ce_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, acc, gout, scale);
+  MYOLO_CHECK_LAUNCH();
   return 0;
 }
 

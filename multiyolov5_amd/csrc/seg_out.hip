@@ -85,8 +85,9 @@ __device__ __forceinline__ void out_range(int i, int in, int out, float s, int& 
 
 // one thread per (n, iy, ix, c) of the low-res gradient
 __global__ __launch_bounds__(256) void seg_up_bwd_kernel(Strided4 g, int H, int W, myolo_tensor glow, float sy, float sx,
-                                                         int acc) {
+                                                         int acc, const float* scale) {
   const int C = glow.c;
+  const float gs = scale ? scale[0] : 1.f;
   const int64_t total = (int64_t)glow.n * glow.h * glow.w * C;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = i;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void seg_up_bwd_kernel(Strided4 g, int H, int 
       }
     }
     const int64_t o = (int64_t)n * glow.sn + (int64_t)iy * glow.sh + (int64_t)ix * glow.sw + c;
+    a *= gs;
     if (acc) a += ld_any(glow.ptr, o, glow.dtype);
     st_any(glow.ptr, o, glow.dtype, a);
   }
@@ -162,7 +164,7 @@ constexpr int RLOW = 2;
 constexpr int UPB_ELEMS = 24;                    // strip elements per thread
 template <typename T>
 __global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, int W, myolo_tensor glow, float sy, float sx,
-                                                            int acc, int xalign, int lds_stride) {
+                                                            int acc, int xalign, int lds_stride, const float* scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* fbuf = reinterpret_cast<float*>(smem_raw);            // [RLOW][lds_stride]
   constexpr int VEC = 16 / (int)sizeof(T);
@@ -233,6 +235,7 @@ __global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, i
       }
     }
   __syncthreads();
+  const float gs = scale ? scale[0] : 1.f;
   const int npairs = nlx * C;
   for (int p = threadIdx.x; p < npairs; p += 256) {
     const int li = p / C, c = p - li * C;
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void seg_up_bwd_cl_kernel(const T* g, int H, i
     for (int r = 0; r < RLOW; ++r) {
       if (r >= nr) break;
       T* o = reinterpret_cast<T*>(glow.ptr) + (int64_t)n * glow.sn + (int64_t)(iy0 + r) * glow.sh + (int64_t)ix * glow.sw + c;
-      float v = s[r];
+      float v = s[r] * gs;
       if (acc) v += (float)*o;
       *o = (T)v;
     }
@@ -358,7 +361,7 @@ extern "C" int myolo_seg_upsample_fwd(const myolo_tensor* low, void* out, int ou
   return 0;
 }
 extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, int64_t sn, int64_t sc, int64_t sh,
-                                      int64_t sw, const myolo_tensor* glow, int accumulate, void* stream) {
+                                      int64_t sw, const myolo_tensor* glow, int accumulate, const float* scale, void* stream) {
   if (!glow || !glow->ptr || !g) return MYOLO_EINVAL;
   Strided4 gg{const_cast<void*>(g), sn, sc, sh, sw, g_dtype};
   const float sy = H > 1 ? (float)(glow->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(glow->w - 1) / (float)(W - 1) : 0.f;
@@ -376,15 +379,15 @@ extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, 
     const int64_t blocks = (int64_t)glow->n * ((glow->h + RLOW - 1) / RLOW) * ((glow->w + LXP - 1) / LXP);
     if (smem <= 64 * 1024 && lds_stride <= 256 * UPB_ELEMS) {
       if (g_dtype == MYOLO_F16)
-        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<half_t>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const half_t*)g, H, W, *glow, sy, sx, accumulate, xalign, lds_stride);
+        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<half_t>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const half_t*)g, H, W, *glow, sy, sx, accumulate, xalign, lds_stride, scale);
       else
-        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<float>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const float*)g, H, W, *glow, sy, sx, accumulate, xalign, lds_stride);
+        hipLaunchKernelGGL(seg_up_bwd_cl_kernel<float>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, (const float*)g, H, W, *glow, sy, sx, accumulate, xalign, lds_stride, scale);
       MYOLO_CHECK_LAUNCH();
       return 0;
     }
   }
   hipLaunchKernelGGL(seg_up_bwd_kernel, dim3(grid_for((int64_t)glow->n * glow->h * glow->w * glow->c, 256, 8192)), dim3(256),
-                     0, (hipStream_t)stream, gg, H, W, *glow, sy, sx, accumulate);
+                     0, (hipStream_t)stream, gg, H, W, *glow, sy, sx, accumulate, scale);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

@@ -180,7 +180,7 @@ class ImportOp(Op):
         sn, sc, sh, sw = meta['stride']
         self.d = self.out.desc()
         self.fwd_calls.append(Call('myolo_seg_upsample_bwd', (plan.in_ptr[self.slot], L.DT[meta['dtype']], h, w, sn, sc, sh, sw,
-                                                              C.byref(self.d), 0)))
+                                                              C.byref(self.d), 0, None)))
         if plan.training and self.out.requires_grad:
             g = torch.empty(n, c, h, w, dtype=meta['dtype'], device=plan.device)
             plan.input_grads[self.slot] = g
@@ -585,9 +585,15 @@ class SegOutOp(Op):
             g = torch.zeros_like(store).permute(0, 3, 1, 2)
             plan.output_grads[self.slot] = g
             out._myolo_grad_buf = g                     # utils.loss writes d(loss)/d(logits) straight into the plan's buffer
+            # device scalar the incoming gradient is multiplied by (1 unless the fused CE left an unnormalised gradient in g;
+            # 'fresh' = set by this step's loss backward, 'dirty' = still holds an old factor) -- see runtime.PlanFn.backward
+            self.gscale = torch.ones(1, dtype=torch.float32, device=plan.device)
+            self.gstate = {'fresh': False, 'dirty': False}
+            out._myolo_grad_scale = (self.gscale, self.gstate)
+            plan.output_scales[self.slot] = (self.gscale, self.gstate)
             self.gld = lw.desc(grad=True)
             self.bwd_calls.append(Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], H, W, *g.stride(), C.byref(self.gld),
-                                                                  self.acc), keep=g))
+                                                                  self.acc, L.ptr(self.gscale)), keep=(g, self.gscale)))
 
 
 class ExportOp(Op):
@@ -614,7 +620,7 @@ class ExportOp(Op):
             plan.output_grads[self.slot] = g
             self.gsd = s.desc(grad=True)
             self.bwd_calls.append(Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], s.h, s.w, *g.stride(), C.byref(self.gsd),
-                                                                  self.acc), keep=g))
+                                                                  self.acc, None), keep=g))
 
 
 class Plan:
@@ -625,6 +631,7 @@ class Plan:
         self.ops, self.bufs, self.tvs = [], [], []
         self.in_meta, self.in_ptr = [], []          # per input slot: {'shape','stride','dtype'} / ctypes pointer cell
         self.input_grads, self.outputs, self.output_grads = {}, {}, {}
+        self.output_scales = {}                     # output slot -> (device scalar, state) of SegOutOp's gradient factor
         self.det_grads = []
         self.params, self._pgrad = [], {}
         self._pack_jobs, self._pack_call = [], None

@@ -91,7 +91,7 @@ class PlanFn(torch.autograd.Function):
         outs = []
         for o in holder.output_tensors():
             d = o.detach()
-            for attr in ('_myolo_low', '_myolo_grad_buf'):          # side channels of the fused loss / argmax kernels
+            for attr in ('_myolo_low', '_myolo_grad_buf', '_myolo_grad_scale'):          # side channels of the fused loss / argmax kernels
                 if hasattr(o, attr):
                     setattr(d, attr, getattr(o, attr))
             outs.append(d)
@@ -108,10 +108,22 @@ class PlanFn(torch.autograd.Function):
                                '(one outstanding forward per module/shape; call backward before the next forward)')
         for s, g in enumerate(grads):
             dst = holder.output_grad_tensor(s)
+            sc = plan.output_scales.get(s)
+            if sc is not None and sc[1]['fresh'] and (g is None or g.data_ptr() != dst.data_ptr()):
+                sc[1]['fresh'] = False
+                raise L.MyoloError('the segmentation logits were consumed by the fused cross-entropy AND another differentiable op: '
+                                   'their gradients cannot be combined (set MYOLO_FUSED_CE=0 for that use)')
             if g is None:
                 dst.zero_()
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                 dst.copy_(g)                              # (the fused losses already wrote into dst: nothing to move)
+            if sc is not None:                            # gradient factor published by the fused CE (utils.loss._SegCE)
+                scale, state = sc
+                if state['fresh']:
+                    state['fresh'], state['dirty'] = False, True
+                elif state['dirty']:
+                    scale.fill_(1.0)
+                    state['dirty'] = False
         plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
         holder.pending_bwd = False
         in_grads = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]

@@ -7,12 +7,17 @@ produced by the library and handed to autograd through `torch.autograd.Function`
 """
 import ctypes as C
 import math
+import os
 
 import torch
 import torch.nn as nn
 
 from .. import _lib as L
 from .torch_utils import is_parallel
+
+
+# MYOLO_FUSED_CE=0: keep the CE backward a separate pass (needed only if the logits feed another differentiable op as well)
+FUSED_CE = os.environ.get('MYOLO_FUSED_CE', '1') != '0'
 
 
 def smooth_BCE(eps=0.1):  # loss.py:11-13
@@ -49,9 +54,28 @@ class _SegCE(torch.autograd.Function):
         pix = sel = None
         if ohem_thresh is not None:
             pix = torch.empty(n * h * w, dtype=torch.float32, device=dev)
-        L.check(lib.myolo_seg_ce_fwd(L.ptr(logits), L.DT[logits.dtype], n, c, h, w, *logits.stride(), L.ptr(target),
-                                     int(ignore_index), L.ptr(acc), L.ptr(pix), None if pix is not None else L.ptr(loss), st),
-                'myolo_seg_ce_fwd')
+        # the producing plan's gradient buffer (saves a 2nd 300 MB tensor + copy); one loss per forward may claim it
+        ctx.grad_buf = None
+        if getattr(logits, '_myolo_grad_buf', None) is not None and not getattr(logits, '_myolo_grad_claimed', False):
+            ctx.grad_buf = logits._myolo_grad_buf
+            logits._myolo_grad_claimed = True
+        # plain mean CE on the plan's own channels-last logits: the forward pass also leaves softmax - onehot in the plan's
+        # gradient buffer and the backward only publishes the scalar gout/n_valid to the buffer's consumer
+        gs = getattr(logits, '_myolo_grad_scale', None)
+        ctx.fused = None
+        if (FUSED_CE and pix is None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
+                and logits.stride() == (h * w * c, 1, w * c, c) and ctx.grad_buf.stride() == logits.stride()
+                and ctx.grad_buf.dtype == logits.dtype and logits.data_ptr() % 16 == 0 and ctx.grad_buf.data_ptr() % 16 == 0):
+            rc = lib.myolo_seg_ce_fwd_grad(L.ptr(logits), L.ptr(ctx.grad_buf), L.DT[logits.dtype], n, c, h, w, L.ptr(target),
+                                           int(ignore_index), L.ptr(acc), L.ptr(loss), st)
+            if rc == 0:
+                ctx.fused = gs
+            elif rc != L.EINVAL:                      # EINVAL = layout the fused kernel does not take: unfused path below
+                L.check(rc, 'myolo_seg_ce_fwd_grad')
+        if ctx.fused is None:
+            L.check(lib.myolo_seg_ce_fwd(L.ptr(logits), L.DT[logits.dtype], n, c, h, w, *logits.stride(), L.ptr(target),
+                                         int(ignore_index), L.ptr(acc), L.ptr(pix), None if pix is not None else L.ptr(loss), st),
+                    'myolo_seg_ce_fwd')
         if pix is not None:
             sel = torch.empty(4, dtype=torch.float32, device=dev)
             scratch = torch.empty(5, dtype=torch.float64, device=dev)
@@ -60,11 +84,6 @@ class _SegCE(torch.autograd.Function):
                                           L.ptr(loss), L.ptr(sel), st), 'myolo_ohem_select')
         ctx.save_for_backward(logits, target, acc)
         ctx.pix, ctx.sel, ctx.ignore, ctx.thresh = pix, sel, int(ignore_index), ohem_thresh
-        # the producing plan's gradient buffer (saves a 2nd 300 MB tensor + copy); one loss per forward may claim it
-        ctx.grad_buf = None
-        if getattr(logits, '_myolo_grad_buf', None) is not None and not getattr(logits, '_myolo_grad_claimed', False):
-            ctx.grad_buf = logits._myolo_grad_buf
-            logits._myolo_grad_claimed = True
         return loss.view(())
 
     @staticmethod
@@ -72,6 +91,12 @@ class _SegCE(torch.autograd.Function):
         logits, target, acc = ctx.saved_tensors
         n, c, h, w = logits.shape
         grad = ctx.grad_buf
+        if ctx.fused is not None:
+            scale, state = ctx.fused
+            gout = go.detach().to(torch.float32).reshape(1).contiguous()
+            L.check(L.lib().myolo_seg_ce_scale(L.ptr(acc), L.ptr(gout), L.ptr(scale), L.stream_ptr()), 'myolo_seg_ce_scale')
+            state['fresh'] = True                   # consumed (and reset) by the plan's backward
+            return grad, None, None, None
         if grad is None or grad.shape != logits.shape or grad.stride() != logits.stride() or grad.dtype != logits.dtype:
             grad = torch.empty_strided(logits.shape, logits.stride(), dtype=logits.dtype, device=logits.device)
         gout = go.detach().to(torch.float32).reshape(1).contiguous()

@@ -39,7 +39,7 @@ for dt in (torch.float16, torch.float32):
     sn, sc, sh, sw = gv.stride()
 
     def run(desc):
-        L.check(lib.myolo_seg_upsample_bwd(L.ptr(g), L.DT[dt], H, W, sn, sc, sh, sw, C.byref(desc), 0, L.stream_ptr()), 'bwd')
+        L.check(lib.myolo_seg_upsample_bwd(L.ptr(g), L.DT[dt], H, W, sn, sc, sh, sw, C.byref(desc), 0, None, L.stream_ptr()), "bwd")
     us = timeit(lambda: run(d))
     os.environ['MYOLO_NO_FAST_UPB'] = '1'
     us2 = timeit(lambda: run(d2), iters=3)

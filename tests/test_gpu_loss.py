@@ -136,3 +136,50 @@ def test_seg_ce_aux_and_full_size_properties():
     ref_loss = torch.nn.functional.cross_entropy(x.detach().float().cpu()[:1], m.cpu()[:1], ignore_index=-1)
     l1 = SegmentationLosses()(x.detach()[:1], m[:1])
     check('segce/full_size_first_image', l1, ref_loss, 2e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+def test_fused_ce_grad_chain_vs_oracle(dtype):
+    """the training step's fused chain through the C ABI: myolo_seg_ce_fwd_grad (loss + softmax-onehot) -> myolo_seg_ce_scale
+    -> myolo_seg_upsample_bwd(scale) must give d(loss*gout)/d(low-res logits) of CE(upsample_x8(low)) (yolo.py:163 +
+    loss.py:236-237), incl. a ragged last strip (N*H*W % 256 != 0) and ignored pixels."""
+    import ctypes as C
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    N, Cc, h, w = 3, 19, 5, 7
+    H, W = h * 8, w * 8                                          # 3*40*56 = 6720 pixels = 26 strips + 64
+    gen = torch.Generator().manual_seed(5)
+    low = (torch.randn(N, Cc, h, w, generator=gen) * 2).to(dtype).float()
+    mask = synth.synth_seg_targets(N, H, W, Cc, seed=6)
+    gout = 3.5
+    lo = low.clone().requires_grad_()
+    up = torch.nn.functional.interpolate(lo, size=(H, W), mode='bilinear', align_corners=True)
+    up_q = up.to(dtype).float()                                   # the hi-res logits exist in `dtype` on the device
+    up_q = up + (up_q - up).detach()
+    ref_loss = loss_ref.seg_ce(up_q, mask)
+    (ref_loss * gout).backward()
+    # device: hi-res logits in NHWC storage, as SegOutOp hands them out
+    hi = up_q.detach().permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+    grad = torch.empty_like(hi)
+    acc = torch.empty(2, dtype=torch.float64, device=DEV)
+    loss = torch.empty(1, dtype=torch.float32, device=DEV)
+    scale = torch.ones(1, dtype=torch.float32, device=DEV)
+    go = torch.full((1,), gout, dtype=torch.float32, device=DEV)
+    st = L.stream_ptr()
+    L.check(lib.myolo_seg_ce_fwd_grad(L.ptr(hi), L.ptr(grad), L.DT[dtype], N, Cc, H, W, L.ptr(mask.to(DEV)), -1, L.ptr(acc),
+                                      L.ptr(loss), st), 'fwd_grad')
+    L.check(lib.myolo_seg_ce_scale(L.ptr(acc), L.ptr(go), L.ptr(scale), st), 'scale')
+    glow = torch.zeros(N, h, w, Cc, dtype=dtype, device=DEV)
+    d = L.Tensor(L.ptr(glow), N, h, w, Cc, h * w * Cc, w * Cc, Cc, L.DT[dtype], 0)
+    L.check(lib.myolo_seg_upsample_bwd(L.ptr(grad), L.DT[dtype], H, W, H * W * Cc, 1, W * Cc, Cc, C.byref(d), 0, L.ptr(scale), st),
+            'up_bwd')
+    check('fusedce/loss', loss, ref_loss.detach().reshape(1), 1e-5 if dtype == torch.float32 else 1e-4)
+    nvalid = int((mask != -1).sum())
+    assert float(acc[1]) == nvalid and abs(float(scale) - gout / nvalid) < 1e-6 * gout / nvalid * 10
+    # unnormalised gradient rows: softmax - onehot sums to 0 over classes, 0 on ignored pixels
+    gf = grad.float()
+    assert float(gf[(mask == -1).to(DEV)].abs().max()) == 0.0
+    check('fusedce/glow', glow.permute(0, 3, 1, 2), lo.grad, 2e-5 if dtype == torch.float32 else 4e-3)
+    # a non-dense layout is rejected (the host falls back to the two-pass path)
+    assert lib.myolo_seg_ce_fwd_grad(C.c_void_p(hi.data_ptr() + 2), L.ptr(grad), L.DT[dtype], N, Cc, H, W, L.ptr(mask.to(DEV)), -1,
+                                     L.ptr(acc), L.ptr(loss), st) == L.EINVAL
