@@ -28,11 +28,14 @@ __device__ __forceinline__ T* pptr(const myolo_tensor& t, bool dense, const PixD
   return vptr<T>(t, n, yy, xx);
 }
 
+// Thread layout shared by the three passes: a workgroup is G*PPB threads (G = C/SEG channel groups, PPB = 256/G pixels);
+// thread (cg = tid % G, pl = tid / G) always owns channel group cg, so its per-channel constants live in registers and
+// the pixel index advances by a fixed stride -- no division and no table read per 16-byte vector.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* rm, float* rv, int64_t* nbt, float* saved, float eps,
-                                                         float mom, int act, myolo_tensor res, myolo_tensor out) {
+                                                         float mom, int act, myolo_tensor res, myolo_tensor out, int G, int PPB) {
   constexpr int SEG = ET<T>::SEG;
   extern __shared__ float tab[];  // [2*C]: scale, shift
   const int C = y.c;
@@ -63,24 +66,32 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && gamma) *nbt += 1;
   __syncthreads();
-  const int G = C / SEG;
-  const int64_t total = M * G;
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  float sc[SEG], sh[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) { sc[i] = tab[cg * SEG + i]; sh[i] = tab[C + cg * SEG + i]; }
   const PixDec pd(y);
   const bool dense = pix_dense(y) && pix_dense(out) && (!res.ptr || pix_dense(res));
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = v / G;
-    const int cg = (int)(v - pix * G);
-    float f[SEG];
-    Vec<T>::unpack(ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), f);
+  const int64_t stride = (int64_t)gridDim.x * PPB;
+  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += 2 * stride) {      // two pixels in flight per thread
+    const int64_t pix2 = pix + stride;
+    const bool has2 = pix2 < M;
+    const int64_t q = has2 ? pix2 : pix;
+    const uint4 r1 = ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), r2 = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG);
+    uint4 a1 = uint4{0u, 0u, 0u, 0u}, a2 = a1;
+    if (res.ptr) { a1 = ldg16(pptr<T>(res, dense, pd, pix) + cg * SEG); a2 = ldg16(pptr<T>(res, dense, pd, q) + cg * SEG); }
+    float f[SEG], f2[SEG];
+    Vec<T>::unpack(r1, f); Vec<T>::unpack(r2, f2);
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) f[i] = act_f(f[i] * tab[cg * SEG + i] + tab[C + cg * SEG + i], act);
+    for (int i = 0; i < SEG; ++i) { f[i] = act_f(fmaf(f[i], sc[i], sh[i]), act); f2[i] = act_f(fmaf(f2[i], sc[i], sh[i]), act); }
     if (res.ptr) {
-      float g[SEG];
-      Vec<T>::unpack(ldg16(pptr<T>(res, dense, pd, pix) + cg * SEG), g);
+      float g[SEG], g2[SEG];
+      Vec<T>::unpack(a1, g); Vec<T>::unpack(a2, g2);
 #pragma unroll
-      for (int i = 0; i < SEG; ++i) f[i] += g[i];
+      for (int i = 0; i < SEG; ++i) { f[i] += g[i]; f2[i] += g2[i]; }
     }
     stg16(pptr<T>(out, dense, pd, pix) + cg * SEG, Vec<T>::pack(f));
+    if (has2) stg16(pptr<T>(out, dense, pd, pix2) + cg * SEG, Vec<T>::pack(f2));
   }
 }
 
@@ -145,57 +156,70 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
                                                                const float* __restrict__ beta, int act,
                                                                const float* __restrict__ dsum, float* dgamma,
                                                                float* dbeta, myolo_tensor dy, myolo_tensor gres,
-                                                               int gres_acc) {
+                                                               int gres_acc, int G, int PPB) {
   constexpr int SEG = ET<T>::SEG;
-  extern __shared__ float tab[];  // [6*C]: sc, sh, mean, invstd, k0 = dsum0/M, k1 = dsum1/M
+  // dx = sc*(dz - k0 - xhat*k1), dz = gout*act'(y*sc + sh), xhat = (y - mean)*invstd, k = dsum/M
+  //    = sc*dz + cb*y + cd   with cb = -sc*k1*invstd, cd = -sc*k0 - cb*mean
+  extern __shared__ float tab[];  // [4*C]: sc, sh, cb, cd
   const int C = y.c;
   const int64_t M = (int64_t)y.n * y.h * y.w;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     if (gamma) {
       const float mean = saved[c], istd = saved[C + c];
       const float sc = gamma[c] * istd;
-      tab[c] = sc; tab[C + c] = beta[c] - mean * sc; tab[2 * C + c] = mean; tab[3 * C + c] = istd;
       float d0 = 0.f, d1 = 0.f;
 #pragma unroll
       for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { d0 += dsum[k * 2 * C + c]; d1 += dsum[k * 2 * C + C + c]; }
-      tab[4 * C + c] = d0 / (float)M; tab[5 * C + c] = d1 / (float)M;
+      const float k0 = d0 / (float)M, k1 = d1 / (float)M;
+      const float cb = -sc * k1 * istd;
+      tab[c] = sc; tab[C + c] = beta[c] - mean * sc; tab[2 * C + c] = cb; tab[3 * C + c] = -sc * k0 - cb * mean;
       if (blockIdx.x == 0) {
         if (dgamma) dgamma[c] += d1;
         if (dbeta) dbeta[c] += d0;
       }
     } else {
-      tab[c] = 1.f; tab[C + c] = 0.f; tab[2 * C + c] = 0.f; tab[3 * C + c] = 1.f; tab[4 * C + c] = 0.f; tab[5 * C + c] = 0.f;
+      tab[c] = 1.f; tab[C + c] = 0.f; tab[2 * C + c] = 0.f; tab[3 * C + c] = 0.f;
     }
   }
   __syncthreads();
-  const int G = C / SEG;
-  const int64_t total = M * G;
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  float sc[SEG], sh[SEG], cb[SEG], cd[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) {
+    const int c = cg * SEG + i;
+    sc[i] = tab[c]; sh[i] = tab[C + c]; cb[i] = tab[2 * C + c]; cd[i] = tab[3 * C + c];
+  }
   const PixDec pd(y);
   const bool dense = pix_dense(y) && pix_dense(gout) && pix_dense(dy) && (!gres.ptr || pix_dense(gres));
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t pix = v / G;
-    const int cg = (int)(v - pix * G);
-    float fy[SEG], fg[SEG], o[SEG];
-    Vec<T>::unpack(ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), fy);
-    Vec<T>::unpack(ldg16(pptr<T>(gout, dense, pd, pix) + cg * SEG), fg);
+  const int64_t stride = (int64_t)gridDim.x * PPB;
+  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += 2 * stride) {      // two pixels in flight per thread
+    const int64_t pix2 = pix + stride;
+    const bool has2 = pix2 < M;
+    const int64_t q = has2 ? pix2 : pix;
+    const uint4 ry = ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), rg = ldg16(pptr<T>(gout, dense, pd, pix) + cg * SEG);
+    const uint4 ry2 = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG), rg2 = ldg16(pptr<T>(gout, dense, pd, q) + cg * SEG);
+    uint4 ra = uint4{0u, 0u, 0u, 0u}, ra2 = ra;
+    if (gres.ptr && gres_acc) { ra = ldg16(pptr<T>(gres, dense, pd, pix) + cg * SEG); ra2 = ldg16(pptr<T>(gres, dense, pd, q) + cg * SEG); }
+    float fy[SEG], fg[SEG], fy2[SEG], fg2[SEG], o[SEG], o2[SEG];
+    Vec<T>::unpack(ry, fy); Vec<T>::unpack(rg, fg); Vec<T>::unpack(ry2, fy2); Vec<T>::unpack(rg2, fg2);
 #pragma unroll
     for (int i = 0; i < SEG; ++i) {
-      const int c = cg * SEG + i;
-      const float sc = tab[c];
-      const float dz = fg[i] * act_grad_f(fy[i] * sc + tab[C + c], act);
-      const float xh = (fy[i] - tab[2 * C + c]) * tab[3 * C + c];
-      o[i] = gamma ? sc * (dz - tab[4 * C + c] - xh * tab[5 * C + c]) : dz;
+      const float dz = fg[i] * act_grad_f(fmaf(fy[i], sc[i], sh[i]), act);
+      const float dz2 = fg2[i] * act_grad_f(fmaf(fy2[i], sc[i], sh[i]), act);
+      o[i] = fmaf(sc[i], dz, fmaf(cb[i], fy[i], cd[i]));
+      o2[i] = fmaf(sc[i], dz2, fmaf(cb[i], fy2[i], cd[i]));
     }
     stg16(pptr<T>(dy, dense, pd, pix) + cg * SEG, Vec<T>::pack(o));
+    if (has2) stg16(pptr<T>(dy, dense, pd, pix2) + cg * SEG, Vec<T>::pack(o2));
     if (gres.ptr) {
-      T* gp = pptr<T>(gres, dense, pd, pix) + cg * SEG;
       if (gres_acc) {
-        float a[SEG];
-        Vec<T>::unpack(ldg16(gp), a);
+        float a[SEG], a2[SEG];
+        Vec<T>::unpack(ra, a); Vec<T>::unpack(ra2, a2);
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) fg[i] += a[i];
+        for (int i = 0; i < SEG; ++i) { fg[i] += a[i]; fg2[i] += a2[i]; }
       }
-      stg16(gp, Vec<T>::pack(fg));
+      stg16(pptr<T>(gres, dense, pd, pix) + cg * SEG, Vec<T>::pack(fg));
+      if (has2) stg16(pptr<T>(gres, dense, pd, pix2) + cg * SEG, Vec<T>::pack(fg2));
     }
   }
 }
@@ -220,16 +244,19 @@ extern "C" int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const
   myolo_tensor r{};
   if (res && res->ptr) { if (!vec_ok(res) || !same_shape(res, y)) return MYOLO_EINVAL; r = *res; }
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
-  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / seg);
-  const int grid = grid_for(total, 256);
+  const int G = y->c / seg;
+  if (G > 256) return MYOLO_EINVAL;
+  const int PPB = 256 / G;
+  const int64_t M = (int64_t)y->n * y->h * y->w;
+  const int grid = grid_for(M, PPB * 2);                 // two pixels per thread and pass
   const size_t smem = (size_t)2 * y->c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
-    hipLaunchKernelGGL(bn_act_fwd_kernel<half_t>, dim3(grid), dim3(256), smem, st, *y, stats, gamma, beta, running_mean,
-                       running_var, nbt, saved, eps, momentum, act, r, *out);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
+                       running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB);
   else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(256), smem, st, *y, stats, gamma, beta, running_mean,
-                       running_var, nbt, saved, eps, momentum, act, r, *out);
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
+                       running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
@@ -268,16 +295,19 @@ extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tens
   myolo_tensor r{};
   if (gres && gres->ptr) { if (!vec_ok(gres) || !same_shape(gres, y)) return MYOLO_EINVAL; r = *gres; }
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
-  const int64_t total = (int64_t)y->n * y->h * y->w * (y->c / seg);
-  const int grid = grid_for(total, 256);
-  const size_t smem = (size_t)6 * y->c * sizeof(float);
+  const int G = y->c / seg;
+  if (G > 256) return MYOLO_EINVAL;
+  const int PPB = 256 / G;
+  const int64_t M = (int64_t)y->n * y->h * y->w;
+  const int grid = grid_for(M, PPB * 2);
+  const size_t smem = (size_t)4 * y->c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<half_t>, dim3(grid), dim3(256), smem, st, *gout, *y, saved, gamma, beta,
-                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
+                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB);
   else
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(256), smem, st, *gout, *y, saved, gamma, beta,
-                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate);
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
+                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
