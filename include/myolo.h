@@ -151,9 +151,11 @@ int myolo_spp_pool_bwd(const myolo_tensor* g5, const myolo_tensor* g9, const myo
 /* nn.Upsample(None, 2, 'nearest') (yaml:31,36) or plain copy (scale=1) into a (slice) view */
 int myolo_copy_up_fwd(const myolo_tensor* x, const myolo_tensor* out, int scale, void* stream);
 int myolo_copy_up_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int scale, int accumulate, void* stream);
-/* bilinear, align_corners=True (yolo.py:57..174, common.py:534-537, detect.py:191) */
+/* bilinear, align_corners=True (yolo.py:57..174, common.py:534-537, detect.py:191).
+ * bwd scratch (optional): fp32[n*h*w*c of gx], ZERO on entry, left dirty -- lets the PyramidPooling case (gx <= 6x6, thousands of
+ * outputs per input pixel) split the reduction over ~512 workgroups instead of one per input pixel. */
 int myolo_bilinear_fwd(const myolo_tensor* x, const myolo_tensor* out, void* stream);
-int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
+int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, float* scratch, void* stream);
 /* nn.AdaptiveAvgPool2d(k) (common.py:521-524, 214): out [n,k,k,c].  scratch (optional): fp32[n*k*k*c] ZEROED by the caller;
  * with it, big bins are summed by many workgroups in parallel. */
 int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, float* scratch, void* stream);

@@ -77,7 +77,7 @@ _PROTOS = {
     'myolo_copy_up_fwd': (C.c_int, [TP, TP, C.c_int, P]),
     'myolo_copy_up_bwd': (C.c_int, [TP, TP, C.c_int, C.c_int, P]),
     'myolo_bilinear_fwd': (C.c_int, [TP, TP, P]),
-    'myolo_bilinear_bwd': (C.c_int, [TP, TP, C.c_int, P]),
+    'myolo_bilinear_bwd': (C.c_int, [TP, TP, C.c_int, P, P]),
     'myolo_adaptive_avgpool_fwd': (C.c_int, [TP, TP, P, P]),
     'myolo_adaptive_avgpool_bwd': (C.c_int, [TP, TP, C.c_int, P]),
     'myolo_gate_fwd': (C.c_int, [TP, TP, TP, P]),

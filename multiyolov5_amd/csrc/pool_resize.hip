@@ -5,6 +5,7 @@
 //   AdaptiveAvgPool2d(k) (common.py:521-524,214)                               fwd / bwd
 //   FFM gate feat*att+feat (common.py:228-229)                                 fwd / bwd
 #include "myolo_dev.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -118,6 +119,136 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(myolo_tensor g5, myolo_ten
         }
       }
     }
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
+// SPP on maps whose plane fits in LDS (the stride-32 map of a 512x1024 image is 16x32): one workgroup owns the whole plane of one
+// (image, channel group) in LDS and pools separably -- 13 taps along x for the three nested windows at once, then 5 + 9 + 13
+// taps along y over the row results -- instead of 169 global loads per output vector.  The row pass keeps the first
+// maximum's dx, the column pass the first row reaching the maximum: together the first maximum in row-major window order,
+// which is what ATen's max_pool2d backward routes the gradient to.
+constexpr size_t SPP_PLANE_LDS = 64 * 1024;      // dynamic LDS available without opting in
+template <typename T, bool IDX>
+__global__ __launch_bounds__(256) void spp_fwd_plane_kernel(myolo_tensor x, myolo_tensor o5, myolo_tensor o9, myolo_tensor o13,
+                                                            uint8_t* idx) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = x.h * x.w, W = x.w, H = x.h;
+  T* tile = reinterpret_cast<T*>(smem);                                   // [HW][SEG]
+  T* rv = tile + (size_t)HW * SEG;                                        // [3][HW][SEG] row maxima
+  uint8_t* ri = reinterpret_cast<uint8_t*>(rv + (size_t)3 * HW * SEG);    // [3][HW][SEG] dx index of the row maximum
+  const int G = x.c / SEG;
+  const int n = blockIdx.x / G, cg = blockIdx.x - n * G;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int y = p / W, xx = p - y * W;
+    *reinterpret_cast<uint4*>(tile + (size_t)p * SEG) = ldg16(vptr<T>(x, n, y, xx) + cg * SEG);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int y = p / W, xx = p - y * W;
+    float m5[SEG], m9[SEG], m13[SEG];
+    int i5[SEG], i9[SEG], i13[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { m5[i] = m9[i] = m13[i] = -INFINITY; i5[i] = i9[i] = i13[i] = 0; }
+#pragma unroll
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int ix = xx + dx;
+      if (ix < 0 || ix >= W) continue;
+      float f[SEG];
+      Vec<T>::unpack(*reinterpret_cast<const uint4*>(tile + (size_t)(y * W + ix) * SEG), f);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        if (f[i] > m13[i]) { m13[i] = f[i]; i13[i] = dx + 6; }
+        if (dx >= -4 && dx <= 4 && f[i] > m9[i]) { m9[i] = f[i]; i9[i] = dx + 4; }
+        if (dx >= -2 && dx <= 2 && f[i] > m5[i]) { m5[i] = f[i]; i5[i] = dx + 2; }
+      }
+    }
+    *reinterpret_cast<uint4*>(rv + ((size_t)0 * HW + p) * SEG) = Vec<T>::pack(m5);
+    *reinterpret_cast<uint4*>(rv + ((size_t)1 * HW + p) * SEG) = Vec<T>::pack(m9);
+    *reinterpret_cast<uint4*>(rv + ((size_t)2 * HW + p) * SEG) = Vec<T>::pack(m13);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+      ri[((size_t)0 * HW + p) * SEG + i] = (uint8_t)i5[i];
+      ri[((size_t)1 * HW + p) * SEG + i] = (uint8_t)i9[i];
+      ri[((size_t)2 * HW + p) * SEG + i] = (uint8_t)i13[i];
+    }
+  }
+  __syncthreads();
+  const int64_t plane = (int64_t)x.n * HW * x.c;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int y = p / W, xx = p - y * W;
+    const int64_t e = ((int64_t)n * HW + p) * x.c + cg * SEG;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const int r = 2 + 2 * w, K = 2 * r + 1;
+      float m[SEG];
+      int id[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) { m[i] = -INFINITY; id[i] = 0; }
+      for (int dy = -r; dy <= r; ++dy) {
+        const int iy = y + dy;
+        if (iy < 0 || iy >= H) continue;
+        const size_t q = (size_t)w * HW + iy * W + xx;
+        float f[SEG];
+        Vec<T>::unpack(*reinterpret_cast<const uint4*>(rv + q * SEG), f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i)
+          if (f[i] > m[i]) { m[i] = f[i]; id[i] = (dy + r) * K + ri[q * SEG + i]; }
+      }
+      const myolo_tensor& o = w == 0 ? o5 : (w == 1 ? o9 : o13);
+      stg16(vptr<T>(o, n, y, xx) + cg * SEG, Vec<T>::pack(m));
+      if (IDX) {
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) idx[(int64_t)w * plane + e + i] = (uint8_t)id[i];
+      }
+    }
+  }
+}
+
+// transpose of the above: every output pixel adds its three gradients to the recorded arg-max positions of the plane (LDS fp32
+// atomics), then the plane is written once.
+template <typename T>
+__global__ __launch_bounds__(256) void spp_bwd_plane_kernel(myolo_tensor g5, myolo_tensor g9, myolo_tensor g13,
+                                                            const uint8_t* __restrict__ idx, myolo_tensor gx, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float accum[];                                        // [HW][SEG]
+  const int HW = gx.h * gx.w, W = gx.w;
+  const int G = gx.c / SEG;
+  const int n = blockIdx.x / G, cg = blockIdx.x - n * G;
+  for (int i = threadIdx.x; i < HW * SEG; i += blockDim.x) accum[i] = 0.f;
+  __syncthreads();
+  const int64_t plane = (int64_t)gx.n * HW * gx.c;
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int y = p / W, xx = p - y * W;
+    const int64_t e = ((int64_t)n * HW + p) * gx.c + cg * SEG;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const int r = 2 + 2 * w, K = 2 * r + 1;
+      const myolo_tensor& g = w == 0 ? g5 : (w == 1 ? g9 : g13);
+      float f[SEG];
+      Vec<T>::unpack(ldg16(vptr<T>(g, n, y, xx) + cg * SEG), f);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        const int id = idx[(int64_t)w * plane + e + i];
+        const int ty = y + id / K - r, tx = xx + id % K - r;
+        atomicAdd(accum + (size_t)(ty * W + tx) * SEG + i, f[i]);
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int y = p / W, xx = p - y * W;
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = accum[(size_t)p * SEG + i];
     T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
     if (acc) {
       float o[SEG];
@@ -319,6 +450,92 @@ __global__ __launch_bounds__(256) void bilinear_bwd_big_kernel(myolo_tensor gout
       for (int i = 0; i < SEG; ++i) o[i] += q[i];
     }
     stg16(gp, Vec<T>::pack(o));
+  }
+}
+
+// PyramidPooling footprints (1x1 .. 6x6 -> 64x128, thousands of outputs per input pixel), split variant: a workgroup owns a
+// few OUTPUT rows of one image.  Per row every thread folds its output pixels into per-input-column partials held in
+// registers (the x weights of <= 6 columns), then adds them, weighted by the row's two y weights, into the workgroup's
+// [kh][kw][C] fp32 tile in LDS; tiles are combined in `scratch` with fp32 atomics and bilinear_bwd_finish converts.
+constexpr int BB_MAXK = 6;
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_split_kernel(myolo_tensor gout, int kh, int kw, float sy, float sx,
+                                                                 int rows_per_block, float* scratch, int G, int lanes) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float tile[];   // [kh*kw*C]
+  const int C = gout.c;
+  const int nrb = (gout.h + rows_per_block - 1) / rows_per_block;
+  const int n = blockIdx.x / nrb, rb = blockIdx.x - n * nrb;
+  const int tsz = kh * kw * C;
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x) tile[i] = 0.f;
+  __syncthreads();
+  const int cg = threadIdx.x % G, lane = threadIdx.x / G;
+  int oy_end = (rb + 1) * rows_per_block;
+  if (oy_end > gout.h) oy_end = gout.h;
+  for (int oy = rb * rows_per_block; oy < oy_end; ++oy) {
+    const float fy = sy * (float)oy;
+    const int y0 = (int)fy;
+    const int y1 = y0 + 1 < kh ? y0 + 1 : kh - 1;
+    const float ly = fy - (float)y0;
+    float t[BB_MAXK][SEG];
+#pragma unroll
+    for (int ix = 0; ix < BB_MAXK; ++ix)
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) t[ix][i] = 0.f;
+    for (int ox = lane; ox < gout.w; ox += lanes) {
+      const float fx = sx * (float)ox;
+      const int x0 = (int)fx;
+      const int x1 = x0 + 1 < kw ? x0 + 1 : kw - 1;
+      const float lx = fx - (float)x0;
+      float f[SEG];
+      Vec<T>::unpack(ldg16(vptr<T>(gout, n, oy, ox) + cg * SEG), f);
+#pragma unroll
+      for (int ix = 0; ix < BB_MAXK; ++ix) {
+        const float w = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) t[ix][i] = fmaf(w, f[i], t[ix][i]);
+      }
+    }
+#pragma unroll
+    for (int ix = 0; ix < BB_MAXK; ++ix) {
+      if (ix < kw) {
+        float* r0 = tile + (y0 * kw + ix) * C + cg * SEG;
+        float* r1 = tile + (y1 * kw + ix) * C + cg * SEG;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) {
+          if (t[ix][i] != 0.f) {
+            atomicAdd(r0 + i, (1.f - ly) * t[ix][i]);
+            if (ly != 0.f) atomicAdd(r1 + i, ly * t[ix][i]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = scratch + (size_t)n * tsz;
+  for (int i = threadIdx.x; i < tsz; i += blockDim.x)
+    if (tile[i] != 0.f) atomicAdd(dst + i, tile[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_finish_kernel(myolo_tensor gx, const float* __restrict__ scratch, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = gx.c / SEG;
+  const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    const float* sp = scratch + (((size_t)n * gx.h + y) * gx.w + xx) * gx.c + cg * SEG;
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = sp[i];
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
   }
 }
 
@@ -594,8 +811,23 @@ extern "C" int myolo_spp_pool_fwd(const myolo_tensor* x, const myolo_tensor* o5,
   if (!vec_ok(x) || !vec_ok(o5) || !vec_ok(o9) || !vec_ok(o13) || !same_shape(x, o5) || !same_shape(x, o9) ||
       !same_shape(x, o13))
     return MYOLO_EINVAL;
-  const int grid = grid_for(nvec(x), 256, 8192);
   hipStream_t st = (hipStream_t)stream;
+  const int HW = x->h * x->w;
+  const int es = x->dtype == MYOLO_F16 ? 2 : 4, seg = 16 / es;
+  const size_t smem = (size_t)HW * 16 * 4 + (size_t)3 * HW * seg;            // tile + 3 row-max planes (16 B/pixel) + 3 index planes
+  if (smem <= SPP_PLANE_LDS && !getenv("MYOLO_SPP_NAIVE")) {
+    const int blocks = x->n * (x->c / seg);
+    if (x->dtype == MYOLO_F16) {
+      if (idx) hipLaunchKernelGGL((spp_fwd_plane_kernel<half_t, true>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
+      else hipLaunchKernelGGL((spp_fwd_plane_kernel<half_t, false>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
+    } else {
+      if (idx) hipLaunchKernelGGL((spp_fwd_plane_kernel<float, true>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
+      else hipLaunchKernelGGL((spp_fwd_plane_kernel<float, false>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
+    }
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
+  const int grid = grid_for(nvec(x), 256, 8192);
   if (x->dtype == MYOLO_F16) {
     if (idx) hipLaunchKernelGGL((spp_fwd_kernel<half_t, true>), dim3(grid), dim3(256), 0, st, *x, *o5, *o9, *o13, idx);
     else hipLaunchKernelGGL((spp_fwd_kernel<half_t, false>), dim3(grid), dim3(256), 0, st, *x, *o5, *o9, *o13, idx);
@@ -611,6 +843,13 @@ extern "C" int myolo_spp_pool_bwd(const myolo_tensor* g5, const myolo_tensor* g9
   if (!vec_ok(gx) || !vec_ok(g5) || !vec_ok(g9) || !vec_ok(g13) || !idx || !same_shape(gx, g5) ||
       !same_shape(gx, g9) || !same_shape(gx, g13))
     return MYOLO_EINVAL;
+  const int HW = gx->h * gx->w;
+  const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
+  if ((size_t)HW * seg * sizeof(float) <= SPP_PLANE_LDS && !getenv("MYOLO_SPP_NAIVE")) {
+    DISPATCH(gx->dtype, spp_bwd_plane_kernel, gx->n * (gx->c / seg), 256, (size_t)HW * seg * sizeof(float), (hipStream_t)stream,
+             *g5, *g9, *g13, idx, *gx, accumulate);
+    return 0;
+  }
   DISPATCH(gx->dtype, spp_bwd_kernel, grid_for(nvec(gx), 256, 8192), 256, 0, (hipStream_t)stream, *g5, *g9, *g13, idx,
            *gx, accumulate);
   return 0;
@@ -639,12 +878,34 @@ extern "C" int myolo_bilinear_fwd(const myolo_tensor* x, const myolo_tensor* out
            ac_scale(x->h, out->h), ac_scale(x->w, out->w));
   return 0;
 }
-extern "C" int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream) {
+extern "C" int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, float* scratch, void* stream) {
   if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
   const int64_t foot = (int64_t)(gout->h / (gx->h > 0 ? gx->h : 1)) * (gout->w / (gx->w > 0 ? gx->w : 1));
+  const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
+  const int G = gx->c / seg;
+  if (foot >= 64 && scratch && gx->h <= BB_MAXK && gx->w <= BB_MAXK && G <= 256 &&
+      (size_t)gx->h * gx->w * gx->c * sizeof(float) <= 48 * 1024) {
+    const int lanes = 256 / G;
+    int nrb = 512 / (gx->n > 0 ? gx->n : 1);            // ~512 workgroups
+    if (nrb < 1) nrb = 1;
+    if (nrb > gout->h) nrb = gout->h;
+    const int rpb = (gout->h + nrb - 1) / nrb;
+    nrb = (gout->h + rpb - 1) / rpb;
+    const size_t smem = (size_t)gx->h * gx->w * gx->c * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (gx->dtype == MYOLO_F16) {
+      hipLaunchKernelGGL(bilinear_bwd_split_kernel<half_t>, dim3(gx->n * nrb), dim3(G * lanes), smem, st, *gout, gx->h, gx->w,
+                         ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), rpb, scratch, G, lanes);
+      hipLaunchKernelGGL(bilinear_bwd_finish_kernel<half_t>, dim3(grid_for(nvec(gx), 256)), dim3(256), 0, st, *gx, scratch, accumulate);
+    } else {
+      hipLaunchKernelGGL(bilinear_bwd_split_kernel<float>, dim3(gx->n * nrb), dim3(G * lanes), smem, st, *gout, gx->h, gx->w,
+                         ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), rpb, scratch, G, lanes);
+      hipLaunchKernelGGL(bilinear_bwd_finish_kernel<float>, dim3(grid_for(nvec(gx), 256)), dim3(256), 0, st, *gx, scratch, accumulate);
+    }
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
   if (foot >= 64) {   // few input pixels, each gathering thousands of outputs: a workgroup per input pixel
-    const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
-    const int G = gx->c / seg;
     int gb = 1;
     while (gb < 8 && gb < G) gb <<= 1;
     const int64_t blocks = (int64_t)gx->n * gx->h * gx->w * ((G + gb - 1) / gb);

@@ -429,7 +429,12 @@ class BilinearOp(SimpleOp):
         self.fwd_calls.append(Call('myolo_bilinear_fwd', (C.byref(self.sd), C.byref(self.dd))))
 
     def emit_bwd(self, plan):
-        self.bwd_calls.append(Call('myolo_bilinear_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc)))
+        s_, d_ = self.src, self.dst
+        scratch = None
+        if s_.h <= 6 and s_.w <= 6 and (d_.h // max(s_.h, 1)) * (d_.w // max(s_.w, 1)) >= 64:      # PyramidPooling footprints
+            scratch = plan.f32_bwd_zero(s_.n * s_.h * s_.w * s_.c)
+        self.bwd_calls.append(Call('myolo_bilinear_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc, L.ptr(scratch)),
+                                   keep=scratch))
 
 
 class AvgPoolOp(SimpleOp):

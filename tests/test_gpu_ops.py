@@ -130,6 +130,44 @@ def test_block_streaming_kernel(name, training, force_stream_kernel):
     test_block(name, training, torch.float16)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+@pytest.mark.parametrize('name', ['spp', 'c3spp'])
+def test_block_spp_large_map_kernels(name, dtype, monkeypatch):
+    """maps whose plane does not fit in LDS take the per-output-vector SPP kernels: same parity cases with that path forced"""
+    monkeypatch.setenv('MYOLO_SPP_NAIVE', '1')
+    test_block(name, True, dtype)
+
+
+def test_pyramid_bilinear_bwd_paths_agree():
+    """myolo_bilinear_bwd: the split-reduction path (scratch given) and the one-workgroup-per-input-pixel path give the same
+    gradient for the PyramidPooling footprints 1x1, 2x2, 3x3, 6x6 -> 64x128 (common.py:534-537), with and without accumulate"""
+    import ctypes as C
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    for dt in (torch.float16, torch.float32):
+        for k in (1, 2, 3, 6):
+            n, c, H, W = 3, 32, 64, 128
+            g = (torch.randn(n, H, W, c, device=DEV) * 0.1).to(dt)
+            base = (torch.randn(n, k, k, c, device=DEV) * 0.1).to(dt)
+            gd = L.Tensor(L.ptr(g), n, H, W, c, H * W * c, W * c, c, L.DT[dt], 0)
+            for acc in (0, 1):
+                outs = []
+                for use_scratch in (True, False):
+                    gx = base.clone()
+                    xd = L.Tensor(L.ptr(gx), n, k, k, c, k * k * c, k * c, c, L.DT[dt], 0)
+                    scratch = torch.zeros(n * k * k * c, device=DEV) if use_scratch else None
+                    L.check(lib.myolo_bilinear_bwd(C.byref(gd), C.byref(xd), acc, L.ptr(scratch), L.stream_ptr()), 'bilinear_bwd')
+                    outs.append(gx.float())
+                # fp64 reference: transpose of F.interpolate(align_corners=True)
+                lo = torch.zeros(n, c, k, k, dtype=torch.float64, requires_grad=True)
+                up = torch.nn.functional.interpolate(lo, size=(H, W), mode='bilinear', align_corners=True)
+                up.backward(g.permute(0, 3, 1, 2).double().cpu())
+                ref = lo.grad.permute(0, 2, 3, 1).float() + (base.float().cpu() if acc else 0)
+                tol = 2e-3 if dt == torch.float16 else 2e-5
+                check(f'bilinear_bwd/split/k{k}/acc{acc}/{dt}', outs[0], ref, tol)
+                check(f'bilinear_bwd/big/k{k}/acc{acc}/{dt}', outs[1], ref, tol)
+
+
 def test_full_resolution_eval_forward_vs_oracle():
     """1x3x512x1024 (the benchmark resolution): fused eval forward in fp16 -- streaming kernel at its real tile counts -- and fp32,
     against the CPU oracle"""
