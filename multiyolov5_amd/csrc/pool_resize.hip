@@ -453,68 +453,77 @@ __global__ __launch_bounds__(256) void bilinear_bwd_big_kernel(myolo_tensor gout
   }
 }
 
-// PyramidPooling footprints (1x1 .. 6x6 -> 64x128, thousands of outputs per input pixel), split variant: a workgroup owns a
-// few OUTPUT rows of one image.  Per row every thread folds its output pixels into per-input-column partials held in
-// registers (the x weights of <= 6 columns), then adds them, weighted by the row's two y weights, into the workgroup's
-// [kh][kw][C] fp32 tile in LDS; tiles are combined in `scratch` with fp32 atomics and bilinear_bwd_finish converts.
+// PyramidPooling footprints (1x1 .. 6x6 -> 64x128, thousands of outputs per input pixel), split variant: a workgroup owns one
+// input row iy of one image and a chunk of <= BB_ROWS output rows of its footprint, staged in LDS with coalesced 16-byte loads.
+// Thread (o = (ix, c), part) folds its share of the x footprint over all staged rows (the x weight is computed once per
+// column); partial sums are combined in `scratch` (fp32 [n][kh][kw][C], zero on entry) with one atomic per thread and
+// bilinear_bwd_finish converts.
 constexpr int BB_MAXK = 6;
+constexpr int BB_ROWS = 8;
 template <typename T>
-__global__ __launch_bounds__(256) void bilinear_bwd_split_kernel(myolo_tensor gout, int kh, int kw, float sy, float sx,
-                                                                 int rows_per_block, float* scratch, int G, int lanes) {
+__global__ __launch_bounds__(256) void bilinear_bwd_split_kernel(myolo_tensor gout, int kh, int kw, float sy, float sx, int chunks,
+                                                                 int per, float* scratch) {
   constexpr int SEG = ET<T>::SEG;
-  extern __shared__ float tile[];   // [kh*kw*C]
-  const int C = gout.c;
-  const int nrb = (gout.h + rows_per_block - 1) / rows_per_block;
-  const int n = blockIdx.x / nrb, rb = blockIdx.x - n * nrb;
-  const int tsz = kh * kw * C;
-  for (int i = threadIdx.x; i < tsz; i += blockDim.x) tile[i] = 0.f;
-  __syncthreads();
-  const int cg = threadIdx.x % G, lane = threadIdx.x / G;
-  int oy_end = (rb + 1) * rows_per_block;
-  if (oy_end > gout.h) oy_end = gout.h;
-  for (int oy = rb * rows_per_block; oy < oy_end; ++oy) {
+  extern __shared__ __attribute__((aligned(16))) char smem_bb[];
+  T* rows = reinterpret_cast<T*>(smem_bb);          // [per][Wo][C]
+  __shared__ float wys[BB_ROWS];
+  const int C = gout.c, Wo = gout.w, G = C / SEG;
+  int b = blockIdx.x;
+  const int ch = b % chunks; b /= chunks;
+  const int iy = b % kh; const int n = b / kh;
+  int ylo, yhi;
+  out_range(iy, kh, gout.h, sy, ylo, yhi);
+  const int r0 = ylo + ch * per;
+  int nr = yhi - r0 + 1;
+  if (nr > per) nr = per;
+  if (nr <= 0) return;
+  if ((int)threadIdx.x < nr) {
+    const int oy = r0 + threadIdx.x;
     const float fy = sy * (float)oy;
     const int y0 = (int)fy;
     const int y1 = y0 + 1 < kh ? y0 + 1 : kh - 1;
     const float ly = fy - (float)y0;
-    float t[BB_MAXK][SEG];
-#pragma unroll
-    for (int ix = 0; ix < BB_MAXK; ++ix)
-#pragma unroll
-      for (int i = 0; i < SEG; ++i) t[ix][i] = 0.f;
-    for (int ox = lane; ox < gout.w; ox += lanes) {
+    float wy = 0.f;
+    if (y0 == iy) wy += 1.f - ly;
+    if (y1 == iy) wy += ly;
+    wys[threadIdx.x] = wy;
+  }
+  const int vec_per_row = Wo * G;
+  for (int v = threadIdx.x; v < nr * vec_per_row; v += 256) {
+    const int r = v / vec_per_row, q = v - r * vec_per_row;
+    const int px = q / G, cg = q - px * G;
+    *reinterpret_cast<uint4*>(rows + ((size_t)r * Wo + px) * C + cg * SEG) = ldg16(vptr<T>(gout, n, r0 + r, px) + cg * SEG);
+  }
+  __syncthreads();
+  const int nout = kw * C;
+  const int parts = 256 / nout > 0 ? 256 / nout : 1;
+  for (int o0 = 0; o0 < nout; o0 += 256) {               // nout > 256: several passes with parts = 1
+    const int o = o0 + (int)threadIdx.x % (parts > 1 ? nout : 256);
+    const int part = parts > 1 ? (int)threadIdx.x / nout : 0;
+    if (o >= nout || part >= parts) continue;
+    const int ix = o / C, c = o - ix * C;
+    int xlo, xhi;
+    out_range(ix, kw, Wo, sx, xlo, xhi);
+    const int span = (xhi - xlo + 1 + parts - 1) / parts;
+    const int xa = xlo + part * span;
+    int xb = xa + span - 1;
+    if (xb > xhi) xb = xhi;
+    float acc = 0.f;
+    for (int ox = xa; ox <= xb; ++ox) {
       const float fx = sx * (float)ox;
       const int x0 = (int)fx;
       const int x1 = x0 + 1 < kw ? x0 + 1 : kw - 1;
       const float lx = fx - (float)x0;
-      float f[SEG];
-      Vec<T>::unpack(ldg16(vptr<T>(gout, n, oy, ox) + cg * SEG), f);
-#pragma unroll
-      for (int ix = 0; ix < BB_MAXK; ++ix) {
-        const float w = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) t[ix][i] = fmaf(w, f[i], t[ix][i]);
-      }
+      float wx = 0.f;
+      if (x0 == ix) wx += 1.f - lx;
+      if (x1 == ix) wx += lx;
+      if (wx == 0.f) continue;
+      float sacc = 0.f;
+      for (int r = 0; r < nr; ++r) sacc = fmaf(wys[r], (float)rows[((size_t)r * Wo + ox) * C + c], sacc);
+      acc = fmaf(wx, sacc, acc);
     }
-#pragma unroll
-    for (int ix = 0; ix < BB_MAXK; ++ix) {
-      if (ix < kw) {
-        float* r0 = tile + (y0 * kw + ix) * C + cg * SEG;
-        float* r1 = tile + (y1 * kw + ix) * C + cg * SEG;
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) {
-          if (t[ix][i] != 0.f) {
-            atomicAdd(r0 + i, (1.f - ly) * t[ix][i]);
-            if (ly != 0.f) atomicAdd(r1 + i, ly * t[ix][i]);
-          }
-        }
-      }
-    }
+    if (acc != 0.f) atomicAdd(scratch + ((size_t)(n * kh + iy) * kw) * C + o, acc);
   }
-  __syncthreads();
-  float* dst = scratch + (size_t)n * tsz;
-  for (int i = threadIdx.x; i < tsz; i += blockDim.x)
-    if (tile[i] != 0.f) atomicAdd(dst + i, tile[i]);
 }
 template <typename T>
 __global__ __launch_bounds__(256) void bilinear_bwd_finish_kernel(myolo_tensor gx, const float* __restrict__ scratch, int acc) {
@@ -883,23 +892,24 @@ extern "C" int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* 
   const int64_t foot = (int64_t)(gout->h / (gx->h > 0 ? gx->h : 1)) * (gout->w / (gx->w > 0 ? gx->w : 1));
   const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
   const int G = gx->c / seg;
-  if (foot >= 64 && scratch && gx->h <= BB_MAXK && gx->w <= BB_MAXK && G <= 256 &&
-      (size_t)gx->h * gx->w * gx->c * sizeof(float) <= 48 * 1024) {
-    const int lanes = 256 / G;
-    int nrb = 512 / (gx->n > 0 ? gx->n : 1);            // ~512 workgroups
-    if (nrb < 1) nrb = 1;
-    if (nrb > gout->h) nrb = gout->h;
-    const int rpb = (gout->h + nrb - 1) / nrb;
-    nrb = (gout->h + rpb - 1) / rpb;
-    const size_t smem = (size_t)gx->h * gx->w * gx->c * sizeof(float);
+  const size_t row_bytes = (size_t)gout->w * gout->c * (gx->dtype == MYOLO_F16 ? 2 : 4);
+  // (6x6 already yields 576+ workgroups in the per-pixel kernel and measures faster there)
+  if (foot >= 64 && scratch && gx->h * gx->w <= 9 && row_bytes <= 32 * 1024) {
+    const int rows_per_iy = gx->h > 1 ? 2 * ((gout->h + gx->h - 2) / (gx->h - 1)) + 6 : gout->h;   // upper bound of one input row's footprint
+    int maxrows = (int)(64 * 1024 / row_bytes);
+    if (maxrows > BB_ROWS) maxrows = BB_ROWS;
+    int per = rows_per_iy * gx->n * gx->h / 512;                     // ~512 workgroups
+    if (per < 1) per = 1;
+    if (per > maxrows) per = maxrows;
+    const int chunks = (rows_per_iy + per - 1) / per;
     hipStream_t st = (hipStream_t)stream;
     if (gx->dtype == MYOLO_F16) {
-      hipLaunchKernelGGL(bilinear_bwd_split_kernel<half_t>, dim3(gx->n * nrb), dim3(G * lanes), smem, st, *gout, gx->h, gx->w,
-                         ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), rpb, scratch, G, lanes);
+      hipLaunchKernelGGL(bilinear_bwd_split_kernel<half_t>, dim3(gx->n * gx->h * chunks), dim3(256), per * row_bytes, st, *gout, gx->h,
+                         gx->w, ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), chunks, per, scratch);
       hipLaunchKernelGGL(bilinear_bwd_finish_kernel<half_t>, dim3(grid_for(nvec(gx), 256)), dim3(256), 0, st, *gx, scratch, accumulate);
     } else {
-      hipLaunchKernelGGL(bilinear_bwd_split_kernel<float>, dim3(gx->n * nrb), dim3(G * lanes), smem, st, *gout, gx->h, gx->w,
-                         ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), rpb, scratch, G, lanes);
+      hipLaunchKernelGGL(bilinear_bwd_split_kernel<float>, dim3(gx->n * gx->h * chunks), dim3(256), per * row_bytes, st, *gout, gx->h,
+                         gx->w, ac_scale(gx->h, gout->h), ac_scale(gx->w, gout->w), chunks, per, scratch);
       hipLaunchKernelGGL(bilinear_bwd_finish_kernel<float>, dim3(grid_for(nvec(gx), 256)), dim3(256), 0, st, *gx, scratch, accumulate);
     }
     MYOLO_CHECK_LAUNCH();
