@@ -7,9 +7,11 @@ from multiyolov5_amd.models import common as C
 from multiyolov5_amd import engine as E
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+NSH = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 dt = torch.float16
 # (cin, cout, k, s, d, H, W) of the input map
 SHAPES = [
+    (64, 384, 1, 1, 1, 64, 128), (64, 256, 1, 1, 1, 64, 128), (128, 512, 1, 1, 1, 32, 64), (128, 256, 1, 1, 1, 32, 64), (256, 512, 1, 1, 1, 16, 32),
     (256, 128, 3, 1, 1, 64, 128), (64, 64, 3, 1, 1, 64, 128), (128, 128, 3, 1, 1, 32, 64), (32, 64, 3, 2, 1, 256, 512),
     (64, 128, 3, 2, 1, 128, 256), (128, 256, 3, 2, 1, 64, 128), (256, 512, 3, 2, 1, 32, 64), (256, 256, 3, 1, 1, 16, 32),
     (256, 128, 1, 1, 1, 64, 128), (16, 32, 3, 1, 1, 256, 512), (256, 128, 1, 1, 1, 32, 64), (256, 256, 1, 1, 1, 32, 64),
@@ -20,7 +22,7 @@ SHAPES = [
 ]
 tot_t = tot_b = tot_f = 0
 print(f'{"cin":>5}{"cout":>5} k s d {"HxW":>9} {"us":>8} {"GB/s":>8} {"TF/s":>7}  ideal_us(6.3TB/s|2.5PF)')
-for cin, cout, k, s, d, H, W in SHAPES:
+for cin, cout, k, s, d, H, W in SHAPES[:NSH]:
     m = C.Conv(cin, cout, k, s).to('cuda')
     if d != 1:
         m.conv.dilation, m.conv.padding = (d, d), (d, d)

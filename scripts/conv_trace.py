@@ -1,0 +1,34 @@
+"""per-launch table of the myolo_conv kernels (forward convs + dgrad) of the last profiled step: shape, kernel, duration,
+algorithmic GB/s and TFLOP/s.  usage: python scripts/conv_trace.py gpurun_out/prof_<tag>/train_kernel_trace.csv"""
+import csv, sys, os, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from multiyolov5_amd import runtime as R, _lib as L, engine as E
+from multiyolov5_amd.models.yolo import Model
+from tests.util import CFG, TAGS
+m = Model(os.path.join(CFG, TAGS['s_psp'])); m.train(True)
+h = R.PlanHolder(m, [torch.zeros(16, 3, 512, 1024)], ('t', 0), torch.float16, True)
+calls = []
+for o in h.plan.ops:
+    calls += [('f', c) for c in o.fwd_calls if c.name == 'myolo_conv']
+for o in reversed(h.plan.ops):
+    calls += [('b', c) for c in o.bwd_calls if c.name == 'myolo_conv']
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+sgd = [i for i, r in enumerate(rows) if 'mt_sgd' in r['Kernel_Name']]
+step = rows[sgd[-2] + 1:sgd[-1] + 1]
+ks = [r for r in step if 'conv_igemm_kernel' in r['Kernel_Name'] or 'conv_stream_kernel' in r['Kernel_Name']]
+print(len(calls), len(ks))
+agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, ''])
+for (ph, c), r in zip(calls, ks):
+    d = E._conv_desc_of(c)
+    t = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+    kn = 'stream' if 'stream' in r['Kernel_Name'] else 'igemm'
+    key = (ph, d.x.h, d.x.w, d.x.c, d.y.h, d.y.w, d.y.c, d.ntaps, kn)
+    a = agg[key]; a[0] += 1; a[1] += t; a[2] += E.conv_call_bytes(c); a[3] += E.conv_call_flops(c)
+tot = sum(a[1] for a in agg.values())
+print(f'total {tot:.0f} us')
+print('ph  in(HxWxC) -> out(HxWxC) taps kern   n   us/call  GB/s  TF/s  total_us')
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+    ph, xh, xw, xc, yh, yw, yc, nt, kn = k
+    print(f'{ph} {xh:4d}x{xw:4d}x{xc:4d} -> {yh:4d}x{yw:4d}x{yc:4d} t{nt} {kn:6s} x{a[0]:2d} {a[1]/a[0]:8.1f} {a[2]/a[1]/1e3:6.0f} {a[3]/a[1]/1e6:6.1f} {a[1]:8.0f}')
