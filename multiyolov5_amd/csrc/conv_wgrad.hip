@@ -334,6 +334,127 @@ __global__ __launch_bounds__(THREADS) void wgrad_fused_kernel(const WgradK p) {
   if (p.db && tci == 0 && tid < WT && co0 + tid < p.cout_w) atomicAdd(p.db + co0 + tid, bias_part);
 }
 
+// ---- 3x3 convolutions with <= 16 input and <= 32 output channels (Focus: 12 -> 32 on the full-resolution map, the LAST weight
+// gradient of the step and therefore on its critical path).  The 64x64 tile of the kernels above would be 7/8 padding there;
+// here the output tile is [32 co][16 ci] per tap and the four waves split the PIXELS of a 128-pixel K step instead (32 each):
+// 18 MFMAs per wave per step, all useful, 11 useful 16-byte loads per thread per 128 pixels.  The waves' partial tiles meet
+// in LDS; the workgroup writes one compact [9][32][16] slice of the split-K workspace.
+constexpr int KPS = 128;
+__global__ __launch_bounds__(THREADS) void wgrad_fused_small_kernel(const WgradK p) {
+  typedef half_t T;
+  constexpr int ES = 2, SEG = 8, NT = 9;
+  constexpr int PD = 32 * ES + 16;                        // dy row pitch (bytes): 32 channels + pad
+  constexpr int PX = 16 * ES + 16;                        // x row pitch: 16 channels + pad
+  __shared__ __attribute__((aligned(16))) char sD[KPS * PD];
+  __shared__ __attribute__((aligned(16))) char sX[NT][KPS * PX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.y;
+  const int HWo = p.Ho * p.Wo;
+  const int Hlog = p.Hi << p.up, Wlog = p.Wi << p.up;
+  const int m_begin = split * p.pix_per_split;
+  int m_end = m_begin + p.pix_per_split;
+  if (m_end > p.M) m_end = p.M;
+  const int nsteps = m_end > m_begin ? (m_end - m_begin + KPS - 1) / KPS : 0;
+
+  f4_t acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[t][i] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int OOB = 0x7fff0000;
+  const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, p.d_bytes, 0x00020000);
+  auto bl = [&](const __amdgpu_buffer_rsrc_t& r, int off) -> uint4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return uint4{v.x, v.y, v.z, v.w};
+  };
+  // dy tile [128 px][4 segments]: two loads per thread; x tiles [128 px][2 segments] per tap: one load per thread and tap
+  const int prow_x = tid >> 1, cx = (tid & 1) * SEG;
+  uint4 rd[2], rx[NT];
+  auto issue = [&](int s) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int v = tid + l * THREADS;
+      const int prow = v >> 2, cd = (v & 3) * SEG;
+      const int m = m_begin + s * KPS + prow;
+      const bool live = m < m_end;
+      const int mm = live ? m : m_begin;
+      const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+      rd[l] = bl(rbd, (live && cd < p.Cout) ? (n * (int)p.d_sn + oy * (int)p.d_sh + ox * (int)p.d_sw + cd) * ES : OOB);
+    }
+    const int m = m_begin + s * KPS + prow_x;
+    const bool live = m < m_end;
+    const int mm = live ? m : m_begin;
+    const int n = mm / HWo; const int rem = mm - n * HWo; const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+    const int xn = n * (int)p.x_sn + cx;
+    const bool cok = live && cx < p.Cin;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      int iy = oy * p.stride + p.tap_dy[t], ix = ox * p.stride + p.tap_dx[t];
+      const bool ok = cok && (unsigned)iy < (unsigned)Hlog && (unsigned)ix < (unsigned)Wlog;
+      iy >>= p.up; ix >>= p.up;
+      rx[t] = bl(rbx, ok ? (xn + iy * (int)p.x_sh + ix * (int)p.x_sw) * ES : OOB);
+    }
+  };
+
+  if (nsteps > 0) issue(0);
+  for (int s = 0; s < nsteps; ++s) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int v = tid + l * THREADS;
+      *reinterpret_cast<uint4*>(&sD[(v >> 2) * PD + (v & 3) * 16]) = rd[l];
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) *reinterpret_cast<uint4*>(&sX[t][prow_x * PX + (tid & 1) * 16]) = rx[t];
+    __syncthreads();
+    if (s + 1 < nsteps) issue(s + 1);                    // next step's loads fly while this one computes
+    const int g = lane >> 4, kq = (lane & 15) >> 2, q = lane & 3;       // transpose-read lane map: see wgrad_kernel
+    h8_t fa[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int ca = (f * 16 + q * 4) * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pr = wave * 32 + 8 * g + 4 * h + kq;
+        fp16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(&sD[pr * PD + ca]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fa[f][4 * h + e] = (half_t)va[e];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      h8_t fb;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int pr = wave * 32 + 8 * g + 4 * h + kq;
+        fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(&sX[t][pr * PX + q * 8]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[4 * h + e] = (half_t)vb[e];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb, acc[t][i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // the four waves' partial [9][32][16] tiles meet in LDS (the staging area is free after the last barrier)
+  float* red = reinterpret_cast<float*>(&sX[0][0]);
+  for (int i = tid; i < NT * 32 * 16; i += THREADS) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = i * 16 + 4 * (lane >> 4) + r, ci = lane & 15;
+        atomicAdd(red + (t * 32 + co) * 16 + ci, acc[t][i][r]);
+      }
+  __syncthreads();
+  float* dst = p.ws + (int64_t)split * (NT * 32 * 16);
+  for (int i = tid; i < NT * 32 * 16; i += THREADS) dst[i] = red[i];
+}
+
 // dw[co][ci][t] += sum over splits of ws[s][t][co][ci].  A workgroup owns 64 consecutive weights (coalesced along ci); its 4
 // waves take every 4th split and combine through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ks, int ntaps,
@@ -416,13 +537,33 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
     if (ks > fit) ks = (int)fit;
     k.ws = d->ws;
   }
+  // Focus-sized 3x3 (<= 16 -> <= 32 channels): compact [9][32][16] slices, waves split the pixels (wgrad_fused_small_kernel)
+  const bool small = fused && !d->db && k.cout_w <= 32 && k.cin_w <= 16 && d->ws && (((uintptr_t)d->ws) & 15) == 0 &&
+                     d->ws_bytes >= (int64_t)2 * 9 * 32 * 16 * (int64_t)sizeof(float) && !getenv("MYOLO_WGRAD_NO_SMALL");
+  if (small) {
+    ks = d->ksplit > 0 ? d->ksplit : 512;                     // two 8-wave-equivalent workgroups per CU
+    const int max_ks = (int)((M + 4 * KPS - 1) / (4 * KPS));
+    if (ks > max_ks) ks = max_ks;
+    const int64_t fit = d->ws_bytes / ((int64_t)9 * 32 * 16 * sizeof(float));
+    if (ks > fit) ks = (int)fit;
+    if (ks < 1) ks = 1;
+    k.ws = d->ws;
+  }
   int pps = (int)((M + ks - 1) / ks);
-  pps = (pps + KP - 1) / KP * KP;
+  const int kstep = small ? KPS : KP;
+  pps = (pps + kstep - 1) / kstep * kstep;
   ks = (int)((M + pps - 1) / pps);
   k.ksplit = ks; k.pix_per_split = pps;
   static const int dbg = getenv("MYOLO_WGRAD_DBG") ? atoi(getenv("MYOLO_WGRAD_DBG")) : 0;
   k.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
+  if (small) {
+    hipLaunchKernelGGL(wgrad_fused_small_kernel, dim3(1, ks), dim3(THREADS), 0, st, k);
+    const int64_t total = (int64_t)9 * k.cout_w * k.cin_w;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, st, k.ws, k.dw, ks, 9, 32, 16, k.cout_w, k.cin_w);
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
   if (fused) hipLaunchKernelGGL(wgrad_fused_kernel<9>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
   else if (dt == MYOLO_F16) hipLaunchKernelGGL(wgrad_kernel<half_t>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);
   else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(out_tiles, ks), dim3(THREADS), 0, st, k);

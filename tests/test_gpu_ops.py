@@ -43,6 +43,7 @@ def _oracle(fn, mod, xs, training):
 CASES = {
     # name: (ctor, oracle fn, input shapes)
     'conv1x1': (lambda C: C.Conv(64, 128, 1, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 1), [(2, 64, 24, 40)]),
+    'conv3x3_small': (lambda C: C.Conv(16, 32, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(3, 16, 37, 53)]),   # Focus-sized: compact wgrad kernel, ragged pixel count
     'conv3x3': (lambda C: C.Conv(32, 64, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(2, 32, 20, 36)]),
     'conv3x3s2': (lambda C: C.Conv(64, 128, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), [(2, 64, 24, 40)]),
     'conv3x3s2_odd': (lambda C: C.Conv(16, 32, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), [(1, 16, 13, 19)]),
