@@ -34,20 +34,25 @@ __global__ __launch_bounds__(256) void pack_weights_mt_kernel(const int64_t* job
   void* dst = reinterpret_cast<void*>(e[1]);
   const int cout = (int)e[2], cin = (int)e[3], ntaps = (int)e[4], rows_pad = (int)e[5], cols_pad = (int)e[6];
   const int transpose = (int)e[7], sdt = (int)e[8], ddt = (int)e[9];
-  const int64_t total = (int64_t)rows_pad * ntaps * cols_pad;
-  int64_t end = (int64_t)start + chunk_elems;
+  // (one packed weight tensor is far below 2^31 elements: 32-bit index arithmetic, one division chain per thread, then strides)
+  const uint32_t total = (uint32_t)rows_pad * (uint32_t)ntaps * (uint32_t)cols_pad;
+  uint32_t end = (uint32_t)start + (uint32_t)chunk_elems;
   if (end > total) end = total;
-  for (int64_t i = (int64_t)start + threadIdx.x; i < end; i += 256) {
-    const int col = (int)(i % cols_pad);
-    const int t = (int)((i / cols_pad) % ntaps);
-    const int row = (int)(i / ((int64_t)cols_pad * ntaps));
+  const uint32_t ucols = (uint32_t)cols_pad, utaps = (uint32_t)ntaps;
+  const bool f16s = sdt == MYOLO_F16, f16d = ddt == MYOLO_F16;
+  for (uint32_t i = (uint32_t)start + threadIdx.x; i < end; i += 256) {
+    const uint32_t q = i / ucols;
+    const int col = (int)(i - q * ucols);
+    const uint32_t row_u = q / utaps;
+    const int t = (int)(q - row_u * utaps);
+    const int row = (int)row_u;
     const int co = transpose ? col : row, ci = transpose ? row : col;
     float v = 0.f;
     if (co < cout && ci < cin) {
-      const int64_t si = ((int64_t)co * cin + ci) * ntaps + t;
-      v = sdt == MYOLO_F16 ? (float)((const half_t*)src)[si] : ((const float*)src)[si];
+      const uint32_t si = ((uint32_t)co * (uint32_t)cin + (uint32_t)ci) * utaps + (uint32_t)t;
+      v = f16s ? (float)((const half_t*)src)[si] : ((const float*)src)[si];
     }
-    if (ddt == MYOLO_F16) ((half_t*)dst)[i] = (half_t)v; else ((float*)dst)[i] = v;
+    if (f16d) ((half_t*)dst)[i] = (half_t)v; else ((float*)dst)[i] = v;
   }
 }
 

@@ -17,6 +17,14 @@ inline bool vec_ok(const myolo_tensor* t) {
 
 // decode vector index -> (n, y, x, cg) for a tensor with G channel groups
 __device__ __forceinline__ void dec(int64_t v, int G, int W, int H, int& n, int& y, int& x, int& cg) {
+  if ((uint64_t)v < 0x80000000ull) {            // the usual case: three 32-bit divisions instead of three emulated 64-bit ones
+    uint32_t u = (uint32_t)v, q = u / (uint32_t)G;
+    cg = (int)(u - q * (uint32_t)G); u = q; q = u / (uint32_t)W;
+    x = (int)(u - q * (uint32_t)W); u = q; q = u / (uint32_t)H;
+    y = (int)(u - q * (uint32_t)H);
+    n = (int)q;
+    return;
+  }
   cg = (int)(v % G); v /= G;
   x = (int)(v % W); v /= W;
   y = (int)(v % H);
@@ -669,10 +677,12 @@ __global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_t
     float a[SEG];
 #pragma unroll
     for (int i = 0; i < SEG; ++i) a[i] = 0.f;
-    for (int by = 0; by < kb; ++by) {
+    // bins [floor(b*H/k), ceil((b+1)*H/k)) overlap by at most one pixel: only the bin y*k/H lands in and its two neighbours can hold y
+    const int byc = (int)(((uint32_t)y * (uint32_t)kb) / (uint32_t)gx.h), bxc = (int)(((uint32_t)xx * (uint32_t)kw) / (uint32_t)gx.w);
+    for (int by = byc > 0 ? byc - 1 : 0; by <= byc + 1 && by < kb; ++by) {
       const int y0 = (by * gx.h) / kb, y1 = ((by + 1) * gx.h + kb - 1) / kb;
       if (y < y0 || y >= y1) continue;
-      for (int bx = 0; bx < kw; ++bx) {
+      for (int bx = bxc > 0 ? bxc - 1 : 0; bx <= bxc + 1 && bx < kw; ++bx) {
         const int x0 = (bx * gx.w) / kw, x1 = ((bx + 1) * gx.w + kw - 1) / kw;
         if (xx < x0 || xx >= x1) continue;
         float f[SEG];

@@ -87,7 +87,9 @@ def test_train_forward_backward_vs_oracle(tag, dtype):
         noise['grad'] = max(rel(p16[k].grad, params[k].grad) for k in params)
 
     def tol_for(key, base):
-        return base if dtype == torch.float32 else max(base, 1.5 * noise[key])
+        # one fp16 run is one draw of that rounding noise (and the kernels' atomics reorder sums run to run): 2x the measured
+        # draw bounds it; at 1.5x the worst-conditioned BN gradient (own noise 12 %) failed about one run in ten
+        return base if dtype == torch.float32 else max(base, 2.0 * noise[key])
     # product
     xin = x.to(DEV, dtype)
     det, seg = m(xin)
