@@ -274,10 +274,11 @@ int myolo_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf,
  * pred: dense [batch, A, no] (xywh, obj, cls...), f16|f32 (arithmetic is fp32).  Workspaces (device, caller-owned):
  * counts int32[batch], cand float[batch][cap][6], cand_idx int32[batch][cap], sorted float[batch][max_nms][6];
  * cap >= A (A*nc when multi_label).  Results: out float[batch][max_det][6] = (x1,y1,x2,y2,conf,cls) in descending conf,
- * nkeep int32[batch]. */
+ * nkeep int32[batch].  class_mask: the `classes=` filter (general.py:476-477) as a bit set, bit j = keep class j; 0 = keep all
+ * (nc <= 64 when non-zero). */
 int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres, int multi_label,
               int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts, float* cand,
-              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, void* stream);
+              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, void* stream);
 
 #ifdef __cplusplus
 }

@@ -17,8 +17,9 @@ __device__ __forceinline__ float ldp(const void* p, int64_t i, int dt) {
   return dt == MYOLO_F16 ? (float)((const half_t*)p)[i] : ((const float*)p)[i];
 }
 
+// class_mask: bit j set = class j passes the `classes=` filter of general.py:476-477 (0 = no filter)
 __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int dt, int A, int no, float conf, int multi,
-                                                         int cap, int* counts, float* cand, int* cand_idx) {
+                                                         int cap, int* counts, float* cand, int* cand_idx, uint64_t class_mask) {
   const int b = blockIdx.y;
   const int nc = no - 5;
   for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
@@ -30,7 +31,7 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
     if (multi && nc > 1) {
       for (int j = 0; j < nc; ++j) {
         const float s = ldp(pred, row + 5 + j, dt) * obj;
-        if (s > conf) {
+        if (s > conf && (!class_mask || ((class_mask >> j) & 1ull))) {
           const int slot = atomicAdd(counts + b, 1);
           if (slot < cap) {
             float* c = cand + ((int64_t)b * cap + slot) * 6;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
         const float s = ldp(pred, row + 5 + j, dt) * obj;
         if (s > best) { best = s; bj = j; }                        // first maximum (torch.max)
       }
-      if (best > conf) {
+      if (best > conf && (!class_mask || ((class_mask >> bj) & 1ull))) {
         const int slot = atomicAdd(counts + b, 1);
         if (slot < cap) {
           float* c = cand + ((int64_t)b * cap + slot) * 6;
@@ -200,7 +201,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
 
 extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres,
                          int multi_label, int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts,
-                         float* cand, int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, void* stream) {
+                         float* cand, int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask,
+                         void* stream) {
+  if (class_mask && no - 5 > 64) return MYOLO_EINVAL;
   if (!pred || (dtype != MYOLO_F16 && dtype != MYOLO_F32) || batch < 1 || A < 1 || no < 6 || cap < 1 || max_det < 1 ||
       max_nms < 1 || max_nms > MAXW * 64 || !counts || !cand || !cand_idx || !sorted || !out || !nkeep)
     return MYOLO_EINVAL;
@@ -208,7 +211,7 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   hipError_t e = hipMemsetAsync(counts, 0, batch * sizeof(int32_t), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), 0, st, pred, dtype, A, no, conf_thres,
-                     multi_label, cap, counts, cand, cand_idx);
+                     multi_label, cap, counts, cand, cand_idx, class_mask);
   hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted);
   const int scan_smem = MAXW * 8 + 64 * 8 + 64 * 16 + LDS_BOXES * 16;
   static bool attr_set = false;

@@ -241,6 +241,15 @@ class PlannedModule(nn.Module):
     their version counters (in-place weight edits re-run the one-off epilogue constant preparation).  Replacing a Parameter
     OBJECT after the first forward is not detected: call invalidate_plans() (Model.fuse() does)."""
 
+    _RUNTIME_STATE = ('_plans', '_tensor_list', '_prepared_version', '_grad_reducer')
+
+    def __getstate__(self):
+        """pickling / deepcopy (checkpoints, ModelEMA) carries the module, not its launch plans (device buffers, ctypes descriptors)"""
+        d = self.__dict__.copy()
+        for k in self._RUNTIME_STATE:
+            d.pop(k, None)
+        return d
+
     def _tensors(self):
         ts = self.__dict__.get('_tensor_list')
         if ts is None:

@@ -51,8 +51,17 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     """general.py:421-509: list (one per image) of [n,6] tensors (x1, y1, x2, y2, conf, cls), descending conf, n <= 300.
     One batched launch sequence for all images; the only host synchronisation is reading the per-image keep counts.
     fp16 predictions are scored and intersected in fp32 (the reference multiplies cls*obj in the input dtype)."""
-    if classes is not None or (labels is not None and len(labels)):
-        raise NotImplementedError('classes= / labels= filtering (general.py:448-456,476-477) is not on the gfx950 hot path')
+    if labels is not None and len(labels):
+        raise NotImplementedError('labels= (auto-labelling priors, general.py:448-456) is not on the gfx950 hot path')
+    class_mask = 0
+    if classes is not None:                                       # general.py:476-477 (detect.py --classes)
+        cl = [int(c) for c in (classes.tolist() if torch.is_tensor(classes) else classes)]
+        if any(c < 0 or c >= 64 for c in cl) or prediction.shape[2] - 5 > 64:
+            raise _L.MyoloError('classes= filter supports class ids 0..63')
+        for c in cl:
+            class_mask |= 1 << c
+        if not cl:                                                # an empty filter keeps nothing
+            return [torch.zeros((0, 6), device=prediction.device, dtype=prediction.dtype) for _ in range(prediction.shape[0])]
     _L.require_gpu(prediction)
     if prediction.dim() != 3 or prediction.dtype not in (torch.float16, torch.float32):
         raise _L.MyoloError('prediction must be a [B,A,5+nc] fp16/fp32 tensor')
@@ -71,7 +80,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     nkeep = torch.empty(B, dtype=torch.int32, device=dev)
     _L.check(_L.lib().myolo_nms(_L.ptr(pred), _L.DT[pred.dtype], B, A, no, _C.c_float(conf_thres), _C.c_float(iou_thres),
                                 int(multi), int(bool(agnostic)), _C.c_float(max_wh), max_nms, max_det, cap, _L.ptr(counts),
-                                _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), _L.stream_ptr()),
+                                _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), class_mask, _L.stream_ptr()),
              'myolo_nms')
     n = nkeep.tolist()                                            # the one sync (the reference syncs per image, 446-495)
     return [out[i, :n[i]].to(prediction.dtype) for i in range(B)]

@@ -181,7 +181,10 @@ def nms_case(ref):
     out = {}
     pred = synth.synth_nms_pred(2, 3000, 10, seed=3)
     for name, kw in (('single', dict(conf_thres=0.25, iou_thres=0.45)),
-                     ('multi', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True))):
+                     ('multi', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)),
+                     ('classes', dict(conf_thres=0.25, iou_thres=0.45, classes=[2, 5, 7])),
+                     ('agnostic', dict(conf_thres=0.25, iou_thres=0.45, agnostic=True)),
+                     ('multi_classes', dict(conf_thres=0.05, iou_thres=0.6, multi_label=True, classes=[0, 9]))):
         res = ref.general.non_max_suppression(pred.clone(), **kw)
         for i, r in enumerate(res):
             out[f'{name}_{i}'] = r.numpy()

@@ -28,7 +28,7 @@ def greedy_nms(boxes, scores, thr):
 
 
 def non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False, max_wh=4096, max_det=300,
-                        max_nms=30000):
+                        max_nms=30000, classes=None, agnostic=False):
     """pred: [B,A,5+nc] float32 (xywh, obj, cls).  Returns list of [n,6] (xyxy, conf, cls) float32."""
     pred = np.asarray(pred, np.float32)
     nc = pred.shape[2] - 5
@@ -49,11 +49,13 @@ def non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False
             j = x[:, 5:].argmax(1)
             conf = x[np.arange(len(x)), 5 + j]
             x = np.concatenate((box, conf[:, None], j[:, None].astype(np.float32)), 1)[conf > conf_thres]
+        if classes is not None:                                       # 476-477 class filter
+            x = x[np.isin(x[:, 5].astype(np.int64), np.asarray(classes, np.int64))]
         if not len(x):
             out.append(np.zeros((0, 6), np.float32)); continue
         if len(x) > max_nms:                                          # 487-488
             x = x[np.argsort(-x[:, 4], kind='stable')[:max_nms]]
-        c = x[:, 5:6] * max_wh                                        # 491-492 class offset
+        c = x[:, 5:6] * (0 if agnostic else max_wh)                   # 491-492 class offset
         keep = greedy_nms(x[:, :4] + c, x[:, 4], iou_thres)[:max_det]  # 493-495
         out.append(x[keep].astype(np.float32))
     return out

@@ -148,3 +148,24 @@ def test_amp_training_steps_run_and_learn():
     assert float((m.model[1].conv.weight - w0).abs().max()) > 0
     assert float((ema.ema.model[1].conv.weight - e0).abs().max()) > 0
     assert seg_losses[-1] < seg_losses[0]                    # the same batch three times: the loss goes down
+
+
+def test_attempt_load_reference_checkpoint_matches_reference_outputs():
+    """models/experimental.attempt_load on a checkpoint pickled by the real reference classes (tests/golden/ref_tiny_ckpt.pt,
+    oracle/make_ckpt_fixture.py): the fused fp32 eval forward reproduces what the reference itself computes from that file
+    (EMA weights; decoded boxes [1,A,15] and class logits), and an Ensemble of two copies concatenates the detections"""
+    from multiyolov5_amd.models import experimental as X
+    ck = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'ref_tiny_ckpt')
+    g = np.load(ck + '.npz')
+    m = X.attempt_load(ck + '.pt', map_location=DEV)
+    x = synth.synth_images(1, 64, 128, seed=3).to(DEV)
+    with torch.no_grad():
+        det, seg = m(x)
+    segs = seg if isinstance(seg, (list, tuple)) else [seg]
+    check('ckpt/z', det[0], g['z'], 2e-4)
+    check('ckpt/seg', segs[0][:, :, ::4, ::4], g['seg'], 2e-4, atol=1e-3)
+    e = X.attempt_load([ck + '.pt', ck + '.pt'], map_location=DEV)
+    with torch.no_grad():
+        y, none = e(x)
+    assert none is None and y.shape[1] == 2 * g['z'].shape[1]
+    check('ckpt/ensemble', y[:, :g['z'].shape[1]], g['z'], 2e-4)

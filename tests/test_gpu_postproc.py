@@ -21,12 +21,17 @@ def _same(got, ref, name):
     np.testing.assert_array_equal(got, ref, err_msg=name)
 
 
-@pytest.mark.parametrize('mode', ['single', 'multi'])
+NMS_MODES = {'single': dict(conf_thres=0.25, iou_thres=0.45), 'multi': dict(conf_thres=0.001, iou_thres=0.6, multi_label=True),
+             'classes': dict(conf_thres=0.25, iou_thres=0.45, classes=[2, 5, 7]), 'agnostic': dict(conf_thres=0.25, iou_thres=0.45, agnostic=True),
+             'multi_classes': dict(conf_thres=0.05, iou_thres=0.6, multi_label=True, classes=[0, 9])}
+
+
+@pytest.mark.parametrize('mode', list(NMS_MODES))
 def test_nms_matches_reference_golden(mode):
     from multiyolov5_amd.utils.general import non_max_suppression
     g = golden('nms')
     pred = synth.synth_nms_pred(2, 3000, 10, seed=3).to(DEV)
-    kw = dict(conf_thres=0.25, iou_thres=0.45) if mode == 'single' else dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)
+    kw = NMS_MODES[mode]
     out = non_max_suppression(pred, **kw)
     assert len(out) == 2
     for i, o in enumerate(out):

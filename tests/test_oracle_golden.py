@@ -124,7 +124,10 @@ def test_nms_restatement():
     g = golden('nms')
     pred = synth.synth_nms_pred(2, 3000, 10, seed=3).numpy()
     for name, kw in (('single', dict(conf_thres=0.25, iou_thres=0.45)),
-                     ('multi', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True))):
+                     ('multi', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True)),
+                     ('classes', dict(conf_thres=0.25, iou_thres=0.45, classes=[2, 5, 7])),
+                     ('agnostic', dict(conf_thres=0.25, iou_thres=0.45, agnostic=True)),
+                     ('multi_classes', dict(conf_thres=0.05, iou_thres=0.6, multi_label=True, classes=[0, 9]))):
         res = nms_ref.non_max_suppression(pred, **kw)
         for i, r in enumerate(res):
             ref = g[f'{name}_{i}']
