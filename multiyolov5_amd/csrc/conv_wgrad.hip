@@ -522,7 +522,12 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   const int out_tiles = k.tiles_co * k.tiles_ci * (fused ? 1 : k.ntaps);
   int ks = d->ksplit;
   if (ks <= 0) {
-    ks = ((fused ? 512 : 1024) + out_tiles - 1) / out_tiles;  // aim at ~1024 workgroups (512 of the 9x heavier fused ones)
+    static const int tgt_fused = getenv("MYOLO_WGRAD_WG_FUSED") ? atoi(getenv("MYOLO_WGRAD_WG_FUSED")) : 128;
+    static const int tgt_tap = getenv("MYOLO_WGRAD_WG") ? atoi(getenv("MYOLO_WGRAD_WG")) : 256;
+    // Few, long-lived workgroups: these kernels run on the side stream BESIDE the dgrad / BatchNorm chain, so they need not fill the
+    // chip, and every extra split costs a [taps][64][64] fp32 partial tile (written + re-read, or 4096 atomics per tap): measured
+    // on the yolov5s step 1024/512 workgroups -> 256/128: 11.29 -> 10.63 ms; 128/64: 11.26 ms (the tail of the last layers shows).
+    ks = ((fused ? tgt_fused : tgt_tap) + out_tiles - 1) / out_tiles;
     const int max_ks = (int)((M + 8 * KP - 1) / (8 * KP));    // but at least 8 K-steps each
     if (ks > max_ks) ks = max_ks;
     if (ks < 1) ks = 1;
