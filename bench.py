@@ -258,10 +258,12 @@ def main():
         if not args.no_kernel_timing:
             b, f, t, n = conv_kernel_timing(tr)
             traffic, tsrc = None, None
-            pmc = os.path.join(ROOT, 'profiles', 'r1_pmc.json')        # separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh)
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+            pmc = cands[-1] if cands else ''        # newest separate rocprofv3 --pmc passes (scripts/gpu_pmc.sh + scripts/pmc_summary.py)
             if os.path.exists(pmc) and args.batch == 16 and tuple(args.img) == (512, 1024) and args.dtype == 'f16':
                 rec = json.load(open(pmc))
-                traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/r1_pmc.json: ' + rec['source']
+                traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/' + os.path.basename(pmc) + ': ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
                                'kernel': 'myolo_conv launches of one step: conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad)',
