@@ -56,14 +56,16 @@ class GradReducer:
             ev.record()
             self.stream.wait_event(ev)
             with torch.cuda.stream(self.stream):
-                if dist.get_backend(self.group) == 'nccl':           # RCCL
-                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-                else:                                                # gloo on device tensors (single-GPU smoke tests): no AVG
+                # DDP's recipe (pre-divide, then SUM): does not depend on the backend offering ReduceOp.AVG; /world is exact in
+                # fp32 for the power-of-two worlds of an 8-GPU node
+                view.mul_(1.0 / self.world)
+                if dist.get_backend(self.group) == 'nccl':           # RCCL: asynchronous on its own stream
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                else:                                                # gloo on device tensors (single-GPU smoke tests)
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                    view.div_(self.world)
-        else:                                           # gloo (CPU tests): no AVG
+        else:                                           # gloo (CPU tests)
+            view.mul_(1.0 / self.world)
             dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-            view.div_(self.world)
 
     def finish(self, flat):
         """make the current stream wait for every outstanding slice."""
