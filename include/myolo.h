@@ -280,6 +280,19 @@ int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_
               int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts, float* cand,
               int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, void* stream);
 
+/* ---- detect.py frame pipeline ------------------------------------------------- */
+/* uint8 HWC frame (h0 x w0 x 3) -> model input [1,3,H,W] NCHW f16|f32: constant border placement at (top,left) = the padding half of
+ * `letterbox` (utils/datasets.py:840-847, no resampling), channel reversal `img[:, :, ::-1].transpose(2, 0, 1)` (datasets.py:185) when
+ * swap_rb, and detect.py:136-137's uint8 -> dtype -> /255 through lut256 (device, 256 values of out_dtype, supplied by the caller
+ * as torch computes them: bit-identical normalisation). */
+int myolo_frame_pack(const uint8_t* frame_hwc, int h0, int w0, int swap_rb, int top, int left, int H, int W, int pad_value,
+                     void* out_nchw, int out_dtype, const void* lut256, void* stream);
+/* detect.py:193-194: mask = colormap[label] (channel-reversed when swap_rb = `label2image(...)[:, :, ::-1]`), dst =
+ * cv2.addWeighted(mask, alpha, im0, beta, gamma) on uint8 (float32 products and sums rounded separately, round-half-even,
+ * saturated).  labels u8|i64 [h,w] (clamped to [0,ncls)); colormap_rgb device uint8[ncls][3]; mask_hwc / dst_hwc: either may be NULL. */
+int myolo_seg_blend(const void* labels, int label_dtype, const uint8_t* im0_hwc, int h, int w, const uint8_t* colormap_rgb, int ncls,
+                    int swap_rb, float alpha, float beta, float gamma, uint8_t* mask_hwc, uint8_t* dst_hwc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,57 @@
+"""CPU restatement (TEST INFRASTRUCTURE) of detect.py's per-frame host steps, numpy only:
+
+* `frame_to_input` -- utils/datasets.py:818-848 `letterbox` (border branch; cv2.copyMakeBorder BORDER_CONSTANT restated as a constant
+  fill -- cv2 is not installed: "parity unpinned" for that one call, whose semantics are a plain fill), datasets.py:185
+  `img[:, :, ::-1].transpose(2, 0, 1)`, detect.py:135-139 `torch.from_numpy(img).half()/float(); img /= 255.0; unsqueeze(0)`
+  (this part IS the reference's own torch code, executed here on CPU).
+* `seg_overlay` -- detect.py:69-72 `label2image` (numpy fancy indexing, as the reference) + `[:, :, ::-1]` + cv2.addWeighted restated from
+  its documented definition dst = saturate(round(src1*alpha + src2*beta + gamma)) in float32 with round-half-even ("parity
+  unpinned": cv2 absent; exact .5 ties are the only place an implementation could differ).
+"""
+import numpy as np
+import torch
+
+
+def letterbox(img, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True, stride=32):
+    shape = img.shape[:2]
+    if isinstance(new_shape, int):
+        new_shape = (new_shape, new_shape)
+    r = min(new_shape[0] / shape[0], new_shape[1] / shape[1])
+    if not scaleup:
+        r = min(r, 1.0)
+    ratio = r, r
+    new_unpad = int(round(shape[1] * r)), int(round(shape[0] * r))
+    dw, dh = new_shape[1] - new_unpad[0], new_shape[0] - new_unpad[1]
+    if auto:
+        dw, dh = np.mod(dw, stride), np.mod(dh, stride)
+    elif scaleFill:
+        dw, dh = 0.0, 0.0
+        new_unpad = (new_shape[1], new_shape[0])
+        ratio = new_shape[1] / shape[1], new_shape[0] / shape[0]
+    dw /= 2
+    dh /= 2
+    if shape[::-1] != new_unpad:
+        raise NotImplementedError('cv2.resize branch')
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    out = np.empty((shape[0] + top + bottom, shape[1] + left + right, 3), np.uint8)
+    out[...] = np.array(color, np.uint8)
+    out[top:top + shape[0], left:left + shape[1]] = img
+    return out, ratio, (dw, dh)
+
+
+def frame_to_input(im0, new_shape=640, stride=32, auto=True, half=True):
+    img, ratio, pad = letterbox(im0, new_shape, stride=stride, auto=auto)
+    img = np.ascontiguousarray(img[:, :, ::-1].transpose(2, 0, 1))
+    t = torch.from_numpy(img)
+    t = t.half() if half else t.float()
+    t /= 255.0
+    return t.unsqueeze(0), ratio, pad
+
+
+def seg_overlay(labels, im0, colormap, alpha=0.4, beta=0.6, gamma=0.0):
+    cm = np.array(colormap, dtype='uint8')
+    mask = cm[labels.astype('int32'), :][:, :, ::-1]
+    t = (mask.astype(np.float32) * np.float32(alpha) + im0.astype(np.float32) * np.float32(beta)) + np.float32(gamma)
+    dst = np.clip(np.rint(t), 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(mask), dst

@@ -106,3 +106,16 @@ def test_plan_dry_build_on_cpu(tag, training):
         nf = sum(len(o.fwd_calls) for o in h.plan.ops)
         nb = sum(len(o.bwd_calls) for o in h.plan.ops)
         assert nf > 70 and (nb > nf if training else nb == 0)
+
+
+def test_letterbox_geometry_matches_restatement():
+    """host logic of utils/datasets.letterbox_params (datasets.py:818-846) vs the oracle's pixel-moving letterbox"""
+    import numpy as np
+    from multiyolov5_amd.utils.datasets import letterbox_params
+    from oracle import frame_ref
+    for shape, ns, auto in (((1024, 2048), 2048, True), ((1000, 2048), 2048, True), ((37, 64), 64, True), ((64, 50), 64, False),
+                            ((480, 640), 640, True), ((640, 640), (640, 640), False)):
+        new_unpad, ratio, pad, (t, b, l, r) = letterbox_params(shape, ns, auto=auto, stride=32)
+        assert tuple(new_unpad) == (shape[1], shape[0])
+        img, rratio, rpad = frame_ref.letterbox(np.zeros(shape + (3,), np.uint8), ns, auto=auto, stride=32)
+        assert ratio == rratio and tuple(pad) == tuple(rpad) and img.shape[:2] == (shape[0] + t + b, shape[1] + l + r)

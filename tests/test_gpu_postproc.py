@@ -127,3 +127,53 @@ def test_seg_metrics_match_reference_golden_and_oracle():
     assert (int(c2), int(l2)) == (int(rc), int(rl))
     np.testing.assert_array_equal(i2, ri)
     np.testing.assert_array_equal(u2, ru)
+
+
+@pytest.mark.parametrize('half', [True, False], ids=['f16', 'f32'])
+@pytest.mark.parametrize('shape,new_shape', [((1024, 2048), 2048), ((1000, 2048), 2048), ((37, 64), 64), ((64, 50), 64)])
+def test_frame_to_input_matches_reference_steps(shape, new_shape, half):
+    """letterbox border + BGR->RGB + HWC->CHW + /255 (datasets.py:818-848,185; detect.py:135-139) in one kernel: bit-identical to
+    the reference's own numpy/torch steps (oracle.frame_ref), incl. odd padding splits"""
+    from multiyolov5_amd.utils.datasets import frame_to_input
+    from oracle import frame_ref
+    rs = np.random.RandomState(shape[0])
+    im0 = rs.randint(0, 256, (shape[0], shape[1], 3)).astype(np.uint8)
+    ref, rratio, rpad = frame_ref.frame_to_input(im0, new_shape, stride=32, half=half)
+    got, ratio, pad = frame_to_input(torch.from_numpy(im0).to(DEV), new_shape, stride=32, half=half)
+    assert ratio == rratio and tuple(pad) == tuple(rpad) and got.shape == ref.shape and got.dtype == ref.dtype
+    if half:
+        assert torch.equal(got.cpu(), ref)
+    else:
+        # fp32 `img /= 255.0`: torch's GPU kernel multiplies by the reciprocal, its CPU kernel divides -- the last bit can differ.  The
+        # product takes its 256 values from torch on the device (what detect.py computes on a GPU); vs the CPU oracle: <= 1 ulp, and
+        # exactly the device's own `arange(256)/255` table
+        assert float((got.cpu() - ref).abs().max()) <= 2.0 ** -24
+        lut = torch.arange(256, device=DEV, dtype=torch.uint8).float()
+        lut /= 255.0
+        from oracle import frame_ref as fr
+        boxed, _, _ = fr.letterbox(im0, new_shape, stride=32)
+        idx = torch.from_numpy(np.ascontiguousarray(boxed[:, :, ::-1].transpose(2, 0, 1))).long().to(DEV)
+        assert torch.equal(got[0], lut[idx])
+
+
+def test_frame_to_input_rejects_resampling():
+    from multiyolov5_amd.utils.datasets import frame_to_input
+    with pytest.raises(NotImplementedError):
+        frame_to_input(torch.zeros(720, 1280, 3, dtype=torch.uint8, device=DEV), 640)
+
+
+@pytest.mark.parametrize('ldt', [torch.uint8, torch.int64], ids=['u8', 'i64'])
+def test_seg_overlay_matches_reference_steps(ldt):
+    """label2image + [:, :, ::-1] + addWeighted(mask, 0.4, im0, 0.6, 0) (detect.py:69-72,193-194): bit-identical bytes"""
+    from multiyolov5_amd.utils.plots import Cityscapes_COLORMAP, label2image, seg_overlay
+    from oracle import frame_ref
+    rs = np.random.RandomState(5)
+    h, w = 203, 517
+    labels = rs.randint(0, 19, (h, w))
+    im0 = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    rmask, rdst = frame_ref.seg_overlay(labels, im0, Cityscapes_COLORMAP)
+    mask, dst = seg_overlay(torch.from_numpy(labels).to(DEV, ldt), torch.from_numpy(im0).to(DEV))
+    np.testing.assert_array_equal(mask.cpu().numpy(), rmask)
+    np.testing.assert_array_equal(dst.cpu().numpy(), rdst)
+    rgb = label2image(torch.from_numpy(labels).to(DEV, ldt))
+    np.testing.assert_array_equal(rgb.cpu().numpy(), rmask[:, :, ::-1])
