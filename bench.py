@@ -90,6 +90,8 @@ class Trainer:
         self.imgs = synth.images(B, H, W, seed=1 + rank).to(dev, self.dtype)
         self.targets = synth.det_targets(B, 8, nc, seed=1 + rank).to(dev)
         self.mask = synth.seg_targets(B, H, W, 19, seed=1 + rank).to(dev)
+        self.segimgs = None                             # second, independent batch of the train.py-faithful step (lazily)
+        self.ni = 0
         if args.stage == 'train':
             from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
             from multiyolov5_amd.utils.optim import FusedSGD, GradScaler
@@ -146,6 +148,49 @@ class Trainer:
         if self.ema is not None:
             self.ema.update(m)                                           # train.py:400-401
         self.last = (loss, segloss)
+
+
+def train_py_step(tr):
+    """one iteration of the reference's loop body as written (train.py:364-401): detection pass (forward, ComputeLoss, backward)
+    on one batch, segmentation pass (forward, CE * batch_size, backward) on a second independent batch, optimizer / EMA every
+    `accumulate = max(round(64 / total_batch), 1)` iterations (train.py:140,396-401).  SURVEY 8(d) "training image" definition (ii)."""
+    a, m, B = tr.args, tr.model, tr.args.batch
+    if tr.segimgs is None:
+        from multiyolov5_amd import synth
+        tr.segimgs = synth.images(B, a.img[0], a.img[1], seed=101).to(tr.dev, tr.dtype)
+        tr.accumulate = max(round(64 / (B * tr.world)), 1)
+    pred = m(tr.imgs)
+    loss, _ = tr.compute_loss(pred[0], tr.targets)
+    if tr.world > 1:
+        loss = loss * tr.world
+    tr.scaler.scale(loss * 0.6).backward()
+    pred = m(tr.segimgs)
+    segloss = tr.compute_seg_loss(pred[1], tr.mask) * B * 0.35
+    tr.scaler.scale(segloss).backward()
+    if tr.reducer is not None:
+        tr.reducer.wait()
+    tr.ni += 1
+    if tr.ni % tr.accumulate == 0:
+        tr.scaler.step(tr.opt)
+        tr.scaler.update()
+        tr.opt.zero_grad()
+        if tr.ema is not None:
+            tr.ema.update(m)
+
+
+def train_py_rate(tr, iters=8, warm=4):
+    for _ in range(warm):
+        train_py_step(tr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        train_py_step(tr)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    B = tr.args.batch * tr.world
+    return {'pairs_per_s': B / dt, 'images_per_s': 2 * B / dt, 'ms_per_iteration': dt * 1e3, 'accumulate': tr.accumulate,
+            'what': 'train.py:364-401 as written: det pass + seg pass (two forward+backward on two batches) per iteration, optimizer '
+                    'and EMA every `accumulate` iterations; a pair = one detection image + one segmentation image'}
 
 
 def conv_kernel_timing(trainer, nsteps=3):
@@ -277,6 +322,11 @@ def main():
                                      'workload': 'pspv5s fused fp16 1x3x1024x2048 fwd + NMS(129024 cand) + x8 upsample+argmax'}
             except Exception as e:                       # the secondary metric must not take the primary line down
                 out['detect_fps'] = {'value': None, 'error': repr(e)}
+        if args.stage == 'train' and not args.no_infer:
+            try:                                         # SURVEY 8(d) definition (ii); secondary, must not take the primary line down
+                out['train_py_step'] = train_py_rate(tr)
+            except Exception as e:
+                out['train_py_step'] = {'pairs_per_s': None, 'error': repr(e)}
         if args.stage == 'train' and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:
