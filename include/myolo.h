@@ -280,6 +280,13 @@ int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_
               int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts, float* cand,
               int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, void* stream);
 
+/* test.py:230-262 (true-positive matrix of one image, the input of ap_per_class): pred [n][6] = (x1,y1,x2,y2,conf,cls) in NMS order and
+ * labels [m][5] = (cls,x1,y1,x2,y2), native image space, device float32; iouv device float[niou] (test.py:98 linspace(0.5,0.95,10));
+ * correct device uint8 [n][niou].  ws: device scratch, 8-byte aligned, >= 8*n + 16*ceil(m/16) bytes.  box_iou arithmetic of
+ * utils/general.py:388-410 in its evaluation order (fp32, IEEE division); no host synchronisation. */
+int myolo_match_predictions(const float* pred, int n, const float* labels, int m, const float* iouv, int niou, uint8_t* correct,
+                            void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- detect.py frame pipeline ------------------------------------------------- */
 /* uint8 HWC frame (h0 x w0 x 3) -> model input [1,3,H,W] NCHW f16|f32: constant border placement at (top,left) = the padding half of
  * `letterbox` (utils/datasets.py:840-847, no resampling), channel reversal `img[:, :, ::-1].transpose(2, 0, 1)` (datasets.py:185) when

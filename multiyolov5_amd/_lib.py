@@ -107,6 +107,7 @@ _PROTOS = {
     'myolo_mt_check_finite': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, P, P]),
     'myolo_mt_ema': (C.c_int, [P, P, C.c_int, C.c_int, C.c_float, P]),
     'myolo_scaler_update': (C.c_int, [P, P, P, C.c_float, C.c_float, C.c_int, P]),
+    'myolo_match_predictions': (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_int, P, P, C.c_int64, P]),
     'myolo_frame_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P]),
     'myolo_seg_blend': (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P, P, P]),
     'myolo_nms': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,

@@ -225,3 +225,64 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// test.py:230-262: which predictions of ONE image count as true positives at each IoU threshold.  pred [n][6] = (x1,y1,x2,y2,conf,
+// cls) in NMS order, labels [m][5] = (cls, x1,y1,x2,y2), both in native image space.  Per target class, predictions of that class
+// are visited in order; a prediction whose best-IoU target (utils/general.py:388-410 box_iou, first maximum) exceeds iouv[0] and
+// is not yet taken takes it and gets correct[j][k] = iou > iouv[k].  The reference walks this with one .item() sync per detection.
+namespace {
+__global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ pred, int n, const float* __restrict__ labels, int m,
+                                                    const float* __restrict__ iouv, int niou, uint8_t* __restrict__ correct,
+                                                    float* best_iou, int* best_t, uint8_t* taken) {
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const float* p = pred + (int64_t)j * 6;
+    const float x1 = p[0], y1 = p[1], x2 = p[2], y2 = p[3], cls = p[5];
+    const float area1 = (x2 - x1) * (y2 - y1);
+    float best = -1.f;
+    int bt = -1;
+    for (int t = 0; t < m; ++t) {
+      const float* l = labels + (int64_t)t * 5;
+      if (l[0] != cls) continue;
+      const float area2 = (l[3] - l[1]) * (l[4] - l[2]);
+      float iw = fminf(x2, l[3]) - fmaxf(x1, l[1]), ih = fminf(y2, l[4]) - fmaxf(y1, l[2]);
+      iw = iw > 0.f ? iw : 0.f;
+      ih = ih > 0.f ? ih : 0.f;
+      const float inter = __fmul_rn(iw, ih);
+      const float iou = __fdiv_rn(inter, __fsub_rn(__fadd_rn(area1, area2), inter));
+      if (bt < 0 || iou > best) { best = iou; bt = t; }             // torch.max(1): first maximum
+    }
+    best_iou[j] = best;
+    best_t[j] = bt;
+    for (int k = 0; k < niou; ++k) correct[(int64_t)j * niou + k] = 0;
+  }
+  for (int t = threadIdx.x; t < m; t += blockDim.x) taken[t] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float thr0 = iouv[0];
+    for (int j = 0; j < n; ++j) {
+      const int t = best_t[j];
+      const float iou = best_iou[j];
+      if (t < 0 || !(iou > thr0) || taken[t]) continue;
+      taken[t] = 1;
+      for (int k = 0; k < niou; ++k) correct[(int64_t)j * niou + k] = iou > iouv[k] ? 1 : 0;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int myolo_match_predictions(const float* pred, int n, const float* labels, int m, const float* iouv, int niou,
+                                       uint8_t* correct, void* ws, int64_t ws_bytes, void* stream) {
+  if (n < 0 || m < 0 || niou < 1 || !iouv || (n > 0 && (!pred || !correct)) || (m > 0 && !labels)) return MYOLO_EINVAL;
+  if (n == 0) return 0;
+  const int64_t need = (int64_t)n * 8 + ((m + 15) / 16) * 16;
+  if (!ws || ws_bytes < need || ((uintptr_t)ws & 7)) return MYOLO_EINVAL;
+  float* best_iou = reinterpret_cast<float*>(ws);
+  int* best_t = reinterpret_cast<int*>(best_iou + n);
+  uint8_t* taken = reinterpret_cast<uint8_t*>(best_t + n);
+  hipLaunchKernelGGL(match_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, pred, n, labels, m, iouv, niou, correct, best_iou, best_t,
+                     taken);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+

@@ -47,3 +47,25 @@ def batch_intersection_union(output, target, nclass):   # metrics.py:252-275
     _, _, inter, union = seg_counts(output, target, nclass)
     assert (inter <= union).all(), 'Intersection area should be smaller than Union area'
     return inter, union
+
+
+def match_predictions(predn, labels, iouv):
+    """test.py:230-262 for one image on the device: predn [n,6] = (xyxy, conf, cls) in native image space and NMS order, labels [m,5] =
+    (cls, xyxy) native; iouv [niou] (test.py:98).  Returns `correct` bool [n, niou] (the per-image input of `ap_per_class`, test.py:
+    265,270).  The reference walks the candidates with one `.item()` per detection; here it is one launch without a sync."""
+    L.require_gpu(predn)
+    n, m = int(predn.shape[0]), int(labels.shape[0])
+    iouv = iouv.to(device=predn.device, dtype=torch.float32).contiguous()
+    niou = int(iouv.numel())
+    correct = torch.zeros(n, niou, dtype=torch.uint8, device=predn.device)
+    if n == 0 or m == 0:
+        return correct.bool()
+    if predn.shape[1] != 6 or labels.shape[1] != 5:
+        raise L.MyoloError('predn must be [n,6] (xyxy, conf, cls) and labels [m,5] (cls, xyxy)')
+    p = predn.to(torch.float32).contiguous()
+    l = labels.to(device=predn.device, dtype=torch.float32).contiguous()
+    ws = torch.empty(n * 8 + (m + 15) // 16 * 16, dtype=torch.uint8, device=predn.device)
+    L.check(L.lib().myolo_match_predictions(L.ptr(p), n, L.ptr(l), m, L.ptr(iouv), niou, L.ptr(correct), L.ptr(ws), ws.numel(),
+                                            L.stream_ptr()), 'myolo_match_predictions')
+    return correct.bool()
+

@@ -207,11 +207,47 @@ def metrics_case(ref):
     print('wrote metrics', int(correct), int(labeled))
 
 
+def match_inputs(seed, n_lab=40, n_fp=60, nc=10, W=2048, H=1024):
+    """labels [m,5] (cls, xyxy) and NMS-ordered predictions [n,6] (xyxy, conf, cls): jittered copies of the labels (2 per label, so
+    duplicates compete for a target), class-confused copies and random false positives"""
+    rs = np.random.RandomState(seed)
+    cx, cy = rs.uniform(50, W - 50, n_lab), rs.uniform(50, H - 50, n_lab)
+    w, h = rs.uniform(20, 300, n_lab), rs.uniform(20, 200, n_lab)
+    lab = np.stack([rs.randint(0, nc, n_lab).astype(np.float32), cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1).astype(np.float32)
+    preds = []
+    for rep, jit in ((0, 0.03), (1, 0.12), (2, 0.3)):
+        j = lab[:, 1:5] + rs.normal(0, 1, (n_lab, 4)).astype(np.float32) * jit * np.stack([w, h, w, h], 1).astype(np.float32)
+        cls = lab[:, 0].copy()
+        if rep == 2:
+            flip = rs.uniform(size=n_lab) < 0.3
+            cls[flip] = (cls[flip] + 1) % nc
+        preds.append(np.concatenate([j, rs.uniform(0.05, 1, (n_lab, 1)).astype(np.float32), cls[:, None]], 1))
+    fx, fy = rs.uniform(0, W - 100, n_fp), rs.uniform(0, H - 100, n_fp)
+    fp = np.stack([fx, fy, fx + rs.uniform(10, 200, n_fp), fy + rs.uniform(10, 200, n_fp), rs.uniform(0.05, 1, n_fp),
+                   rs.randint(0, nc + 2, n_fp)], 1).astype(np.float32)
+    p = np.concatenate(preds + [fp], 0).astype(np.float32)
+    p = p[np.argsort(-p[:, 4], kind='stable')]
+    return torch.from_numpy(p), torch.from_numpy(lab)
+
+
+def match_case(ref):
+    from . import metrics_ref
+    out = {}
+    iouv = torch.linspace(0.5, 0.95, 10)                        # test.py:98
+    for i, seed in enumerate((1, 2, 3)):
+        p, l = match_inputs(seed, n_lab=(40, 7, 120)[i])
+        assert torch.equal(metrics_ref.box_iou(p[:, :4], l[:, 1:5]), ref.general.box_iou(p[:, :4], l[:, 1:5]))
+        c = metrics_ref.match_predictions(p, l, iouv, iou_fn=ref.general.box_iou)      # test.py:230-262 around the reference's box_iou
+        out[f'pred_{i}'], out[f'labels_{i}'], out[f'correct_{i}'] = p.numpy(), l.numpy(), c.numpy()
+        print('match', i, p.shape[0], l.shape[0], int(c[:, 0].sum()), int(c[:, -1].sum()))
+    np.savez_compressed(os.path.join(GOLD, 'match.npz'), iouv=iouv.numpy(), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics']
+    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics', 'match']
     if 'models' in which:
         model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
         model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
@@ -224,6 +260,8 @@ def main():
         nms_case(ref)
     if 'metrics' in which:
         metrics_case(ref)
+    if 'match' in which:
+        match_case(ref)
 
 
 if __name__ == '__main__':

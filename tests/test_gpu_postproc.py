@@ -177,3 +177,19 @@ def test_seg_overlay_matches_reference_steps(ldt):
     np.testing.assert_array_equal(dst.cpu().numpy(), rdst)
     rgb = label2image(torch.from_numpy(labels).to(DEV, ldt))
     np.testing.assert_array_equal(rgb.cpu().numpy(), rmask[:, :, ::-1])
+
+
+def test_match_predictions_matches_reference_golden():
+    """test.py:230-262 (true-positive matrix per image) in one launch: bit-identical to the golden built around the reference's own
+    box_iou, incl. duplicate detections competing for one target, class-confused detections and classes without targets"""
+    from multiyolov5_amd.utils.metrics import match_predictions
+    g = golden('match')
+    iouv = torch.from_numpy(g['iouv']).to(DEV)
+    for i in range(3):
+        p, l = torch.from_numpy(g[f'pred_{i}']).to(DEV), torch.from_numpy(g[f'labels_{i}']).to(DEV)
+        c = match_predictions(p, l, iouv)
+        assert c.dtype == torch.bool and tuple(c.shape) == (p.shape[0], 10)
+        np.testing.assert_array_equal(c.cpu().numpy(), g[f'correct_{i}'], err_msg=f'match/{i}')
+    # no predictions / no labels: all-false matrices of the right shape
+    assert tuple(match_predictions(torch.zeros(0, 6, device=DEV), l, iouv).shape) == (0, 10)
+    assert not match_predictions(p, torch.zeros(0, 5, device=DEV), iouv).any()

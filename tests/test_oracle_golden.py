@@ -151,3 +151,15 @@ def test_metrics_restatement_matches_reference_golden():
     assert int(c) == int(g['correct']) and int(l) == int(g['labeled'])
     np.testing.assert_array_equal(i, g['inter'])
     np.testing.assert_array_equal(u, g['union'])
+
+
+def test_match_predictions_restatement():
+    """test.py:230-262 restated (oracle.metrics_ref) vs the golden made around the reference's own utils.general.box_iou"""
+    from oracle import metrics_ref
+    g = golden('match')
+    iouv = torch.from_numpy(g['iouv'])
+    for i in range(3):
+        p, l = torch.from_numpy(g[f'pred_{i}']), torch.from_numpy(g[f'labels_{i}'])
+        c = metrics_ref.match_predictions(p, l, iouv)
+        assert np.array_equal(c.numpy(), g[f'correct_{i}'])
+        assert c.any(0).all() or i == 1                     # every IoU threshold has true positives (tiny case 1 may not)
