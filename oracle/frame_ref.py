@@ -1,7 +1,7 @@
 """CPU restatement (TEST INFRASTRUCTURE) of detect.py's per-frame host steps, numpy only:
 
-* `frame_to_input` -- utils/datasets.py:818-848 `letterbox` (border branch; cv2.copyMakeBorder BORDER_CONSTANT restated as a constant
-  fill -- cv2 is not installed: "parity unpinned" for that one call, whose semantics are a plain fill), datasets.py:185
+* `frame_to_input` -- utils/datasets.py:818-848 `letterbox` (border branch; pinned by tests/golden/letterbox.npz, written by running the
+  reference's own letterbox with cv2.copyMakeBorder BORDER_CONSTANT served by a numpy constant fill -- cv2 is not installed), datasets.py:185
   `img[:, :, ::-1].transpose(2, 0, 1)`, detect.py:135-139 `torch.from_numpy(img).half()/float(); img /= 255.0; unsqueeze(0)`
   (this part IS the reference's own torch code, executed here on CPU).
 * `seg_overlay` -- detect.py:69-72 `label2image` (numpy fancy indexing, as the reference) + `[:, :, ::-1]` + cv2.addWeighted restated from

@@ -243,11 +243,36 @@ def match_case(ref):
     np.savez_compressed(os.path.join(GOLD, 'match.npz'), iouv=iouv.numpy(), **out)
 
 
+def letterbox_case(ref):
+    """geometry (and border pixels) of the reference's own utils.datasets.letterbox for frames that need no resampling; cv2 is not
+    installed, so its one call on that branch (copyMakeBorder BORDER_CONSTANT) is served by a numpy constant fill"""
+    cv2 = sys.modules['cv2']
+
+    def copy_make_border(img, top, bottom, left, right, border_type, value=(0, 0, 0)):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), img.dtype)
+        out[...] = np.array(value, img.dtype)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+    cv2.copyMakeBorder, cv2.BORDER_CONSTANT, cv2.INTER_LINEAR = copy_make_border, 0, 1
+    import utils.datasets as rdatasets
+    cases = [((1024, 2048), 2048, True), ((1000, 2048), 2048, True), ((37, 64), 64, True), ((64, 50), 64, False), ((480, 640), 640, True),
+             ((640, 640), 640, False), ((333, 640), 640, True), ((720, 1280), 1280, True)]
+    out = {'cases': np.array([[h, w, ns, int(auto)] for (h, w), ns, auto in cases])}
+    rs = np.random.RandomState(0)
+    for i, ((h, w), ns, auto) in enumerate(cases):
+        im = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        img, ratio, pad = rdatasets.letterbox(im, ns, auto=auto, stride=32)
+        out[f'geom_{i}'] = np.array([img.shape[0], img.shape[1], ratio[0], ratio[1], pad[0], pad[1]], np.float64)
+        out[f'sum_{i}'] = np.array([int(img.astype(np.int64).sum()), int(img[0, 0, 0]), int(img[-1, -1, 2])])
+    np.savez_compressed(os.path.join(GOLD, 'letterbox.npz'), **out)
+    print('wrote letterbox', len(cases))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics', 'match']
+    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics', 'match', 'letterbox']
     if 'models' in which:
         model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
         model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
@@ -262,6 +287,8 @@ def main():
         metrics_case(ref)
     if 'match' in which:
         match_case(ref)
+    if 'letterbox' in which:
+        letterbox_case(ref)
 
 
 if __name__ == '__main__':

@@ -163,3 +163,22 @@ def test_match_predictions_restatement():
         c = metrics_ref.match_predictions(p, l, iouv)
         assert np.array_equal(c.numpy(), g[f'correct_{i}'])
         assert c.any(0).all() or i == 1                     # every IoU threshold has true positives (tiny case 1 may not)
+
+
+def test_letterbox_restatement_and_host_geometry():
+    """utils.datasets.letterbox of the reference (golden) vs oracle.frame_ref.letterbox (pixels) and the product's host geometry
+    (multiyolov5_amd.utils.datasets.letterbox_params)"""
+    from multiyolov5_amd.utils.datasets import letterbox_params
+    from oracle import frame_ref
+    g = golden('letterbox')
+    rs = np.random.RandomState(0)
+    for i, (h, w, ns, auto) in enumerate(g['cases']):
+        im = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        img, ratio, pad = frame_ref.letterbox(im, int(ns), auto=bool(auto), stride=32)
+        geom = g[f'geom_{i}']
+        assert (img.shape[0], img.shape[1]) == (int(geom[0]), int(geom[1])) and tuple(ratio) == (geom[2], geom[3])
+        assert (float(pad[0]), float(pad[1])) == (geom[4], geom[5])
+        assert [int(img.astype(np.int64).sum()), int(img[0, 0, 0]), int(img[-1, -1, 2])] == list(g[f'sum_{i}'])
+        new_unpad, r2, p2, (t, b, l, r) = letterbox_params((int(h), int(w)), int(ns), auto=bool(auto), stride=32)
+        assert tuple(r2) == tuple(ratio) and (float(p2[0]), float(p2[1])) == (geom[4], geom[5])
+        assert (h + t + b, w + l + r) == (int(geom[0]), int(geom[1]))
