@@ -268,11 +268,29 @@ def letterbox_case(ref):
     print('wrote letterbox', len(cases))
 
 
+def boxes_case(ref):
+    """the box helpers detect.py / test.py chain after NMS (utils/general.py xywh2xyxy 265-272, scale_coords 319-332 incl. clip_coords
+    335-340, box_iou 388-410), run from the reference itself"""
+    rs = np.random.RandomState(4)
+    out = {}
+    xywh = torch.from_numpy(rs.uniform(0, 600, (50, 4)).astype(np.float32))
+    out['xywh'], out['xyxy'] = xywh.numpy(), ref.general.xywh2xyxy(xywh).numpy()
+    cases = [((512, 1024), (1000, 2000), None), ((384, 640), (720, 1280), None), ((640, 640), (480, 640), None),
+             ((1024, 2048), (1024, 2048), ((1.0, 1.0), (0.0, 12.0)))]
+    out['ncases'] = np.array(len(cases))
+    for i, (s1, s0, rp) in enumerate(cases):
+        c = torch.from_numpy(rs.uniform(-50, max(s1) + 50, (40, 6)).astype(np.float32))
+        out[f'coords_in_{i}'] = c.numpy().copy()
+        out[f'coords_out_{i}'] = ref.general.scale_coords(s1, c[:, :4].clone(), s0, rp).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'boxes.npz'), **out)
+    print('wrote boxes')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics', 'match', 'letterbox']
+    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics', 'match', 'letterbox', 'boxes']
     if 'models' in which:
         model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
         model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
@@ -289,6 +307,8 @@ def main():
         match_case(ref)
     if 'letterbox' in which:
         letterbox_case(ref)
+    if 'boxes' in which:
+        boxes_case(ref)
 
 
 if __name__ == '__main__':

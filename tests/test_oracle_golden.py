@@ -182,3 +182,16 @@ def test_letterbox_restatement_and_host_geometry():
         new_unpad, r2, p2, (t, b, l, r) = letterbox_params((int(h), int(w)), int(ns), auto=bool(auto), stride=32)
         assert tuple(r2) == tuple(ratio) and (float(p2[0]), float(p2[1])) == (geom[4], geom[5])
         assert (h + t + b, w + l + r) == (int(geom[0]), int(geom[1]))
+
+
+def test_box_helpers_match_reference():
+    """multiyolov5_amd.utils.general xywh2xyxy / scale_coords (+clip_coords), the host-side chain detect.py:168 and test.py:196,244 run
+    after NMS, vs the reference's own outputs (they are device-agnostic torch code: checked here on CPU)"""
+    from multiyolov5_amd.utils.general import scale_coords, xywh2xyxy
+    g = golden('boxes')
+    assert np.array_equal(xywh2xyxy(torch.from_numpy(g['xywh'])).numpy(), g['xyxy'])
+    cases = [((512, 1024), (1000, 2000), None), ((384, 640), (720, 1280), None), ((640, 640), (480, 640), None),
+             ((1024, 2048), (1024, 2048), ((1.0, 1.0), (0.0, 12.0)))]
+    for i, (s1, s0, rp) in enumerate(cases):
+        c = torch.from_numpy(g[f'coords_in_{i}'])[:, :4].clone()
+        assert np.array_equal(scale_coords(s1, c, s0, rp).numpy(), g[f'coords_out_{i}'])
