@@ -28,7 +28,10 @@ for (ph, c), r in zip(calls, ks):
     a = agg[key]; a[0] += 1; a[1] += t; a[2] += E.conv_call_bytes(c); a[3] += E.conv_call_flops(c)
 tot = sum(a[1] for a in agg.values())
 print(f'total {tot:.0f} us')
-print('ph  in(HxWxC) -> out(HxWxC) taps kern   n   us/call  GB/s  TF/s  total_us')
+HBM, MFMA = 8.0e12, 2.5e15          # peaks used by bench.py (MI355X_MICROARCH.md)
+ideal_tot = sum(max(a[2] / HBM, a[3] / MFMA) * 1e6 for a in agg.values())
+print(f'per-layer roofline (max(bytes/8 TB/s, flops/2.5 PF/s)) summed: {ideal_tot:.0f} us -> achieved fraction {ideal_tot / tot:.3f}')
+print('ph  in(HxWxC) -> out(HxWxC) taps kern   n   us/call  GB/s  TF/s  total_us  roofline_us/call  frac')
 for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     ph, xh, xw, xc, yh, yw, yc, nt, kn = k
-    print(f'{ph} {xh:4d}x{xw:4d}x{xc:4d} -> {yh:4d}x{yw:4d}x{yc:4d} t{nt} {kn:6s} x{a[0]:2d} {a[1]/a[0]:8.1f} {a[2]/a[1]/1e3:6.0f} {a[3]/a[1]/1e6:6.1f} {a[1]:8.0f}')
+    print(f'{ph} {xh:4d}x{xw:4d}x{xc:4d} -> {yh:4d}x{yw:4d}x{yc:4d} t{nt} {kn:6s} x{a[0]:2d} {a[1]/a[0]:8.1f} {a[2]/a[1]/1e3:6.0f} {a[3]/a[1]/1e6:6.1f} {a[1]:8.0f} {max(a[2] / HBM, a[3] / MFMA) * 1e6 / a[0]:8.1f} {max(a[2] / HBM, a[3] / MFMA) * 1e6 / a[1]:6.2f}')
