@@ -8,11 +8,16 @@ hipGraph-capturable (torch.cuda.graph == hipGraph on ROCm).  There is no CPU pat
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
 from . import _lib as L
 from ._lib import Tensor as CT
+
+# MYOLO_PAR=1: forward launch lists run branch-parallel on several HIP streams (sched.py; experimental, unmeasured -- default off)
+PAR_FWD = os.environ.get('MYOLO_PAR', '0') == '1'
+PAR_STREAMS = 4
 
 SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
@@ -789,9 +794,48 @@ class Plan:
             if self._pack_key != tuple(j[0].data_ptr() for j in self._pack_jobs):     # a parameter was re-allocated (.to(), load)
                 self._build_pack_table()
             self._pack_call(st)
+        if PAR_FWD and self.flat_grad_is_cuda():
+            self._run_fwd_parallel()
+            return
         for op in self.ops:
             for c in op.fwd_calls:
                 c(st)
+
+    def flat_grad_is_cuda(self):
+        return torch.device(self.device).type == 'cuda'
+
+    def _run_fwd_parallel(self):
+        """forward launch list dealt to PAR_STREAMS HIP streams by sched.forward_schedule: side streams fork from the caller's stream
+        (after the arena fill / weight pack above) and are joined back into it at the end, so callers -- and a hipGraph capture --
+        see the same single-stream contract as the serial loop."""
+        from . import sched as S
+        st = self.__dict__
+        if st.get('_par') is None:
+            deps, sch, empty = S.forward_schedule(self, PAR_STREAMS)
+            bad = S.check_schedule(deps, sch, empty)
+            if bad:
+                raise L.MyoloError(f'parallel forward schedule leaves {len(bad)} dependencies unordered: {bad[:4]}')
+            streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(PAR_STREAMS - 1)]
+            events = {i: torch.cuda.Event() for i in sch.events}
+            st['_par'] = (sch, streams, events)
+        sch, streams, events = st['_par']
+        main = torch.cuda.current_stream()
+        cur = [main] + streams[1:]
+        for k in sch.joins:
+            cur[k].wait_stream(main)
+        ptrs = [C.c_void_p(s.cuda_stream) for s in cur]
+        for i, op in enumerate(self.ops):
+            if not op.fwd_calls:
+                continue
+            k = sch.stream[i]
+            for j in sch.waits[i]:
+                cur[k].wait_event(events[j])
+            for c in op.fwd_calls:
+                c(ptrs[k])
+            if i in events:
+                events[i].record(cur[k])
+        for k in sch.joins:
+            main.wait_stream(cur[k])
 
     def grad_buckets(self, reducer):
         """bucket layout of flat_grad for a parallel.GradReducer (cached per reducer)."""

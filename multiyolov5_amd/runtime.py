@@ -294,7 +294,7 @@ class PlannedModule(nn.Module):
         h, grad = self._holder(tensors, spec)
         if grad:
             outs = PlanFn.apply(h, *tensors, *h.plan.params)
-        elif not self.training and GRAPH_EVAL:
+        elif not self.training and GRAPH_EVAL and not E.PAR_FWD:        # (capturing the multi-stream list crashed HIP: eager only)
             outs = h.run_graphed(tensors)
         else:
             h.bind_inputs(tensors)
