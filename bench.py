@@ -211,12 +211,14 @@ def conv_kernel_timing(trainer, nsteps=3):
         rec.append((self, e0, e1))
 
     E.Call.__call__ = timed
+    graph_mode, E.GRAPH_TRAIN = E.GRAPH_TRAIN, False     # per-launch events need the launch list issued call by call, not a graph replay
     try:
         for _ in range(nsteps):
             trainer.step()
         torch.cuda.synchronize()
     finally:
         E.Call.__call__ = orig
+        E.GRAPH_TRAIN = graph_mode
     tot_t = sum(e0.elapsed_time(e1) for _, e0, e1 in rec) * 1e-3 / nsteps
     tot_b = sum(E.conv_call_bytes(c) for c, _, _ in rec) / nsteps
     tot_f = sum(E.conv_call_flops(c) for c, _, _ in rec) / nsteps

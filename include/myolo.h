@@ -165,6 +165,11 @@ int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myol
 int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
                    const myolo_tensor* gfeat, int accumulate, float* gatt_f32 /* [n*c] zeroed by caller */,
                    void* stream);
+/* ARM / Attention gate: out = feat*att (torch.mul(feat, atten), common.py:192,207) -- the FFM gate without the `+ feat` */
+int myolo_gate_mul_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream);
+int myolo_gate_mul_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
+                       const myolo_tensor* gfeat, int accumulate, float* gatt_f32 /* [n*c] zeroed by caller */,
+                       void* stream);
 /* out (+)= a  (elementwise on views; BiSe `m16 + feat3`, gradient fan-in) */
 int myolo_add(const myolo_tensor* a, const myolo_tensor* out, int accumulate, void* stream);
 int myolo_fill_zero(const myolo_tensor* t, void* stream);

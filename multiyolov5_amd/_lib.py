@@ -82,6 +82,8 @@ _PROTOS = {
     'myolo_adaptive_avgpool_bwd': (C.c_int, [TP, TP, C.c_int, P]),
     'myolo_gate_fwd': (C.c_int, [TP, TP, TP, P]),
     'myolo_gate_bwd': (C.c_int, [TP, TP, TP, TP, C.c_int, P, P]),
+    'myolo_gate_mul_fwd': (C.c_int, [TP, TP, TP, P]),
+    'myolo_gate_mul_bwd': (C.c_int, [TP, TP, TP, TP, C.c_int, P, P]),
     'myolo_add': (C.c_int, [TP, TP, C.c_int, P]),
     'myolo_fill_zero': (C.c_int, [TP, P]),
     'myolo_cast_from_f32': (C.c_int, [P, TP, P]),

@@ -30,9 +30,14 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     objs = []
     procs = []
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')] + \
+        [os.path.join(os.path.dirname(HERE), 'include', 'myolo.h')]
+    hdr_t = max(os.path.getmtime(h) for h in hdrs)
     for src in sources():
         obj = os.path.join(HERE, 'lib', os.path.basename(src)[:-4] + '.o')
         objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
+            continue                                     # object is newer than its source and every header
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:

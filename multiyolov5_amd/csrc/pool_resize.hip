@@ -705,7 +705,7 @@ __global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_t
 
 // ---------------------------------------------------------------- FFM gate
 template <typename T>
-__global__ __launch_bounds__(256) void gate_fwd_kernel(myolo_tensor feat, myolo_tensor att, myolo_tensor out) {
+__global__ __launch_bounds__(256) void gate_fwd_kernel(myolo_tensor feat, myolo_tensor att, myolo_tensor out, float one) {
   constexpr int SEG = ET<T>::SEG;
   const int G = feat.c / SEG;
   const int64_t total = (int64_t)feat.n * feat.h * feat.w * G;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(myolo_tensor feat, myolo_
     Vec<T>::unpack(ldg16(vptr<T>(feat, n, y, xx) + cg * SEG), f);
     Vec<T>::unpack(ldg16(vptr<T>(att, n, 0, 0) + cg * SEG), a);
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) f[i] = f[i] * a[i] + f[i];
+    for (int i = 0; i < SEG; ++i) f[i] = f[i] * a[i] + one * f[i];      // one = 1: FFM (feat*att + feat); 0: ARM / Attention (feat*att)
     stg16(vptr<T>(out, n, y, xx) + cg * SEG, Vec<T>::pack(f));
   }
 }
@@ -724,7 +724,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(myolo_tensor feat, myolo_
 template <typename T>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(myolo_tensor gout, myolo_tensor feat, myolo_tensor att,
                                                        myolo_tensor gfeat, int acc, float* gatt, int G, int PPB,
-                                                       int blocks_per_img) {
+                                                       int blocks_per_img, float one) {
   constexpr int SEG = ET<T>::SEG;
   extern __shared__ float red[];  // [PPB][G*SEG]
   const int n = blockIdx.x / blocks_per_img, bi = blockIdx.x % blocks_per_img;
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(myolo_tensor gout, myolo_
     Vec<T>::unpack(ldg16(vptr<T>(gout, n, y, xx) + cg * SEG), g);
     Vec<T>::unpack(ldg16(vptr<T>(feat, n, y, xx) + cg * SEG), f);
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) { s[i] += g[i] * f[i]; o[i] = g[i] * (1.f + a[i]); }
+    for (int i = 0; i < SEG; ++i) { s[i] += g[i] * f[i]; o[i] = g[i] * (one + a[i]); }
     T* gp = vptr<T>(gfeat, n, y, xx) + cg * SEG;
     if (acc) {
       float q[SEG];
@@ -965,16 +965,21 @@ extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_
   DISPATCH(gx->dtype, aap_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx, accumulate);
   return 0;
 }
-extern "C" int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out,
-                              void* stream) {
+static int gate_fwd_impl(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, float one, void* stream) {
   if (!vec_ok(feat) || !vec_ok(att) || !vec_ok(out) || !same_shape(feat, out) || !same_nc(feat, att) || att->h != 1 ||
       att->w != 1)
     return MYOLO_EINVAL;
-  DISPATCH(feat->dtype, gate_fwd_kernel, grid_for(nvec(feat), 256), 256, 0, (hipStream_t)stream, *feat, *att, *out);
+  DISPATCH(feat->dtype, gate_fwd_kernel, grid_for(nvec(feat), 256), 256, 0, (hipStream_t)stream, *feat, *att, *out, one);
   return 0;
 }
-extern "C" int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
-                              const myolo_tensor* gfeat, int accumulate, float* gatt, void* stream) {
+extern "C" int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream) {
+  return gate_fwd_impl(feat, att, out, 1.0f, stream);
+}
+extern "C" int myolo_gate_mul_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream) {
+  return gate_fwd_impl(feat, att, out, 0.0f, stream);
+}
+static int gate_bwd_impl(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
+                         const myolo_tensor* gfeat, int accumulate, float* gatt, float one, void* stream) {
   if (!vec_ok(gout) || !vec_ok(feat) || !vec_ok(att) || !vec_ok(gfeat) || !gatt || !same_shape(gout, feat) ||
       !same_shape(gfeat, feat) || !same_nc(feat, att))
     return MYOLO_EINVAL;
@@ -990,12 +995,20 @@ extern "C" int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat
   hipStream_t st = (hipStream_t)stream;
   if (feat->dtype == MYOLO_F16)
     hipLaunchKernelGGL(gate_bwd_kernel<half_t>, dim3(feat->n * bpi), dim3(G * PPB), smem, st, *gout, *feat, *att, *gfeat,
-                       accumulate, gatt, G, PPB, bpi);
+                       accumulate, gatt, G, PPB, bpi, one);
   else
     hipLaunchKernelGGL(gate_bwd_kernel<float>, dim3(feat->n * bpi), dim3(G * PPB), smem, st, *gout, *feat, *att, *gfeat,
-                       accumulate, gatt, G, PPB, bpi);
+                       accumulate, gatt, G, PPB, bpi, one);
   MYOLO_CHECK_LAUNCH();
   return 0;
+}
+extern "C" int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
+                              const myolo_tensor* gfeat, int accumulate, float* gatt, void* stream) {
+  return gate_bwd_impl(gout, feat, att, gfeat, accumulate, gatt, 1.0f, stream);
+}
+extern "C" int myolo_gate_mul_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,
+                                  const myolo_tensor* gfeat, int accumulate, float* gatt, void* stream) {
+  return gate_bwd_impl(gout, feat, att, gfeat, accumulate, gatt, 0.0f, stream);
 }
 extern "C" int myolo_add(const myolo_tensor* a, const myolo_tensor* out, int accumulate, void* stream) {
   if (!vec_ok(a) || !vec_ok(out) || !same_shape(a, out)) return MYOLO_EINVAL;

@@ -15,9 +15,9 @@ import torch
 from . import _lib as L
 from ._lib import Tensor as CT
 
-# MYOLO_PAR=1: forward launch lists run branch-parallel on several HIP streams (sched.py; experimental, unmeasured -- default off)
-PAR_FWD = os.environ.get('MYOLO_PAR', '0') == '1'
-PAR_STREAMS = 4
+# MYOLO_GRAPH_TRAIN=0: training launch lists are enqueued call by call instead of replayed as hipGraphs (see Plan.run_fwd / run_bwd)
+GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '1') != '0'
+BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '6'))
 
 SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
@@ -539,10 +539,11 @@ class SppPoolOp(Op):
 
 
 class GateOp(Op):
-    """FFM: out = feat*att + feat (common.py:228-229)."""
+    """FFM: out = feat*att + feat (common.py:228-229); residual=False: ARM / Attention out = feat*att (common.py:192,207)."""
 
-    def __init__(self, plan, feat, att, out):
+    def __init__(self, plan, feat, att, out, residual=True):
         self.feat, self.att, self.out = feat, att, out
+        self.fn = 'myolo_gate' if residual else 'myolo_gate_mul'
         self.acc, self.zero_first, self.acc_att = 0, [], 0
 
     def plan_bwd(self, plan):
@@ -554,7 +555,7 @@ class GateOp(Op):
     def build(self, plan):
         super().build(plan)
         self.fd, self.ad, self.od = self.feat.desc(), self.att.desc(), self.out.desc()
-        self.fwd_calls.append(Call('myolo_gate_fwd', (C.byref(self.fd), C.byref(self.ad), C.byref(self.od))))
+        self.fwd_calls.append(Call(self.fn + '_fwd', (C.byref(self.fd), C.byref(self.ad), C.byref(self.od))))
         if plan.training:
             for tv, a, b in self.zero_first:
                 z = TV(plan, tv.n, tv.h, tv.w, b - a)
@@ -563,7 +564,7 @@ class GateOp(Op):
                 self.bwd_calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
             self.gatt = plan.f32_bwd_zero(self.att.n * self.att.c)
             self.god, self.gfd, self.gad = self.out.desc(grad=True), self.feat.desc(grad=True), self.att.desc(grad=True)
-            self.bwd_calls.append(Call('myolo_gate_bwd', (C.byref(self.god), C.byref(self.fd), C.byref(self.ad),
+            self.bwd_calls.append(Call(self.fn + '_bwd', (C.byref(self.god), C.byref(self.fd), C.byref(self.ad),
                                                           C.byref(self.gfd), self.acc, L.ptr(self.gatt))))
             self.bwd_calls.append(Call('myolo_cast_from_f32', (L.ptr(self.gatt), C.byref(self.gad))))
 
@@ -786,56 +787,74 @@ class Plan:
                 c(st)
 
     # ---- run ----------------------------------------------------------------------------------------
-    def run_fwd(self):
-        st = L.stream_ptr()
+    # A training plan is ~330 forward + ~340 backward C-ABI launches: issued one ctypes call at a time that is ~5.6 ms of host time per
+    # step.  After two eager runs the launch lists are captured ONCE into hipGraphs (torch.cuda.CUDAGraph == hipGraph on ROCm) and a
+    # run is a handful of graph launches.  Only plan-owned static buffers are baked into the graphs: the ops that read caller tensors
+    # (FocusPackOp / ImportOp) stay outside and run eagerly first.  The backward is cut into BWD_SEGMENTS pieces; each piece is one
+    # graph for the main stream (BatchNorm backward, dgrad, pooling ...) and one for the weight-gradient side stream, chained by
+    # events BETWEEN graph launches -- no cross-stream dependency is captured (a multi-stream capture crashed HIP in round 1), and the
+    # RCCL slices of a parallel.GradReducer are issued eagerly between the pieces.
+    def _zero_fwd(self):
         if self._used[0]:
             self._arena[0][:self._used[0]].zero_()
+
+    def _check_pack_table(self):
+        if self._pack_call is not None and self._pack_key != tuple(j[0].data_ptr() for j in self._pack_jobs):
+            self._build_pack_table()                          # a parameter was re-allocated (.to(), load): new table, new graphs
+            self.__dict__.pop('_graphs', None)
+
+    def _fwd_lists(self):
+        """(ops reading caller tensors -> eager, every other op -> graph)"""
+        eager = [op for op in self.ops if isinstance(op, (FocusPackOp, ImportOp))]
+        rest = [op for op in self.ops if not isinstance(op, (FocusPackOp, ImportOp))]
+        return eager, rest
+
+    def _fwd_body(self, st, ops):
+        self._zero_fwd()
         if self._pack_call is not None:
-            if self._pack_key != tuple(j[0].data_ptr() for j in self._pack_jobs):     # a parameter was re-allocated (.to(), load)
-                self._build_pack_table()
             self._pack_call(st)
-        if PAR_FWD and self.flat_grad_is_cuda():
-            self._run_fwd_parallel()
-            return
-        for op in self.ops:
+        for op in ops:
             for c in op.fwd_calls:
                 c(st)
 
+    def graphable(self):
+        return GRAPH_TRAIN and self.training and torch.device(self.device).type == 'cuda'
+
+    def run_fwd(self):
+        st = L.stream_ptr()
+        self._check_pack_table()
+        if not self.graphable():
+            self._fwd_body(st, self.ops)
+            return
+        g = self.__dict__.setdefault('_graphs', {'warm': 0})
+        eager, rest = self._fwd_lists()
+        for op in eager:
+            for c in op.fwd_calls:
+                c(st)
+        if g['warm'] < 2 or g.get('failed'):
+            g['warm'] += 1
+            self._fwd_body(st, rest)
+            return
+        if 'fwd' not in g:
+            try:
+                g['fwd'] = self._capture(lambda s: self._fwd_body(s, rest))
+            except Exception as e:  # noqa: BLE001 -- capture is an optimisation only: fall back to the eager launch list, loudly once
+                import warnings
+                warnings.warn(f'multiyolov5_amd: hipGraph capture of the training forward failed ({e!r}); running eagerly')
+                g['failed'] = True
+                self._fwd_body(st, rest)
+                return
+        g['fwd'].replay()
+
+    def _capture(self, body, stream=None):
+        """capture body(stream_ptr) into a hipGraph (nothing executes during capture)"""
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=stream):
+            body(L.stream_ptr())
+        return graph
+
     def flat_grad_is_cuda(self):
         return torch.device(self.device).type == 'cuda'
-
-    def _run_fwd_parallel(self):
-        """forward launch list dealt to PAR_STREAMS HIP streams by sched.forward_schedule: side streams fork from the caller's stream
-        (after the arena fill / weight pack above) and are joined back into it at the end, so callers -- and a hipGraph capture --
-        see the same single-stream contract as the serial loop."""
-        from . import sched as S
-        st = self.__dict__
-        if st.get('_par') is None:
-            deps, sch, empty = S.forward_schedule(self, PAR_STREAMS)
-            bad = S.check_schedule(deps, sch, empty)
-            if bad:
-                raise L.MyoloError(f'parallel forward schedule leaves {len(bad)} dependencies unordered: {bad[:4]}')
-            streams = [None] + [torch.cuda.Stream(device=self.device) for _ in range(PAR_STREAMS - 1)]
-            events = {i: torch.cuda.Event() for i in sch.events}
-            st['_par'] = (sch, streams, events)
-        sch, streams, events = st['_par']
-        main = torch.cuda.current_stream()
-        cur = [main] + streams[1:]
-        for k in sch.joins:
-            cur[k].wait_stream(main)
-        ptrs = [C.c_void_p(s.cuda_stream) for s in cur]
-        for i, op in enumerate(self.ops):
-            if not op.fwd_calls:
-                continue
-            k = sch.stream[i]
-            for j in sch.waits[i]:
-                cur[k].wait_event(events[j])
-            for c in op.fwd_calls:
-                c(ptrs[k])
-            if i in events:
-                events[i].record(cur[k])
-        for k in sch.joins:
-            main.wait_stream(cur[k])
 
     def grad_buckets(self, reducer):
         """bucket layout of flat_grad for a parallel.GradReducer (cached per reducer)."""
@@ -847,43 +866,128 @@ class Plan:
             self._bucket_key = key
         return self._buckets
 
-    def run_bwd(self, reducer=None):
-        """backward launch list.  Weight-gradient kernels go to a side HIP stream: they only feed the optimizer, so they
-        overlap with the latency-bound dgrad / BatchNorm chain on the main stream (many of those launches fill < 1 CU wave)."""
-        main = torch.cuda.current_stream() if self.flat_grad.is_cuda else None
-        st = L.stream_ptr()
+    def _zero_bwd(self):
         if self._used[1]:
             self._arena[1][:self._used[1]].zero_()
         if self.training:
             self.flat_grad.zero_()
-        side = side_ptr = None
-        if main is not None and self.use_side_stream:
-            if getattr(self, '_side', None) is None:
-                self._side = torch.cuda.Stream(device=self.device)
-            side = self._side
-            side.wait_stream(main)                       # the zero fills above
-            side_ptr = C.c_void_p(side.cuda_stream)
+
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
+    def _bwd_segments(self, reducer):
+        """cut points of the backward op list (descending op index): [(hi, lo, [buckets ready after op lo])] -- a bucket boundary
+        always ends a segment, the rest is balanced by launch count"""
         pending = list(self.grad_buckets(reducer)) if reducer is not None else []
-        for i in range(len(self.ops) - 1, -1, -1):
+        n = len(self.ops)
+        cuts = {0}
+        for _, _, ready in pending:
+            cuts.add(max(0, min(n, ready)))
+        ncalls = [len(op.bwd_calls) for op in self.ops]
+        tot = sum(ncalls)
+        nseg = max(1, BWD_SEGMENTS)
+        acc, k = 0, 1
+        for i in range(n - 1, 0, -1):
+            acc += ncalls[i]
+            if acc >= tot * k / nseg:
+                cuts.add(i)
+                k += 1
+        cuts = sorted(cuts, reverse=True)
+        segs, hi = [], n
+        for lo in cuts:
+            if lo == hi:
+                continue
+            ready = [(a, b) for a, b, r in pending if lo <= r < hi] if lo > 0 else [(a, b) for a, b, r in pending if r < hi]
+            segs.append((hi, lo, ready))
+            hi = lo
+        return segs
+
+    def _seg_main(self, st, hi, lo, with_side):
+        for i in range(hi - 1, lo - 1, -1):
             for c in self.ops[i].bwd_calls:
-                if c.side and side is not None:
+                if not (c.side and with_side):
+                    c(st)
+
+    def _seg_side(self, st, hi, lo):
+        for i in range(hi - 1, lo - 1, -1):
+            for c in self.ops[i].bwd_calls:
+                if c.side:
+                    c(st)
+
+    def capture_bwd(self, reducer=None):
+        """capture the backward pieces (called from the forward, on the caller's thread, once the forward graph exists: nothing
+        executes during a capture, so no gradients are needed yet).  Returns True when the backward can be replayed."""
+        g = self.__dict__.get('_graphs')
+        if not self.graphable() or g is None or 'fwd' not in g or g.get('failed'):
+            return False
+        use_side = self.use_side_stream
+        if g.get('bwd_key') == (id(reducer), use_side):
+            return True
+        try:
+            caps = []
+            for hi, lo, _ in self._bwd_segments(reducer):
+                gm = self._capture(lambda s, hi=hi, lo=lo: self._seg_main(s, hi, lo, use_side))
+                gs = None
+                if use_side and any(c.side for i in range(lo, hi) for c in self.ops[i].bwd_calls):
+                    gs = self._capture(lambda s, hi=hi, lo=lo: self._seg_side(s, hi, lo))
+                caps.append((gm, gs))
+            g['bwd'], g['bwd_key'] = caps, (id(reducer), use_side)
+            return True
+        except Exception as e:  # noqa: BLE001 -- capture is an optimisation only
+            import warnings
+            warnings.warn(f'multiyolov5_amd: hipGraph capture of the training backward failed ({e!r}); running eagerly')
+            g['failed'] = True
+            return False
+
+    def run_bwd(self, reducer=None):
+        """backward launch list.  Weight-gradient kernels go to a side HIP stream: they only feed the optimizer, so they
+        overlap with the latency-bound dgrad / BatchNorm chain on the main stream (many of those launches fill < 1 CU wave)."""
+        cuda = self.flat_grad.is_cuda
+        main = torch.cuda.current_stream() if cuda else None
+        use_side = cuda and self.use_side_stream
+        side = self._side_stream() if use_side else None
+        g = self.__dict__.get('_graphs')
+        graphed = self.graphable() and g is not None and 'fwd' in g and not g.get('failed')
+        segs = self._bwd_segments(reducer)
+        if graphed and 'bwd' not in g:
+            graphed = self.capture_bwd(reducer)
+        if graphed and g.get('bwd_key') != (id(reducer), use_side):
+            graphed = False                                   # reducer attached / detached after the capture: eager this time
+        self._zero_bwd()
+        if side is not None:
+            side.wait_stream(main)                            # the zero fills above
+        side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
+        st = L.stream_ptr()
+        for k, (hi, lo, ready) in enumerate(segs):
+            if graphed:
+                gm, gs = g['bwd'][k]
+                gm.replay()
+                if gs is not None:
                     ev = torch.cuda.Event()
                     ev.record(main)
                     side.wait_event(ev)
-                    c(side_ptr)
-                else:
-                    c(st)
-            if pending and pending[0][2] >= i:           # every kernel writing into this slice has been enqueued
+                    with torch.cuda.stream(side):
+                        gs.replay()
+            else:
+                for i in range(hi - 1, lo - 1, -1):
+                    for c in self.ops[i].bwd_calls:
+                        if c.side and side is not None:
+                            ev = torch.cuda.Event()
+                            ev.record(main)
+                            side.wait_event(ev)
+                            c(side_ptr)
+                        else:
+                            c(st)
+            if ready:                                         # every kernel writing into these slices has been enqueued
                 if side is not None:
                     main.wait_stream(side)
-                while pending and pending[0][2] >= i:
-                    lo, hi, _ = pending.pop(0)
-                    reducer.reduce_slice(self.flat_grad, lo, hi)
+                for a, b in ready:
+                    reducer.reduce_slice(self.flat_grad, a, b)
         if side is not None:
             main.wait_stream(side)
         if reducer is not None:
-            for lo, hi, _ in pending:
-                reducer.reduce_slice(self.flat_grad, lo, hi)
             reducer.finish(self.flat_grad)
 
     def nbytes(self):
@@ -919,8 +1023,8 @@ class SegHandle:
 class DecodeHandle:
     """eval-mode Detect: (cat of decoded levels, [raw levels]) (yolo.py:225)."""
 
-    def __init__(self, det_handles, strides, anchor_grid):
-        self.dets, self.strides, self.anchor_grid = det_handles, strides, anchor_grid
+    def __init__(self, det_handles, module):
+        self.dets, self.module = det_handles, module     # the live Detect module: anchors / strides are re-read by prepare()
 
 
 class DecodeOp(Op):
@@ -937,14 +1041,27 @@ class DecodeOp(Op):
         self.z = torch.zeros(n, a_total, no, dtype=plan.dtype, device=plan.device)
         plan.outputs[self.slot] = self.z
         row0 = 0
-        self.anch = []
+        self.anch, self.strd = [], []
         for i, c in enumerate(convs):
-            wh = (C.c_float * (na * 2))(*[float(v) for v in self.h.anchor_grid[i].reshape(-1).tolist()])
+            wh = (C.c_float * (na * 2))()
+            sd = C.c_float(0.0)
             self.anch.append(wh)
+            self.strd.append(sd)
             self.fwd_calls.append(Call('myolo_detect_decode', (L.ptr(c.det_out), L.DT[plan.dtype], n, na, c.out.h, c.out.w, no,
-                                                               C.c_float(float(self.h.strides[i])), wh, L.ptr(self.z),
-                                                               a_total, row0)))
+                                                               sd, wh, L.ptr(self.z), a_total, row0)))
             row0 += rows[i]
+        self.prepare()
+
+    def prepare(self):
+        """anchor_grid / stride are launch-time HOST constants of myolo_detect_decode: re-read them from the live module whenever
+        a buffer version changed (load_state_dict into a live model, autoanchor's `m.anchor_grid[:] = ...`)"""
+        m = self.h.module
+        ag = m.anchor_grid.detach().float().cpu()
+        for i, wh in enumerate(self.anch):
+            v = ag[i].reshape(-1).tolist()
+            for j in range(len(wh)):
+                wh[j] = float(v[j])
+            self.strd[i].value = float(m.stride[i])
 
 
 # ---------------------------------------------------------------------------------------------------------

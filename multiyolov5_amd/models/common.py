@@ -171,6 +171,15 @@ class Upsample(PlannedModule):
         super().__init__()
         self.size, self.scale_factor, self.mode, self.align_corners = size, scale_factor, mode, align_corners
 
+    def __reduce_ex__(self, protocol):
+        """pickled / deep-copied as the torch.nn.Upsample the reference's yaml names (checkpoints written here must only name classes
+        the reference has, train.py:485); models.yolo._emit_layer runs a plain nn.Upsample through this class again"""
+        m = nn.Upsample(self.size, self.scale_factor, self.mode, self.align_corners)
+        for k in ('i', 'f', 'type', 'np', 'training'):
+            if k in self.__dict__:
+                setattr(m, k, self.__dict__[k])
+        return (nn.Upsample, (self.size, self.scale_factor, self.mode, self.align_corners), dict(m.__dict__))
+
     def emit(self, plan, x):
         s = int(self.scale_factor)
         out = plan.new(x.n, x.h * s, x.w * s, x.c)
@@ -204,29 +213,38 @@ def emit_broadcast(plan, g, h, w):
     return out
 
 
-class _BareConvBNAct(nn.Sequential):
-    """nn.Sequential(Conv2d(k3,dilated,bias=False), BatchNorm2d, SiLU) as written inline in RFB/ASPP (common.py:481-490)."""
-
-    def __init__(self, c1, c2, d):
-        super().__init__(nn.Conv2d(c1, c2, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
+def _bare_conv_bn_act(c1, c2, d):
+    """nn.Sequential(Conv2d(k3,dilated,bias=False), BatchNorm2d, SiLU) exactly as written inline in RFB/ASPP (common.py:481-490):
+    plain torch containers (so that a pickled model names only classes the reference also has); `_emit_bare` runs them."""
+    return nn.Sequential(nn.Conv2d(c1, c2, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
                          nn.BatchNorm2d(c2), nn.SiLU())
 
-    def emit(self, plan, x):
-        return emit_conv(plan, x, self[0], self[1], L.ACT_SILU)[0]
+
+def _emit_bare(plan, seq, x):
+    return emit_conv(plan, x, seq[0], seq[1], _act_code(seq[2]))[0]
 
 
 def _emit_seq(plan, seq, x):
-    for m in seq:
-        x = m.emit(plan, x)
+    """nn.Sequential of `Conv` wrappers and inline Conv2d, BatchNorm2d, act triples"""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            x = emit_conv(plan, x, m, mods[i + 1], _act_code(mods[i + 2]))[0]
+            i += 3
+        else:
+            x = m.emit(plan, x)
+            i += 1
     return x
 
 
-class _GlobalBranch(nn.Sequential):
-    def __init__(self, c1, c2):
-        super().__init__(nn.AdaptiveAvgPool2d(1), Conv(c1, c2, k=1))
+def _global_branch(c1, c2):
+    return nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv(c1, c2, k=1))
 
-    def emit(self, plan, x):
-        return self[1].emit(plan, emit_avgpool(plan, x, 1))
+
+def _emit_global(plan, seq, x):
+    return seq[1].emit(plan, emit_avgpool(plan, x, 1))
 
 
 class RFB2(PlannedModule):
@@ -238,26 +256,27 @@ class RFB2(PlannedModule):
         self.has_globel = has_globel
         ip = in_planes // map_reduce
         self.branch0 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1))
-        self.branch1 = _BareConvBNAct(ip, ip, d[0])
-        self.branch2 = _BareConvBNAct(ip, ip, d[1])
+        self.branch1 = _bare_conv_bn_act(ip, ip, d[0])
+        self.branch2 = _bare_conv_bn_act(ip, ip, d[1])
         self.branch3 = nn.Sequential(Conv(in_planes, ip, k=1, s=1))
         if self.has_globel:
-            self.branch4 = _GlobalBranch(ip, ip)
+            self.branch4 = _global_branch(ip, ip)
         self.ConvLinear = Conv(int(5 * ip) if has_globel else int(4 * ip), out_planes, k=1, s=1)
 
     def emit(self, plan, x, res=None):
         x3 = _emit_seq(plan, self.branch3, x)
         x0 = _emit_seq(plan, self.branch0, x)
-        x1 = self.branch1.emit(plan, x0)
-        x2 = self.branch2.emit(plan, x1)
+        x1 = _emit_bare(plan, self.branch1, x0)
+        x2 = _emit_bare(plan, self.branch2, x1)
         parts = [x0, x1, x2, x3]
         if self.has_globel:
-            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x2), x.h, x.w))
+            parts.append(emit_broadcast(plan, _emit_global(plan, self.branch4, x2), x.h, x.w))
         return self.ConvLinear.emit(plan, plan.cat(parts))
 
 
 class RFB1(PlannedModule):
-    """parallel-branch variant (common.py:416-466); not instantiated by any shipped head, kept for the API."""
+    """parallel-branch variant (common.py:416-466): the commented alternative encoder of SegMaskLab (yolo.py:110); branch3 carries
+    the only 5x5 (25-tap) convolution of the block library."""
 
     def __init__(self, in_planes, out_planes, map_reduce=4, d=[3, 5, 7], has_globel=False):
         super().__init__()
@@ -265,31 +284,17 @@ class RFB1(PlannedModule):
         self.has_globel = has_globel
         ip = in_planes // map_reduce
         self.branch0 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1))
-        self.branch1 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1), *_BareConvBNAct(ip, ip, d[0]))
-        self.branch2 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1), *_BareConvBNAct(ip, ip, d[1]))
-        self.branch3 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=5, s=1), *_BareConvBNAct(ip, ip, d[2]))
+        self.branch1 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1), *_bare_conv_bn_act(ip, ip, d[0]))
+        self.branch2 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=3, s=1), *_bare_conv_bn_act(ip, ip, d[1]))
+        self.branch3 = nn.Sequential(Conv(in_planes, ip, k=1, s=1), Conv(ip, ip, k=5, s=1), *_bare_conv_bn_act(ip, ip, d[2]))
         if self.has_globel:
-            self.branch4 = _GlobalBranch(in_planes, ip)
+            self.branch4 = _global_branch(in_planes, ip)
         self.Fusion = Conv(int(5 * ip) if has_globel else int(4 * ip), out_planes, k=1, s=1)
 
-    @staticmethod
-    def _branch(plan, seq, x):
-        mods = list(seq)
-        i = 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Conv2d):       # inline Conv2d, BN, SiLU triple
-                x = emit_conv(plan, x, m, mods[i + 1], L.ACT_SILU)[0]
-                i += 3
-            else:
-                x = m.emit(plan, x)
-                i += 1
-        return x
-
     def emit(self, plan, x):
-        parts = [self._branch(plan, b, x) for b in (self.branch0, self.branch1, self.branch2, self.branch3)]
+        parts = [_emit_seq(plan, b, x) for b in (self.branch0, self.branch1, self.branch2, self.branch3)]
         if self.has_globel:
-            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x), x.h, x.w))
+            parts.append(emit_broadcast(plan, _emit_global(plan, self.branch4, x), x.h, x.w))
         return self.Fusion.emit(plan, plan.cat(parts))
 
 
@@ -301,30 +306,24 @@ class ASPP(PlannedModule):
         self.has_globel = has_globel
         self.hid = in_planes // map_reduce
         self.branch0 = nn.Sequential(Conv(in_planes, self.hid, k=1, s=1))
-        self.branch1 = _BareConvBNAct(in_planes, self.hid, d[0])
-        self.branch2 = _BareConvBNAct(in_planes, self.hid, d[1])
-        self.branch3 = _BareConvBNAct(in_planes, self.hid, d[2])
+        self.branch1 = _bare_conv_bn_act(in_planes, self.hid, d[0])
+        self.branch2 = _bare_conv_bn_act(in_planes, self.hid, d[1])
+        self.branch3 = _bare_conv_bn_act(in_planes, self.hid, d[2])
         if self.has_globel:
-            self.branch4 = _GlobalBranch(in_planes, self.hid)
+            self.branch4 = _global_branch(in_planes, self.hid)
         self.ConvLinear = Conv(int(5 * self.hid) if has_globel else int(4 * self.hid), out_planes, k=1, s=1)
 
     def emit(self, plan, x):
-        parts = [_emit_seq(plan, self.branch0, x), self.branch1.emit(plan, x), self.branch2.emit(plan, x),
-                 self.branch3.emit(plan, x)]
+        parts = [_emit_seq(plan, b, x) for b in (self.branch0, self.branch1, self.branch2, self.branch3)]
         if self.has_globel:
-            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x), x.h, x.w))
+            parts.append(emit_broadcast(plan, _emit_global(plan, self.branch4, x), x.h, x.w))
         return self.ConvLinear.emit(plan, plan.cat(parts))
 
 
-class _ConvThenBare(nn.Sequential):
-    """nn.Sequential(Conv(c1,hid,1), Conv2d(k3,dilated,bias=False), BatchNorm2d, SiLU) of ASPPs (common.py:288-305)."""
-
-    def __init__(self, c1, c2, d):
-        super().__init__(Conv(c1, c2, k=1), nn.Conv2d(c2, c2, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
+def _conv_then_bare(c1, c2, d):
+    """nn.Sequential(Conv(c1,hid,1), Conv2d(k3,dilated,bias=False), BatchNorm2d, SiLU) of ASPPs (common.py:288-305)"""
+    return nn.Sequential(Conv(c1, c2, k=1), nn.Conv2d(c2, c2, kernel_size=3, stride=1, padding=d, dilation=d, bias=False),
                          nn.BatchNorm2d(c2), nn.SiLU())
-
-    def emit(self, plan, x):
-        return emit_conv(plan, self[0].emit(plan, x), self[1], self[2], L.ACT_SILU)[0]
 
 
 class ASPPs(PlannedModule):
@@ -335,18 +334,17 @@ class ASPPs(PlannedModule):
         self.has_globel = has_globel
         self.hid = in_planes // map_reduce
         self.branch0 = nn.Sequential(Conv(in_planes, self.hid, k=1), Conv(self.hid, self.hid, k=3, s=1))
-        self.branch1 = _ConvThenBare(in_planes, self.hid, d[0])
-        self.branch2 = _ConvThenBare(in_planes, self.hid, d[1])
-        self.branch3 = _ConvThenBare(in_planes, self.hid, d[2])
+        self.branch1 = _conv_then_bare(in_planes, self.hid, d[0])
+        self.branch2 = _conv_then_bare(in_planes, self.hid, d[1])
+        self.branch3 = _conv_then_bare(in_planes, self.hid, d[2])
         if self.has_globel:
-            self.branch4 = _GlobalBranch(in_planes, self.hid)
+            self.branch4 = _global_branch(in_planes, self.hid)
         self.ConvLinear = Conv(int(5 * self.hid) if has_globel else int(4 * self.hid), out_planes, k=1, s=1)
 
     def emit(self, plan, x):
-        parts = [_emit_seq(plan, self.branch0, x), self.branch1.emit(plan, x), self.branch2.emit(plan, x),
-                 self.branch3.emit(plan, x)]
+        parts = [_emit_seq(plan, b, x) for b in (self.branch0, self.branch1, self.branch2, self.branch3)]
         if self.has_globel:
-            parts.append(emit_broadcast(plan, self.branch4.emit(plan, x), x.h, x.w))
+            parts.append(emit_broadcast(plan, _emit_global(plan, self.branch4, x), x.h, x.w))
         return self.ConvLinear.emit(plan, plan.cat(parts))
 
 
@@ -399,8 +397,15 @@ class FFM(PlannedModule):
         return out
 
 
+def _emit_se_bn(plan, pooled, conv_mod, act):
+    """`Conv(c, c, k=1, act=False)` (+ the nn.Sigmoid that follows it) on the pooled [n,1,1,c] vector (common.py:183,188,200):
+    the sigmoid rides in the BatchNorm kernel's activation slot (train) / the conv epilogue (fused eval)."""
+    bn = conv_mod.bn if hasattr(conv_mod, 'bn') else None
+    return emit_conv(plan, pooled, conv_mod.conv, bn, act)[0]
+
+
 class Attention(PlannedModule):
-    """SE gate x * W(x) (common.py:177-192); not instantiated by the shipped heads."""
+    """SE gate x * W(x) (common.py:177-192)."""
 
     def __init__(self, chan, reduction=1):
         super().__init__()
@@ -411,12 +416,18 @@ class Attention(PlannedModule):
             self.W = nn.Sequential(nn.AdaptiveAvgPool2d(1), Conv(chan, chan, k=1, s=1, act=False), nn.Sigmoid())
 
     def emit(self, plan, x):
-        raise NotImplementedError('Attention/ARM gates (x*att without the +x) are not wired on the gfx950 path yet; '
-                                  'no shipped head instantiates them (reference yolo.py:43-49 keeps them commented)')
+        a = emit_avgpool(plan, x, 1)
+        convs = [m for m in self.W if isinstance(m, Conv)]
+        for m in convs[:-1]:
+            a = m.emit(plan, a)
+        a = _emit_se_bn(plan, a, convs[-1], L.ACT_SIGMOID)
+        out = plan.new(x.n, x.h, x.w, x.c)
+        plan.add(E.GateOp(plan, x, a, out, residual=False))
+        return out
 
 
 class ARM(PlannedModule):
-    """AttentionRefinementModule (common.py:195-207); not instantiated by the shipped heads."""
+    """AttentionRefinementModule: feat = Conv3x3(x); feat * sigmoid(BN(W GAP(feat))) (common.py:195-207)."""
 
     def __init__(self, in_chan, out_chan, *args, **kwargs):
         super().__init__()
@@ -425,4 +436,8 @@ class ARM(PlannedModule):
                                                nn.Sigmoid())
 
     def emit(self, plan, x):
-        raise NotImplementedError('ARM is not wired on the gfx950 path yet; no shipped head instantiates it')
+        feat = self.conv.emit(plan, x)
+        a = _emit_se_bn(plan, emit_avgpool(plan, feat, 1), self.channel_attention[1], L.ACT_SIGMOID)
+        out = plan.new(feat.n, feat.h, feat.w, feat.c)
+        plan.add(E.GateOp(plan, feat, a, out, residual=False))
+        return out

@@ -93,7 +93,8 @@ class Ensemble(nn.ModuleList):
         y = []
         for module in self:
             det = module(x, augment)[0]
-            y.append(det[0] if isinstance(det, (tuple, list)) else det)
+            # forward outputs alias plan-owned static buffers: a module listed twice would overwrite its first result
+            y.append((det[0] if isinstance(det, (tuple, list)) else det).clone())
         y = torch.cat(y, 1)  # nms ensemble
         return y, None  # inference, train output
 

@@ -35,10 +35,6 @@ def _up(plan, x, scale):
     return out
 
 
-class _Dropout(nn.Dropout):
-    pass
-
-
 def _emit_dropout(plan, m, x):
     if plan.training and m.p > 0:
         out = plan.new(x.n, x.h, x.w, x.c)
@@ -178,7 +174,7 @@ class Detect(PlannedModule):
             dets.append(E.DetHandle(op))
         if plan.training or self.export:
             return dets
-        return E.DecodeHandle(dets, [float(s) for s in self.stride], self.anchor_grid.detach().float().cpu())
+        return E.DecodeHandle(dets, self)
 
 
 _SEG_HEADS = (SegMaskBiSe, SegMaskLab, SegMaskBase, SegMaskPSP)

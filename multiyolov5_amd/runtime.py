@@ -88,6 +88,7 @@ class PlanFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         holder.bind_inputs(tensors[:holder.n_in])
         plan.run_fwd()
+        plan.capture_bwd(holder.module.__dict__.get('_grad_reducer'))      # no-op until the forward graph exists / once captured
         outs = []
         for o in holder.output_tensors():
             d = o.detach()
@@ -96,6 +97,8 @@ class PlanFn(torch.autograd.Function):
                     setattr(d, attr, getattr(o, attr))
             outs.append(d)
         outs = tuple(outs)
+        holder.generation += 1                       # activations / BN statistics / dropout masks of this forward
+        ctx.generation = holder.generation
         holder.pending_bwd = True
         return outs
 
@@ -103,7 +106,7 @@ class PlanFn(torch.autograd.Function):
     def backward(ctx, *grads):
         holder = ctx.holder
         plan = holder.plan
-        if not holder.pending_bwd:
+        if not holder.pending_bwd or ctx.generation != holder.generation:
             raise L.MyoloError('backward through a plan whose activations were overwritten by a newer forward '
                                '(one outstanding forward per module/shape; call backward before the next forward)')
         for s, g in enumerate(grads):
@@ -172,6 +175,7 @@ class PlanHolder:
         plan.register_params([p for p in module.parameters()])
         plan.build()
         self.pending_bwd = False
+        self.generation = 0
         self.sig = None
 
     @staticmethod
@@ -239,7 +243,12 @@ class PlannedModule(nn.Module):
     Host cost matters (a training step is ~700 launches): the parameter / buffer tensors are listed once per module and a
     forward only re-reads their data pointers (re-allocation by .to()/.half()/load_state_dict is detected) and, in eval mode,
     their version counters (in-place weight edits re-run the one-off epilogue constant preparation).  Replacing a Parameter
-    OBJECT after the first forward is not detected: call invalidate_plans() (Model.fuse() does)."""
+    OBJECT after the first forward is not detected: call invalidate_plans() (Model.fuse() does).
+
+    Outputs are views of plan-owned static buffers (that is what makes a forward allocation-free and hipGraph-replayable): the
+    next forward of the same module with the same input signature overwrites them in place.  Callers that keep results across
+    forwards (accumulated predictions, one module used twice inside an Ensemble) must clone them -- models.experimental.Ensemble
+    does.  A backward through activations that a newer forward has overwritten raises (forward generation counter)."""
 
     _RUNTIME_STATE = ('_plans', '_tensor_list', '_prepared_version', '_grad_reducer')
 
@@ -282,6 +291,8 @@ class PlannedModule(nn.Module):
             v = self._param_version()
             if self.__dict__.get('_prepared_version') != v:
                 h.plan.prepare()
+                h.__dict__['_graph'] = None             # host-side launch constants (Detect anchors) are baked into a capture
+                h.__dict__['_graph_warm'] = 0
                 self.__dict__['_prepared_version'] = v
         return h, grad
 
@@ -294,7 +305,7 @@ class PlannedModule(nn.Module):
         h, grad = self._holder(tensors, spec)
         if grad:
             outs = PlanFn.apply(h, *tensors, *h.plan.params)
-        elif not self.training and GRAPH_EVAL and not E.PAR_FWD:        # (capturing the multi-stream list crashed HIP: eager only)
+        elif not self.training and GRAPH_EVAL:
             outs = h.run_graphed(tensors)
         else:
             h.bind_inputs(tensors)
@@ -305,10 +316,3 @@ class PlannedModule(nn.Module):
     def invalidate_plans(self):
         self.__dict__.pop('_plans', None)
         self.__dict__.pop('_tensor_list', None)
-
-    def __getstate__(self):       # plans hold device pointers: never pickled (train.py:485 pickles whole modules)
-        d = dict(self.__dict__)
-        d.pop('_plans', None)
-        d.pop('_prepared_version', None)
-        d.pop('_tensor_list', None)
-        return d

@@ -108,6 +108,61 @@ def model_case(ref, cfg_name, tag, with_backward):
     print('wrote', tag, len(out), 'arrays')
 
 
+BLOCKS = {
+    # name: (reference ctor, input shape [N,C,H,W])  -- blocks no shipped yaml instantiates (north_star names them): pinned directly
+    'rfb1': (lambda C: C.RFB1(64, 64, map_reduce=4, d=[3, 5, 7], has_globel=False), (2, 64, 12, 16)),
+    'rfb1_global': (lambda C: C.RFB1(96, 64, map_reduce=6, d=[3, 5, 7], has_globel=True), (2, 96, 8, 12)),
+    'arm': (lambda C: C.ARM(64, 32), (2, 64, 8, 12)),
+    'attention': (lambda C: C.Attention(64), (3, 64, 6, 8)),
+    'attention_r4': (lambda C: C.Attention(64, reduction=4), (2, 64, 6, 8)),
+}
+
+
+def block_inputs(name):
+    """(state_dict, x, r): synthetic weights for the block (oracle.synth streams over the reference class's own state_dict shapes),
+    input and the fixed cotangent of the backward."""
+    import zlib
+    seed = zlib.crc32(name.encode()) % 1000
+    rs = np.random.RandomState(100 + seed)
+    shape = BLOCKS[name][1]
+    x = torch.from_numpy(rs.normal(0, 1, shape).astype(np.float32))
+    return x, seed
+
+
+def blocks_case(ref):
+    """RFB1 / ARM / Attention run from the reference's own classes (models/common.py:177-207,416-466): train-mode forward +
+    backward (batch-stat BN, all parameter and input gradients) and eval-mode forward."""
+    import models.common as rcommon
+    out = {}
+    for name, (ctor, shape) in BLOCKS.items():
+        torch.manual_seed(0)
+        m = ctor(rcommon)
+        ref.torch_utils.initialize_weights(m)                      # eps 1e-3 / momentum 0.03 as inside Model
+        sd = synth.synth_state_dict({k: v.clone() for k, v in m.state_dict().items()}, seed=3)
+        m.load_state_dict(sd, strict=True)
+        x, seed = block_inputs(name)
+        out[f'{name}/x'] = x.numpy()                                # (weights are regenerated by the tests: synth_state_dict(seed=3))
+        m.train()
+        xin = x.clone().requires_grad_()
+        y = m(xin)
+        r = torch.from_numpy(np.random.RandomState(200 + seed).normal(0, 1, tuple(y.shape)).astype(np.float32))
+        (y * r).sum().backward()
+        out[f'{name}/r'] = r.numpy()
+        out[f'{name}/train_out'] = y.detach().numpy()
+        out[f'{name}/dx'] = xin.grad.numpy()
+        for k, p_ in m.named_parameters():
+            out[f'{name}/grad/{k}'] = p_.grad.numpy()
+        for k, b in m.named_buffers():
+            if 'running' in k:
+                out[f'{name}/after/{k}'] = b.numpy().copy()
+        m.load_state_dict(sd, strict=True)
+        m.eval()
+        with torch.no_grad():
+            out[f'{name}/eval_out'] = m(x).numpy()
+    np.savez_compressed(os.path.join(GOLD, 'blocks.npz'), **out)
+    print('wrote blocks', len(out))
+
+
 def loss_case(ref):
     out = {}
     rs = np.random.RandomState(7)
@@ -290,13 +345,17 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['models', 'losses', 'nms', 'metrics', 'match', 'letterbox', 'boxes']
+    which = sys.argv[1:] or ['models', 'blocks', 'losses', 'nms', 'metrics', 'match', 'letterbox', 'boxes']
     if 'models' in which:
         model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
         model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
         model_case(ref, 'yolov5s_city_seg_lab.yaml', 's_lab', True)
         model_case(ref, 'yolov5s_city_seg_bise.yaml', 's_bise', True)
-        model_case(ref, 'yolov5m_city_seg_lab.yaml', 'm_lab', False)
+        model_case(ref, 'yolov5m_city_seg_lab.yaml', 'm_lab', True)
+    if 'm_lab' in which:
+        model_case(ref, 'yolov5m_city_seg_lab.yaml', 'm_lab', True)
+    if 'blocks' in which:
+        blocks_case(ref)
     if 'losses' in which:
         loss_case(ref)
     if 'nms' in which:

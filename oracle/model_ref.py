@@ -29,6 +29,7 @@ class Ctx:
         self.training = training
         self.dropout_p = dropout_p   # Base/BiSe heads (yolo.py:65,140); tests pin with 0.0
         self.record = record         # optional dict: name -> tensor (per-layer taps)
+        self.dropout_fn = None       # tests: replay a given keep-mask instead of drawing one (dropout parity is statistical)
 
     def has(self, key):
         return key in self.sd
@@ -105,6 +106,37 @@ def rfb2(ctx, p, x, d=(2, 3), has_globel=False):  # common.py:470-511
     return conv_block(ctx, p + '.ConvLinear', torch.cat(parts, 1))
 
 
+def rfb1(ctx, p, x, d=(3, 5, 7), has_globel=False):  # common.py:416-466 (parallel branches; branch3 has the 5x5 Conv)
+    def branch(q, k2, dil):
+        y = conv_block(ctx, q + '.1', conv_block(ctx, q + '.0', x), k2)
+        if dil is None:
+            return y
+        y = F.conv2d(y, ctx.sd[q + '.2.weight'], None, 1, dil, dil)          # inline Conv2d, BatchNorm2d, SiLU (430-432)
+        return F.silu(_bn(ctx, q + '.3', y))
+    parts = [branch(p + '.branch0', 3, None), branch(p + '.branch1', 3, d[0]), branch(p + '.branch2', 3, d[1]),
+             branch(p + '.branch3', 5, d[2])]
+    if has_globel:
+        g = conv_block(ctx, p + '.branch4.1', F.adaptive_avg_pool2d(x, 1))
+        parts.append(g.expand(-1, -1, x.shape[2], x.shape[3]))               # F.interpolate(1x1 -> HxW, 'nearest') (464)
+    return conv_block(ctx, p + '.Fusion', torch.cat(parts, 1))
+
+
+def attention(ctx, p, x, reduction=1):  # common.py:177-192: x * sigmoid(Conv(act=False)(... GAP(x)))
+    a = F.adaptive_avg_pool2d(x, 1)
+    if reduction > 1:
+        a = conv_block(ctx, p + '.W.1', a)
+        a = conv_block(ctx, p + '.W.2', a, act=False)
+    else:
+        a = conv_block(ctx, p + '.W.1', a, act=False)
+    return x * torch.sigmoid(a)
+
+
+def arm(ctx, p, x):  # common.py:195-207
+    feat = conv_block(ctx, p + '.conv', x, 3)
+    a = conv_block(ctx, p + '.channel_attention.1', F.adaptive_avg_pool2d(feat, 1), act=False)
+    return torch.mul(feat, torch.sigmoid(a))
+
+
 def aspp(ctx, p, x, d=(3, 6, 9), has_globel=True):  # common.py:233-275
     parts = [conv_block(ctx, p + '.branch0.0', x)]
     for i in range(3):
@@ -144,6 +176,8 @@ def ffm(ctx, p, x, k):  # common.py:210-230 (x already concatenated)
 
 
 def _dropout(ctx, x):
+    if ctx.dropout_fn is not None and ctx.training:
+        return ctx.dropout_fn(x)
     return F.dropout(x, ctx.dropout_p, ctx.training) if ctx.dropout_p > 0 else x
 
 

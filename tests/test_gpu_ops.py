@@ -61,6 +61,11 @@ CASES = {
     'pyramid': (lambda C: C.PyramidPooling(64), lambda c, p, x: model_ref.pyramid_pooling(c, p, x), [(2, 64, 8, 16)]),
     'pyramid_big': (lambda C: C.PyramidPooling(64), lambda c, p, x: model_ref.pyramid_pooling(c, p, x), [(2, 64, 32, 48)]),
     'ffm_k3': (lambda C: C.FFM(64, 32, k=3, is_cat=False), lambda c, p, x: model_ref.ffm(c, p, x, 3), [(2, 64, 8, 16)]),
+    'rfb1': (lambda C: C.RFB1(64, 64, map_reduce=4, d=[3, 5, 7]), lambda c, p, x: model_ref.rfb1(c, p, x, (3, 5, 7), False), [(2, 64, 14, 22)]),   # 25-tap 5x5 conv: fwd, dgrad, wgrad
+    'rfb1_global': (lambda C: C.RFB1(96, 64, map_reduce=6, has_globel=True), lambda c, p, x: model_ref.rfb1(c, p, x, (3, 5, 7), True), [(2, 96, 8, 12)]),
+    'arm': (lambda C: C.ARM(64, 32), lambda c, p, x: model_ref.arm(c, p, x), [(2, 64, 8, 16)]),
+    'attention': (lambda C: C.Attention(64), lambda c, p, x: model_ref.attention(c, p, x, 1), [(3, 64, 6, 10)]),
+    'attention_r4': (lambda C: C.Attention(64, reduction=4), lambda c, p, x: model_ref.attention(c, p, x, 4), [(2, 64, 6, 10)]),
     'ffm_cat': (lambda C: C.FFM(64, 64, k=1, is_cat=True), lambda c, p, x: model_ref.ffm(c, p, torch.cat(x, 1), 1), [(2, 16, 8, 16), (2, 48, 8, 16)]),
 }
 
@@ -124,7 +129,7 @@ def force_stream_kernel():
 
 
 @pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
-@pytest.mark.parametrize('name', ['conv1x1', 'conv3x3', 'conv3x3s2', 'conv3x3s2_odd', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'aspp', 'ffm_k3'])
+@pytest.mark.parametrize('name', ['conv1x1', 'conv3x3', 'conv3x3s2', 'conv3x3s2_odd', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'rfb1', 'aspp', 'ffm_k3'])
 def test_block_streaming_kernel(name, training, force_stream_kernel):
     """the same block parity cases with the streaming conv kernel forced on (ragged M, stride 2, dilation, residual,
     accumulate, BatchNorm statistics) -- at the default threshold it only serves maps of >= 65536 pixels"""
@@ -195,3 +200,37 @@ def test_full_resolution_eval_forward_vs_oracle():
         check(f'fullres/{dtype}/seg', seg, rseg, tol)
         if dtype == torch.float32:
             assert (seg.argmax(1).cpu() != rseg.argmax(1)).float().mean() < 1e-3
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
+@pytest.mark.parametrize('name', ['rfb1', 'rfb1_global', 'arm', 'attention', 'attention_r4'])
+def test_block_vs_reference_class_golden(name, dtype):
+    """RFB1 / ARM / Attention against outputs and gradients written by the reference's OWN classes (models/common.py:177-207,
+    416-466; tests/golden/blocks.npz, oracle/make_golden.py blocks_case): train forward, input + parameter gradients, running
+    statistics, eval forward"""
+    from tests.test_oracle_golden import block_state_dict
+    from tests.util import golden
+    g = golden('blocks')
+    sd, mod = block_state_dict(name)
+    mod.load_state_dict(sd, strict=True)
+    from multiyolov5_amd.utils.torch_utils import initialize_weights
+    initialize_weights(mod)
+    mod = mod.to(DEV).train()
+    tol = TOL[dtype]
+    x = torch.from_numpy(g[f'{name}/x']).to(DEV, dtype).requires_grad_()
+    y = mod(x)
+    bad = []
+    check(f'gold/{name}/train_out', y, g[f'{name}/train_out'], tol, collect=bad)
+    (y.float() * torch.from_numpy(g[f'{name}/r']).to(DEV)).sum().backward()
+    check(f'gold/{name}/dx', x.grad, g[f'{name}/dx'], tol * 2, collect=bad)
+    for k, p in mod.named_parameters():
+        check(f'gold/{name}/d{k}', p.grad, g[f'{name}/grad/{k}'], tol * 3, collect=bad)
+    for k, b in mod.named_buffers():
+        if 'running' in k:
+            check(f'gold/{name}/{k}', b, g[f'{name}/after/{k}'], tol, collect=bad)
+    mod.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+    mod.eval()
+    with torch.no_grad():
+        ye = mod(torch.from_numpy(g[f'{name}/x']).to(DEV, dtype))
+    check(f'gold/{name}/eval_out', ye, g[f'{name}/eval_out'], tol, collect=bad)
+    assert not bad, '\n'.join(bad)

@@ -55,7 +55,7 @@ def test_forward_train_and_eval(tag):
     assert (seg.argmax(1).numpy() != g['eval_seg_argmax']).mean() < 1e-4
 
 
-@pytest.mark.parametrize('tag', ['s_psp', 's_bise'])
+@pytest.mark.parametrize('tag', ['s_psp', 's_bise', 'm_lab'])
 def test_backward_matches_reference(tag):
     g = golden('model_' + tag)
     cfg = load_cfg(tag)
@@ -195,3 +195,45 @@ def test_box_helpers_match_reference():
     for i, (s1, s0, rp) in enumerate(cases):
         c = torch.from_numpy(g[f'coords_in_{i}'])[:, :4].clone()
         assert np.array_equal(scale_coords(s1, c, s0, rp).numpy(), g[f'coords_out_{i}'])
+
+
+BLOCK_FNS = {
+    'rfb1': lambda c, p, x: model_ref.rfb1(c, p, x, (3, 5, 7), False),
+    'rfb1_global': lambda c, p, x: model_ref.rfb1(c, p, x, (3, 5, 7), True),
+    'arm': lambda c, p, x: model_ref.arm(c, p, x),
+    'attention': lambda c, p, x: model_ref.attention(c, p, x, 1),
+    'attention_r4': lambda c, p, x: model_ref.attention(c, p, x, 4),
+}
+
+
+def block_state_dict(name):
+    """weights of a blocks.npz case: synth_state_dict(seed 3) over the mirror class's state_dict (same keys as the reference class)"""
+    from multiyolov5_amd.models import common as C
+    from oracle.make_golden import BLOCKS
+    m = BLOCKS[name][0](C)
+    return synth.synth_state_dict({k: v.clone() for k, v in m.state_dict().items()}, seed=3), m
+
+
+@pytest.mark.parametrize('name', list(BLOCK_FNS))
+def test_block_restatement_matches_reference_classes(name):
+    """RFB1 / ARM / Attention (models/common.py:177-207,416-466): oracle functions vs the reference's own classes (blocks.npz)"""
+    g = golden('blocks')
+    sd, _ = block_state_dict(name)
+    sd = {'m.' + k: v for k, v in sd.items()}
+    params = {k: v.requires_grad_() for k, v in sd.items() if v.dtype.is_floating_point and 'running' not in k}
+    x = torch.from_numpy(g[f'{name}/x']).requires_grad_()
+    ctx = model_ref.Ctx(sd, True, dropout_p=0.0)
+    y = BLOCK_FNS[name](ctx, 'm', x)
+    np.testing.assert_allclose(y.detach().numpy(), g[f'{name}/train_out'], rtol=1e-4, atol=2e-5)
+    (y * torch.from_numpy(g[f'{name}/r'])).sum().backward()
+    np.testing.assert_allclose(x.grad.numpy(), g[f'{name}/dx'], rtol=2e-3, atol=2e-5)
+    for k, p in params.items():
+        ref = g[f'{name}/grad/' + k[2:]]
+        assert np.abs(p.grad.numpy() - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-6, k
+    for k in g.files:
+        if k.startswith(f'{name}/after/'):
+            np.testing.assert_allclose(sd['m.' + k[len(name) + 7:]].detach().numpy(), g[k], rtol=1e-4, atol=1e-6)
+    sd2, _ = block_state_dict(name)
+    with torch.no_grad():
+        ye = BLOCK_FNS[name](model_ref.Ctx({'m.' + k: v for k, v in sd2.items()}, False), 'm', torch.from_numpy(g[f'{name}/x']))
+    np.testing.assert_allclose(ye.numpy(), g[f'{name}/eval_out'], rtol=1e-4, atol=2e-5)

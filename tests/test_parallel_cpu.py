@@ -79,3 +79,34 @@ def test_layout_single_process():
     b = red.layout([10, 10, 10, 10], [0, 3, 5, 9])
     assert b == [(20, 40, 5), (0, 20, 0)]
     assert GradReducer(M(), 1).layout([5], [2]) == [(0, 5, 2)]
+
+
+def test_reducer_is_not_pickled_or_deepcopied_with_the_model(tmp_path):
+    """train.py:481-499 deep-copies and torch.saves the model (and ModelEMA deep-copies it) with the gradient exchange attached:
+    the GradReducer (process group, HIP stream, Work handles) and every other runtime key must stay out of the copy / the file"""
+    import copy
+    import io
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.common import Conv
+    from multiyolov5_amd.parallel import GradReducer
+
+    class Unpicklable:                       # stands in for the ProcessGroup / Stream members
+        def __reduce__(self):
+            raise TypeError('process groups do not pickle')
+    m = Conv(8, 16, 3)
+    red = GradReducer(m, world_size=2)
+    red.group = Unpicklable()
+    m.__dict__['_plans'] = {'k': Unpicklable()}
+    m.__dict__['_tensor_list'] = [Unpicklable()]
+    assert '_grad_reducer' in m.__dict__
+    st = m.__getstate__()
+    assert not any(k in st for k in R.PlannedModule._RUNTIME_STATE)
+    c = copy.deepcopy(m)
+    assert not any(k in c.__dict__ for k in R.PlannedModule._RUNTIME_STATE)
+    buf = io.BytesIO()
+    torch.save({'model': m}, buf)
+    buf.seek(0)
+    back = torch.load(buf, weights_only=False)['model']
+    assert not any(k in back.__dict__ for k in R.PlannedModule._RUNTIME_STATE)
+    assert torch.equal(back.conv.weight, m.conv.weight)
+    assert m.__dict__['_grad_reducer'] is red         # the live model keeps its reducer
