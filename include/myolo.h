@@ -35,7 +35,7 @@ extern "C" {
 
 #define MYOLO_EINVAL (-22)
 #define MYOLO_MAX_TAPS 25
-#define MYOLO_STAT_COPIES 8
+#define MYOLO_STAT_COPIES 32
 
 typedef struct myolo_tensor {
   void*   ptr;
@@ -50,7 +50,9 @@ int myolo_version(void);                 /* ABI version of this header */
 const char* myolo_arch(void);            /* "gfx950" */
 
 /* tuning / test knobs: "stream_min_tiles" (minimum number of 32-pixel row tiles for the streaming conv kernel, default 2048; the
- * parity tests set 1 so that small shapes exercise it), "stream_off" (1: always use the LDS-tiled kernel).  Returns 0 or MYOLO_EINVAL. */
+ * parity tests set 1 so that small shapes exercise it), "stream_off" (1: always use the LDS-tiled kernel), "halo_min_tiles" (minimum
+ * number of output tiles for the LDS-halo k x k kernel, default 96; tests set 1), "halo_off" (1: never use it).  Returns 0 or
+ * MYOLO_EINVAL. */
 int myolo_set_option(const char* name, int value);
 
 /* ---- weights ------------------------------------------------------------------------------- */
@@ -80,7 +82,7 @@ int myolo_focus_pack(const void* img_nchw, int src_dtype, int n, int h, int w, f
  *   y[n,oy,ox,:] (+)= epilogue( sum_t  x[n, (oy*stride+tap_dy[t])>>up, (ox*stride+tap_dx[t])>>up, :] . W[:,tap_w[t],:] )
  *   epilogue(v) = act(v*scale[c] + shift[c]) + res      (each part optional)
  *   stats != NULL: atomically accumulates per-channel sum / sum of squares of the raw fp32 accumulators into ONE of
- *                  MYOLO_STAT_COPIES (8) interleaved copies [copy][2][cout] (copy = workgroup id % 8; the consumer adds the
+ *                  MYOLO_STAT_COPIES (32) interleaved copies [copy][2][cout] (copy = workgroup id % 32; the consumer adds the
  *                  copies): stats is fp32[8*2*cout], zeroed by the caller   (training-mode BatchNorm statistics)
  *   det_no  > 0 : y is written in Detect's permuted layout [n, na, h, w, det_no] (yolo.py:214)           */
 typedef struct myolo_conv_desc {

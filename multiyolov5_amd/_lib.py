@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'libmyolo.so')
 F32, F16, U8, I64 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
 MAX_TAPS = 25
-STAT_COPIES = 8         # include/myolo.h MYOLO_STAT_COPIES
+STAT_COPIES = 32        # include/myolo.h MYOLO_STAT_COPIES
 DT = {torch.float32: F32, torch.float16: F16, torch.uint8: U8, torch.int64: I64}
 TORCH_DT = {F32: torch.float32, F16: torch.float16}
 

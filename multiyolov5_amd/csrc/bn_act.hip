@@ -43,12 +43,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float sc = 1.f, sh = 0.f;
     if (gamma) {
-      float ssum = 0.f, qsum = 0.f;
-#pragma unroll
-      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { ssum += stats[k * 2 * C + c]; qsum += stats[k * 2 * C + C + c]; }
-      const float mean = ssum / (float)M;
-      float var = qsum / (float)M - mean * mean;
-      var = var > 0.f ? var : 0.f;
+      // the copies are combined and E[x^2] - mean^2 is formed in fp64: the fp32 partial sums are exact to ~1e-7 each, the
+      // cancellation (|mean| >> std channels) happens in double
+      double ssum = 0.0, qsum = 0.0;
+#pragma unroll 8
+      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { ssum += (double)stats[k * 2 * C + c]; qsum += (double)stats[k * 2 * C + C + c]; }
+      const double meand = ssum / (double)M;
+      double vard = qsum / (double)M - meand * meand;
+      const float mean = (float)meand;
+      float var = vard > 0.0 ? (float)vard : 0.f;
       const float invstd = rsqrtf(var + eps);
       sc = gamma[c] * invstd;
       sh = beta[c] - mean * sc;

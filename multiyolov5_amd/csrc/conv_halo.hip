@@ -1,0 +1,394 @@
+// LDS-staged input tiles for the k x k (3x3, dilated 3x3, 5x5) stride-1 convolutions and their dgrads (fp16).
+//
+//   The streaming kernel (conv_stream.hip) re-issues the global loads of the same pixel rows once per tap: fine for 1x1, but a 3x3
+//   layer pulls every input byte nine times through the vector-memory path (64->64 @64x128 ran at 0.08 of its roofline).
+//   Here a workgroup (4 waves) owns an output tile of TH x 32 pixels of one image and
+//     * stages the tile's input HALO ((TH+kh-1) x (32+kw-1) pixels) through LDS once per 32-channel chunk, double buffered: the
+//       global loads of chunk s+1 are in flight (registers) while chunk s is computed, one barrier per chunk;
+//     * serves all taps from LDS: an MFMA B fragment (16 consecutive pixels of one halo row, 16-byte K segment lane>>4) is one
+//       ds_read_b128 at (pixel + tap offset); halo pixels are 64-byte rows whose 16-byte segment index is XOR-ed with
+//       2*bit2(pixel), which is conflict-free for the ds_read_b128 lane groups at EVERY pixel alignment (the +-1 / +-d tap shifts);
+//     * keeps the whole weight panel of its N tile ([BN][taps*cin_pad]) in LDS for the life of the (persistent) workgroup;
+//     * issues the MFMA as D^T = W . X^T (lane = pixel, 4 consecutive channels per lane): 8-byte NHWC stores from registers,
+//       BatchNorm statistics accumulated per lane and flushed once per workgroup.
+//   Out-of-image halo pixels and padded channels are masked by the buffer-resource bounds check (no branches, no zero page).
+//   Tiles are dealt in XCD-contiguous ranges (neighbouring tiles share halo rows in one L2).
+//
+// Same contract as myolo_conv (include/myolo.h); selected by myolo_conv when the layer qualifies.
+#include "myolo_dev.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace halo {
+
+constexpr int THREADS = 256;
+constexpr int TW = 32;
+constexpr int KCH = 32;             // halves per chunk = one 64-byte LDS pixel row
+
+struct ConvH {
+  const char* x; int64_t x_sn, x_sh, x_sw; int Hi, Wi, Cin;
+  char* y; int64_t y_sn, y_sh, y_sw; int Ho, Wo, Cout, N;
+  const char* w; int cin_pad, cout_pad, wtaps, ntaps;
+  int tap_off[MYOLO_MAX_TAPS], tap_w[MYOLO_MAX_TAPS];      // halo-relative pixel offset (dy+oy0)*hw + (dx+ox0)
+  const float* scale; const float* shift; int act; int accumulate;
+  const char* res; int64_t r_sn, r_sh, r_sw;
+  float* stats;
+  int tiles_x, tiles_y, ntiles, tiles_per_xcd, pitchB;
+  int hw, hh, ox0, oy0, nvec;        // halo width / height (pixels), origin offset (= -min dx, -min dy), 16-byte vectors per chunk
+  int x_bytes, y_bytes, r_bytes;
+  int xbuf_bytes;                    // bytes of one halo buffer
+  int dbg;                           // profiling only (set_option "halo_dbg"): 1 no stores, 2 no global loads, 4 no MFMA, 8 no panel
+};
+
+__device__ __forceinline__ int swzB(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // weight panel: H = {0,2,3,1}
+__device__ __forceinline__ int xoff(int pix, int seg) { return pix * 64 + ((seg ^ ((pix >> 1) & 2)) << 4); }   // halo tile
+
+// MF: 16-pixel fragments per wave (4: tile 8 x 32, 2: tile 4 x 32); NVT: staging vectors per thread and chunk
+// EPI 0: raw output (+ BatchNorm statistics); EPI 1: scale/shift + activation (eval).  EXTRA: residual / accumulate loads.
+template <int BN, int MF, int NVT, int EPI, int EXTRA>
+__global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
+  constexpr int NF = BN / 16;
+  constexpr int TH = MF * 2;          // 4 waves x (MF/2) rows x 2 fragments per row
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sB = smem;                                                        // [BN][pitchB] weight panel
+  float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [2][BN] scale, shift
+  int* sTap = reinterpret_cast<int*>(sT + 2 * BN);                        // [MAX_TAPS] halo pixel offset of each tap
+  char* sX = reinterpret_cast<char*>(sTap + 32);                          // [2][xbuf_bytes]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int tn = blockIdx.y;
+
+  // ---- epilogue constants / tap table, once per workgroup (the weight panel is staged below, behind the first halo loads) ----
+  if (EPI == 1)
+    for (int c = tid; c < BN; c += THREADS) {
+      const int cg = tn * BN + c;
+      sT[c] = (p.scale && cg < p.Cout) ? p.scale[cg] : 1.0f;
+      sT[BN + c] = (p.shift && cg < p.Cout) ? p.shift[cg] : 0.0f;
+    }
+  for (int t = tid; t < p.ntaps; t += THREADS) sTap[t] = p.tap_off[t];
+
+  constexpr int OOB = 0x7fff0000;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.res ? p.res : p.y), 0, p.res ? p.r_bytes : 0, 0x00020000);
+
+  // ---- staging roles: vector v = tid + j*256 of a chunk = (halo pixel v>>2, 16-byte segment v&3) ----
+  int s_rel[NVT], s_pyx[NVT], s_lds[NVT];
+#pragma unroll
+  for (int j = 0; j < NVT; ++j) {
+    const int v = tid + j * THREADS;
+    const int pv = v >> 2, seg = v & 3;
+    const int py = pv / p.hw, px = pv - py * p.hw;
+    const bool in = v < p.nvec;
+    s_pyx[j] = in ? ((py << 16) | px) : -1;
+    s_rel[j] = (py * (int)p.x_sh + px * (int)p.x_sw) * 2 + seg * 16;
+    s_lds[j] = xoff(pv, seg);
+  }
+  const int seg_c = (tid & 3) * 8;      // first channel of this thread's segment inside a chunk
+
+  // ---- tiles of this workgroup: XCD-contiguous ranges ----
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, sstride = gridDim.x >> 3;
+  const int tile_lo = xcd * p.tiles_per_xcd;
+  int tile_hi = tile_lo + p.tiles_per_xcd;
+  if (tile_hi > p.ntiles) tile_hi = p.ntiles;
+  const int my_first = tile_lo + slot;
+  const int ntl = my_first < tile_hi ? (tile_hi - my_first + sstride - 1) / sstride : 0;
+  const int kchunks = p.cin_pad / KCH;
+  const int nsteps = ntl * kchunks;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+
+  // issue cursor
+  int i_tile = my_first, i_kc = 0;
+  int i_base = 0, i_mask = 0;           // byte offset of the halo origin of the tile; per-vector validity bits
+  auto decode_issue = [&]() {
+    const int n = i_tile / tiles_per_img; const int r = i_tile - n * tiles_per_img;
+    const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
+    const int hy0 = ty * TH - p.oy0, hx0 = tx * TW - p.ox0;
+    i_base = (n * (int)p.x_sn + hy0 * (int)p.x_sh + hx0 * (int)p.x_sw) * 2;
+    i_mask = 0;
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+      const int py = s_pyx[j] >> 16, px = s_pyx[j] & 0xffff;
+      const bool ok = s_pyx[j] >= 0 && (unsigned)(hy0 + py) < (unsigned)p.Hi && (unsigned)(hx0 + px) < (unsigned)p.Wi;
+      i_mask |= ok ? (1 << j) : 0;
+    }
+  };
+  uint4 stage[NVT];
+  auto issue = [&]() {
+    const int cb = i_kc * KCH;
+    const bool cok = cb + seg_c < p.Cin;
+#pragma unroll
+    for (int j = 0; j < NVT; ++j) {
+      const bool ok = cok && ((i_mask >> j) & 1) && !(p.dbg & 2);
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? i_base + s_rel[j] + cb * 2 : OOB, 0, 0);
+      stage[j] = uint4{v.x, v.y, v.z, v.w};
+    }
+    if (++i_kc == kchunks) { i_kc = 0; i_tile += sstride; }
+  };
+  auto commit = [&](int buf) {          // registers -> LDS halo buffer
+    char* dst = sX + buf * p.xbuf_bytes;
+#pragma unroll
+    for (int j = 0; j < NVT; ++j)
+      if (s_pyx[j] >= 0) *reinterpret_cast<uint4*>(dst + s_lds[j]) = stage[j];
+  };
+
+  // compute cursor
+  int c_tile = my_first, c_kc = 0;
+  f4_t acc[MF][NF];
+#pragma unroll
+  for (int i = 0; i < MF; ++i)
+#pragma unroll
+    for (int j = 0; j < NF; ++j) acc[i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  float st_s[NF][4], st_q[NF][4];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st_s[nf][r] = 0.f; st_q[nf][r] = 0.f; }
+
+  // this lane's pixel inside the halo tile for each of its fragments, at tap offset 0
+  int pbase[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) pbase[mf] = (wave * (MF / 2) + (mf >> 1)) * p.hw + (mf & 1) * 16 + l15;
+
+  auto epilogue = [&](int tile) {
+    const int n = tile / tiles_per_img; const int r0 = tile - n * tiles_per_img;
+    const int ty = r0 / p.tiles_x, tx = r0 - ty * p.tiles_x;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int oy = ty * TH + wave * (MF / 2) + (mf >> 1), ox = tx * TW + (mf & 1) * 16 + l15;
+      const bool mok = oy < p.Ho && ox < p.Wo && !(p.dbg & 1);
+      const int yoff = (n * (int)p.y_sn + oy * (int)p.y_sh + ox * (int)p.y_sw) * 2;
+      const int roff = EXTRA ? (n * (int)p.r_sn + oy * (int)p.r_sh + ox * (int)p.r_sw) * 2 : 0;
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const int cl = nf * 16 + 4 * lq;
+        const int c0 = tn * BN + cl;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v0 = acc[mf][nf][r];
+          acc[mf][nf][r] = 0.f;
+          if (EPI == 0) { v[r] = v0; if (mok) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; } }
+          else v[r] = act_f(v0 * sT[cl + r] + sT[BN + cl + r], p.act);
+        }
+        const bool ok = mok && c0 < p.Cout;
+        if (EXTRA) {
+          if (p.res) {
+            const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(rr, ok ? roff + c0 * 2 : OOB, 0, 0);
+            const h4_t gh = *reinterpret_cast<const h4_t*>(&g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)gh[r];
+          }
+          if (p.accumulate) {
+            const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
+            const h4_t gh = *reinterpret_cast<const h4_t*>(&g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)gh[r];
+          }
+        }
+        h4_t o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2_t*>(&o), ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
+      }
+    }
+  };
+
+  auto load_frags = [&](int t, const char* xb, uint4* fa, uint4* fb) {
+    const int toff = sTap[t];
+    const char* brow = sB + l15 * p.pitchB + (t * p.cin_pad + c_kc * KCH) * 2 + ((lq ^ swzB(l15)) << 4);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) fb[nf] = *reinterpret_cast<const uint4*>(brow + nf * 16 * p.pitchB);
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) fa[mf] = *reinterpret_cast<const uint4*>(xb + xoff(pbase[mf] + toff, lq));
+  };
+  auto mma = [&](const uint4* fa, const uint4* fb) {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)   // weights as the A operand, pixels as the B operand: D[cout][pixel]
+        acc[mf][nf] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8_t*>(&fb[nf]),
+                                                             *reinterpret_cast<const h8_t*>(&fa[mf]), acc[mf][nf], 0, 0, 0);
+  };
+
+  // ---- pipeline over (tile, chunk) steps ----
+  if (nsteps > 0) {
+    decode_issue();
+    issue();                             // the first halo chunk is in flight while the weight panel is staged
+  }
+  if (!(p.dbg & 8)) stage_weight_panel<BN, THREADS>(sB, p.w, tn, p.pitchB, p.cin_pad, p.ntaps, p.wtaps, p.tap_w, tid);
+  if (nsteps > 0) commit(0);
+  __syncthreads();                       // weight panel, tables and the first halo chunk are in LDS
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < nsteps;
+    if (more) {
+      if (i_kc == 0) decode_issue();     // (i_tile already advanced by the previous issue)
+      issue();                           // global loads of step s+1: in flight during the MFMAs below
+    }
+    const char* xb = sX + buf * p.xbuf_bytes;
+    uint4 fa0[MF], fb0[NF], fa1[MF], fb1[NF];
+    load_frags(0, xb, fa0, fb0);
+    int t = (p.dbg & 4) ? p.ntaps : 0;
+    for (; t + 1 < p.ntaps; t += 2) {
+      load_frags(t + 1, xb, fa1, fb1);
+      mma(fa0, fb0);
+      if (t + 2 < p.ntaps) load_frags(t + 2, xb, fa0, fb0);
+      mma(fa1, fb1);
+    }
+    if ((p.ntaps & 1) && !(p.dbg & 4)) mma(fa0, fb0);
+    if (++c_kc == kchunks) { c_kc = 0; epilogue(c_tile); c_tile += sstride; }
+    if (more) commit(buf ^ 1);
+    __syncthreads();
+  }
+
+  if (EPI == 0 && p.stats) {
+    float* red = reinterpret_cast<float*>(sX);         // [4 waves][2*BN]; the loop ended with a barrier
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = st_s[nf][r], q2 = st_q[nf][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q2 += __shfl_xor(q2, o, 64); }
+        if (l15 == 0) {
+          const int cl = nf * 16 + 4 * lq + r;
+          red[wave * 2 * BN + cl] = s;
+          red[wave * 2 * BN + BN + cl] = q2;
+        }
+      }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += THREADS) {
+      const float a = red[t] + red[2 * BN + t] + red[4 * BN + t] + red[6 * BN + t];
+      const int cl = t < BN ? t : t - BN;
+      const int c = tn * BN + cl;
+      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
+    }
+  }
+}
+
+template <int BN, int MF, int NVT, int EPI, int EXTRA>
+int launch4(const ConvH& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
+  auto kern = conv_halo_kernel<BN, MF, NVT, EPI, EXTRA>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+template <int BN, int MF, int NVT>
+int launch3(const ConvH& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
+  const bool raw = !k.scale && !k.shift && k.act == MYOLO_ACT_NONE;
+  const bool extra = k.res != nullptr || k.accumulate;
+  if (raw) return extra ? launch4<BN, MF, NVT, 0, 1>(k, grid_x, ntile_n, smem, st) : launch4<BN, MF, NVT, 0, 0>(k, grid_x, ntile_n, smem, st);
+  return extra ? launch4<BN, MF, NVT, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<BN, MF, NVT, 1, 0>(k, grid_x, ntile_n, smem, st);
+}
+template <int BN, int MF>
+int launch2(const ConvH& k, int nvt, int grid_x, int ntile_n, int smem, hipStream_t st) {
+  return nvt <= 6 ? launch3<BN, MF, 6>(k, grid_x, ntile_n, smem, st) : launch3<BN, MF, 10>(k, grid_x, ntile_n, smem, st);
+}
+
+}  // namespace halo
+
+static inline int halo_panel_pitch(int K) {                    // bytes; multiple of 64 with an odd number of 64-byte blocks
+  int blocks = (K * 2 + 63) / 64;
+  if (!(blocks & 1)) ++blocks;
+  return blocks * 64;
+}
+
+static int g_halo_off = -1;          // -1: from the environment (MYOLO_NO_HALO)
+static int g_halo_dbg = 0;
+static int g_halo_min_tiles = -1;    // minimum number of 8x32 tiles (MYOLO_HALO_MIN_TILES, default 16)
+
+int myolo_conv_halo_set(const char* name, int value) {
+  if (!strcmp(name, "halo_off")) { g_halo_off = value; return 0; }
+  if (!strcmp(name, "halo_min_tiles")) { g_halo_min_tiles = value; return 0; }
+  if (!strcmp(name, "halo_dbg")) { g_halo_dbg = value; return 0; }
+  return myolo_wgrad_tile_set(name, value);        // "wgrad_tile_off"
+}
+
+// returns -1 when the layer does not qualify (caller falls back to the other kernels), else a hipError_t / 0
+int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream) {
+  using namespace halo;
+  if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
+  if (g_halo_min_tiles < 0) g_halo_min_tiles = getenv("MYOLO_HALO_MIN_TILES") ? atoi(getenv("MYOLO_HALO_MIN_TILES")) : 16;
+  if (g_halo_off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
+  if (d->ntaps < 2 || d->stride != 1 || d->up_shift != 0 || d->cin_pad % KCH) return -1;
+  if (d->x.h != d->y.h || d->x.w != d->y.w) return -1;
+  if (d->stats && (d->scale || d->shift || d->act != MYOLO_ACT_NONE)) return -1;
+  int mindy = 0, maxdy = 0, mindx = 0, maxdx = 0;
+  for (int t = 0; t < d->ntaps; ++t) {
+    mindy = d->tap_dy[t] < mindy ? d->tap_dy[t] : mindy; maxdy = d->tap_dy[t] > maxdy ? d->tap_dy[t] : maxdy;
+    mindx = d->tap_dx[t] < mindx ? d->tap_dx[t] : mindx; maxdx = d->tap_dx[t] > maxdx ? d->tap_dx[t] : maxdx;
+  }
+  const int K = d->ntaps * d->cin_pad;
+  // K > 832 (128-channel 3x3 and up): only a 32-wide N tile of the panel fits beside the halo buffers, the input would be staged
+  // Cout/32 times and the LDS-tiled kernel measured faster (27 vs 31 us at 128->128, 32x64)
+  static const int max_k = getenv("MYOLO_HALO_MAX_K") ? atoi(getenv("MYOLO_HALO_MAX_K")) : 832;
+  if (K > max_k) return -1;
+  const int pitch = halo_panel_pitch(K);
+  const int64_t px_total = (int64_t)d->y.n * d->y.h * d->y.w;
+  // tile height: 8 rows unless that leaves the chip short of workgroups
+  int bn = 0, mf = 0, hh = 0, hw = 0, nvt = 0, xbuf = 0, smem = 0;
+  const int bns[2] = {64, 32};
+  for (int bi = 0; bi < 2 && !bn; ++bi) {
+    const int b = bns[bi];
+    if (d->cout_pad % b) continue;
+    for (int m = 4; m >= 2 && !bn; m -= 2) {
+      const int th = m * 2;
+      const int64_t tiles = (int64_t)d->y.n * ((d->y.h + th - 1) / th) * ((d->y.w + TW - 1) / TW) * (d->cout_pad / b);
+      if (m == 4 && tiles < 384 && d->y.h > 4) continue;            // < 1.5 workgroups per CU: use 4-row tiles
+      const int hh_ = th + (maxdy - mindy), hw_ = TW + (maxdx - mindx);
+      const int nvec = hh_ * hw_ * 4;
+      const int nvt_ = (nvec + THREADS - 1) / THREADS;
+      if (nvt_ > 10) continue;
+      const int xb = hh_ * hw_ * 64;
+      const int sm = b * pitch + 2 * b * 4 + 32 * 4 + 2 * xb;
+      if (sm > 160 * 1024) continue;
+      bn = b; mf = m; hh = hh_; hw = hw_; nvt = nvt_; xbuf = xb; smem = sm;
+    }
+  }
+  if (!bn) return -1;
+  ConvH k;
+  k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw;
+  k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;
+  k.y = (char*)d->y.ptr; k.y_sn = d->y.sn; k.y_sh = d->y.sh; k.y_sw = d->y.sw;
+  k.Ho = d->y.h; k.Wo = d->y.w; k.Cout = d->y.c; k.N = d->y.n;
+  k.w = (const char*)d->w; k.cin_pad = d->cin_pad; k.cout_pad = d->cout_pad; k.wtaps = d->wtaps; k.ntaps = d->ntaps;
+  k.ox0 = -mindx; k.oy0 = -mindy; k.hw = hw; k.hh = hh; k.nvec = hh * hw * 4; k.xbuf_bytes = xbuf;
+  for (int i = 0; i < MYOLO_MAX_TAPS; ++i) {
+    k.tap_off[i] = i < d->ntaps ? (d->tap_dy[i] - mindy) * hw + (d->tap_dx[i] - mindx) : 0;
+    k.tap_w[i] = d->tap_w[i];
+  }
+  k.scale = d->scale; k.shift = d->shift; k.act = d->act; k.accumulate = d->accumulate;
+  k.res = (const char*)d->res.ptr; k.r_sn = d->res.sn; k.r_sh = d->res.sh; k.r_sw = d->res.sw;
+  k.stats = d->stats; k.dbg = g_halo_dbg;
+  const int th = mf * 2;
+  k.tiles_x = (k.Wo + TW - 1) / TW; k.tiles_y = (k.Ho + th - 1) / th;
+  const int64_t nt = (int64_t)k.N * k.tiles_x * k.tiles_y;
+  if (px_total <= 0 || nt > 0x3fffffff) return MYOLO_EINVAL;
+  k.ntiles = (int)nt;
+  if (k.ntiles * (d->cout_pad / bn) < g_halo_min_tiles) return -1;     // tiny maps: launch-latency bound either way
+  k.tiles_per_xcd = (k.ntiles + 7) / 8;
+  k.pitchB = pitch;
+  auto span = [](const myolo_tensor& t) -> int64_t {
+    return (((int64_t)t.n - 1) * t.sn + ((int64_t)t.h - 1) * t.sh + ((int64_t)t.w - 1) * t.sw + t.c) * 2;
+  };
+  // halo origins lie up to (oy0 rows + ox0 pixels) before the view: offsets are formed in 32-bit signed arithmetic
+  const int64_t xb = span(d->x), yb = span(d->y), rb = d->res.ptr ? span(d->res) : 0;
+  if (xb >= 0x3ffe0000LL || yb >= 0x3ffe0000LL || rb >= 0x3ffe0000LL) return -1;
+  k.x_bytes = (int)xb; k.y_bytes = (int)yb; k.r_bytes = (int)rb;
+  const int ntile_n = d->cout_pad / bn;
+  int per_cu = (160 * 1024) / (smem + 512);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int per_xcd = 32 * per_cu / ntile_n;
+  if (per_xcd < 1) per_xcd = 1;
+  if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
+  const int grid_x = per_xcd * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (bn == 64) return mf == 4 ? launch2<64, 4>(k, nvt, grid_x, ntile_n, smem, st) : launch2<64, 2>(k, nvt, grid_x, ntile_n, smem, st);
+  return mf == 4 ? launch2<32, 4>(k, nvt, grid_x, ntile_n, smem, st) : launch2<32, 2>(k, nvt, grid_x, ntile_n, smem, st);
+}

@@ -350,8 +350,10 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   if (d->x.c % seg || d->x.sw % seg || d->x.sh % seg || d->x.sn % seg || ((uintptr_t)d->x.ptr & 15)) return MYOLO_EINVAL;
   if (d->det_no > 0 && (d->y.c % d->det_no)) return MYOLO_EINVAL;
   if (d->res.ptr && d->res.dtype != dt) return MYOLO_EINVAL;
-  if (dt == MYOLO_F16) {                       // HBM-bound layers: the streaming kernel (conv_stream.hip)
-    const int r = myolo_conv_stream_try(d, stream);
+  if (dt == MYOLO_F16) {
+    int r = myolo_conv_halo_try(d, stream);    // k x k stride-1 layers: input halo tiles staged in LDS (conv_halo.hip)
+    if (r != -1) return r;
+    r = myolo_conv_stream_try(d, stream);      // HBM-bound 1x1 / strided layers: the streaming kernel (conv_stream.hip)
     if (r != -1) return r;
   }
   ConvK k;

@@ -47,19 +47,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
   const int l15 = lane & 15, lq = lane >> 4;
   const int tn = blockIdx.y;
 
-  // ---- stage the weight panel once ----
-  {
-    const int vec_per_tap = p.cin_pad / 8;
-    const int vec_per_row = p.ntaps * vec_per_tap;
-    const int total = BN * vec_per_row;
-    for (int v = tid; v < total; v += THREADS) {
-      const int r = v / vec_per_row; const int q = v - r * vec_per_row;
-      const int t = q / vec_per_tap; const int s = q - t * vec_per_tap;
-      const uint4 val = ldg16(p.w + ((int64_t)((tn * BN + r) * p.wtaps + p.tap_w[t]) * p.cin_pad + s * 8) * 2);
-      const int g = t * vec_per_tap + s;                      // 16-byte segment index inside the panel row
-      *reinterpret_cast<uint4*>(sB + r * p.pitchB + (g >> 2) * 64 + (((g & 3) ^ swz(r)) << 4)) = val;
-    }
-  }
+  // (the weight panel is staged further down, BEHIND the first activation loads: both are ~2 us round trips at kernel start)
   // epilogue constants live in LDS: a global load inside the epilogue would sit BEHIND the prefetched activations in the
   // in-order vmcnt queue and drain the whole pipeline every tile
   float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [2][BN] scale, shift
@@ -251,6 +239,9 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
   // ---- software pipeline: RING-1 chunks in flight ----
 #pragma unroll
   for (int j = 0; j < RING - 1; ++j) issue(ring[j]);
+  // ---- stage the weight panel once (the activation loads above are already in flight) ----
+  stage_weight_panel<BN, THREADS>(sB, p.w, tn, p.pitchB, p.cin_pad, p.ntaps, p.wtaps, p.tap_w, tid);
+  __syncthreads();
   for (int q = 0; q < nchunks; q += RING) {
 #pragma unroll
     for (int j = 0; j < RING; ++j) {
@@ -322,12 +313,17 @@ static inline int panel_pitch(int K) {                    // bytes; multiple of 
 // returns -1 when the layer does not qualify (caller falls back to the LDS-tiled kernel), else a hipError_t / 0
 static int g_stream_min_tiles = -1;      // -1: from the environment (MYOLO_STREAM_MIN_TILES) or 2048
 static int g_stream_off = -1;
+static int g_stream_dbg = -1;           // profiling only: 1 no stores, 2 no activation loads
+static int g_stream_per_cu = 0;         // 0: default (2 workgroups per CU when LDS allows)
 
 extern "C" int myolo_set_option(const char* name, int value) {
   if (!name) return MYOLO_EINVAL;
   if (!strcmp(name, "stream_min_tiles")) { g_stream_min_tiles = value; return 0; }
   if (!strcmp(name, "stream_off")) { g_stream_off = value; return 0; }
-  return MYOLO_EINVAL;
+  if (!strcmp(name, "stream_dbg")) { g_stream_dbg = value; return 0; }
+  if (!strcmp(name, "stream_per_cu")) { g_stream_per_cu = value; return 0; }
+  return myolo_conv_halo_set(name, value);      // "halo_off", "halo_min_tiles"
+
 }
 
 int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
@@ -371,8 +367,8 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   k.ydense = dense(k.y_sn, k.y_sh, k.y_sw, k.Ho, k.Wo) && (!k.res || dense(k.r_sn, k.r_sh, k.r_sw, k.Ho, k.Wo));
   k.xdense = d->ntaps == 1 && d->stride == 1 && d->up_shift == 0 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 &&
              k.Hi == k.Ho && k.Wi == k.Wo && dense(k.x_sn, k.x_sh, k.x_sw, k.Hi, k.Wi);
-  static const int dbg = getenv("MYOLO_STREAM_DBG") ? atoi(getenv("MYOLO_STREAM_DBG")) : 0;
-  k.dbg = dbg;
+  if (g_stream_dbg < 0) g_stream_dbg = getenv("MYOLO_STREAM_DBG") ? atoi(getenv("MYOLO_STREAM_DBG")) : 0;
+  k.dbg = g_stream_dbg;
   if (k.stats && (k.scale || k.shift || k.act != MYOLO_ACT_NONE)) return -1;   // statistics only with the raw epilogue
   auto span = [](const myolo_tensor& t) -> int64_t {
     return (((int64_t)t.n - 1) * t.sn + ((int64_t)t.h - 1) * t.sh + ((int64_t)t.w - 1) * t.sw + t.c) * 2;
@@ -384,7 +380,10 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   if (smem < WAVES * 2 * bn * 4) smem = WAVES * 2 * bn * 4;
   const int ntile_n = d->cout_pad / bn;
   int per_cu = (160 * 1024) / (smem + 1024);
-  if (per_cu > 2) per_cu = 2;                          // 8-wave workgroups: 2 per CU at <= 128 VGPRs
+  // ONE 8-wave workgroup per CU: measured on the 1x1 layers of the step (64..384 channels at 64x128 / 128x256) 256 workgroups beat
+  // 512 by 15-30 % -- half the weight-panel fills and half the same-address statistics atomics, two tiles per wave to pipeline
+  if (per_cu > 1) per_cu = 1;
+  if (g_stream_per_cu > 0) per_cu = g_stream_per_cu;
   if (per_cu < 1) per_cu = 1;
   int per_xcd = 32 * per_cu / ntile_n;                 // 32 CUs per XCD
   if (per_xcd < 1) per_xcd = 1;

@@ -493,6 +493,21 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   if (d->ntaps < 1 || d->ntaps > MYOLO_MAX_TAPS) return MYOLO_EINVAL;
   if (d->x.c % seg || d->x.sw % seg || d->x.sh % seg || d->x.sn % seg || ((uintptr_t)d->x.ptr & 15)) return MYOLO_EINVAL;
   if (d->dy.sw % seg || d->dy.sh % seg || d->dy.sn % seg || ((uintptr_t)d->dy.ptr & 15)) return MYOLO_EINVAL;
+  if (dt == MYOLO_F16 && !((d->cin > 0 ? d->cin : d->x.c) <= 16 && d->ntaps == 9)) {      // (Focus-sized 3x3: the compact kernel below)
+    int ks2 = 0, cop = 0, cip = 0, uws = 0;
+    const int r = myolo_wgrad_tile_try(d, stream, &ks2, &cop, &cip, &uws);     // LDS-staged spatial tiles (conv_wgrad_tile.hip)
+    if (r != -1) {
+      if (r != 0) return r;
+      if (uws) {
+        const int cw = d->cout > 0 ? d->cout : d->dy.c, iw = d->cin > 0 ? d->cin : d->x.c;
+        const int64_t total = (int64_t)d->ntaps * cw * iw;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, (hipStream_t)stream, d->ws, d->dw, ks2,
+                           d->ntaps, cop, cip, cw, iw);
+        MYOLO_CHECK_LAUNCH();
+      }
+      return 0;
+    }
+  }
   WgradK k;
   k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw; k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;
   k.dy = (const char*)d->dy.ptr; k.d_sn = d->dy.sn; k.d_sh = d->dy.sh; k.d_sw = d->dy.sw;

@@ -1,0 +1,280 @@
+// Weight gradient with LDS-staged spatial tiles (fp16), 1x1 and 3x3 (any dilation), stride 1 or 2.
+//
+//   dW[co][ci][t] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, oy*s + dy_t, ox*s + dx_t, ci]
+//
+// The per-tap / fused kernels of conv_wgrad.hip stage a 32-pixel K step per barrier pair and load every shifted x tile of a 3x3
+// separately (9 global loads and 9 LDS stores per pixel and step: r1 profile 92 us for a 64->64 layer whose operands stream in 6 us).
+// Here a workgroup owns a [32*COF x 32*CIF] block of the gradient for ALL taps and walks TH x 32-pixel tiles of the feature map:
+//   * waves 4..7 are LOADERS: they bring the dy tile and the x HALO tile ((TH-1)*s+kh x 31*s+kw pixels) of tile i+1 into the other
+//     LDS buffer (8 independent 16-byte loads in flight per thread) while
+//   * waves 0..3 (2 x 2 over co x ci) run the MFMAs of tile i: the K fragment is 32 consecutive pixels of one tile row; both operands
+//     are pixel-major in LDS exactly as in HBM and are read with the gfx950 transpose read ds_read_b64_tr_b16 (4 consecutive K values
+//     of the lane's own channel), the dy fragments of a row are read once and reused by all taps;
+//   * one barrier per tile; accumulators (taps x COF x CIF fragments) stay in registers over the workgroup's whole tile range
+//     (split-K over tiles: partial blocks go to the workspace of conv_wgrad.hip's reduce kernel, or fp32 atomics for 1x1).
+// x is written to LDS once per tile (halo ratio ~1.4) instead of once per tap.
+#include "myolo_dev.h"
+#include <stdlib.h>
+#include <string.h>
+
+namespace wgt {
+
+constexpr int THREADS = 512;
+constexpr int TW = 32;
+
+struct WgT {
+  const char* x; int64_t x_sn, x_sh, x_sw; int Hi, Wi, Cin;
+  const char* dy; int64_t d_sn, d_sh, d_sw; int Ho, Wo, Cout, N;
+  float* dw; float* ws;
+  int ntaps, stride;
+  int tap_off[9];                    // halo pixel offset of tap t: (dy_t - mindy) * hw + (dx_t - mindx)
+  int mindy, mindx, hw, hh, TH;
+  int tiles_x, tiles_y, ntiles, ksplit;
+  int tiles_co, tiles_ci, cout_w, cin_w;
+  int x_bytes, d_bytes;
+  int dbuf_bytes, xbuf_bytes;        // bytes of one dy / x LDS buffer
+};
+
+template <int NT, int COF, int CIF>
+__global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
+  constexpr int CO_T = 32 * COF, CI_T = 32 * CIF;
+  constexpr int PD = CO_T * 2 + 16, PX = CI_T * 2 + 16;       // LDS pixel-row pitches (bytes)
+  constexpr int DV = CO_T / 8, XV = CI_T / 8;                  // 16-byte vectors per pixel
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sD = smem;                                  // [2][TH*32][PD]
+  char* sX = smem + 2 * p.dbuf_bytes;               // [2][hh*hw][PX]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  const int tci = b % p.tiles_ci; const int tco = b / p.tiles_ci;
+  const int split = blockIdx.y;
+  const int co0 = tco * CO_T, ci0 = tci * CI_T;
+  const int tiles_per_img = p.tiles_x * p.tiles_y;
+  const int ntl = split < p.ntiles ? (p.ntiles - split + p.ksplit - 1) / p.ksplit : 0;    // tiles split, split+ksplit, ...
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------ loaders
+    const int lt = tid - 256;
+    constexpr int OOB = 0x7fff0000;
+    constexpr int U = 8;
+    const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, p.d_bytes, 0x00020000);
+    const int ndv = p.TH * TW * DV, nxv = p.hh * p.hw * XV;
+    auto load_tile = [&](int tile, int buf) {
+      const int n = tile / tiles_per_img; const int r0 = tile - n * tiles_per_img;
+      const int ty = r0 / p.tiles_x, tx = r0 - ty * p.tiles_x;
+      const int oy0 = ty * p.TH, ox0 = tx * TW;
+      char* dD = sD + buf * p.dbuf_bytes;
+      char* dX = sX + buf * p.xbuf_bytes;
+      const int dbase = (n * (int)p.d_sn + oy0 * (int)p.d_sh + ox0 * (int)p.d_sw + co0) * 2;
+      for (int base = 0; base < ndv; base += 256 * U) {
+        uint4 tmp[U]; int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = base + u * 256 + lt;
+          const int pix = v / DV, seg = v - pix * DV;
+          const int r = pix >> 5, c = pix & 31;
+          const bool ok = v < ndv && oy0 + r < p.Ho && ox0 + c < p.Wo && co0 + seg * 8 < p.Cout;
+          const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rbd, ok ? dbase + (r * (int)p.d_sh + c * (int)p.d_sw + seg * 8) * 2 : OOB, 0, 0);
+          tmp[u] = uint4{q.x, q.y, q.z, q.w};
+          dst[u] = v < ndv ? pix * PD + seg * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (dst[u] >= 0) *reinterpret_cast<uint4*>(dD + dst[u]) = tmp[u];
+      }
+      const int iy0 = oy0 * p.stride + p.mindy, ix0 = ox0 * p.stride + p.mindx;
+      const int xbase = (n * (int)p.x_sn + iy0 * (int)p.x_sh + ix0 * (int)p.x_sw + ci0) * 2;
+      for (int base = 0; base < nxv; base += 256 * U) {
+        uint4 tmp[U]; int dst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int v = base + u * 256 + lt;
+          const int pix = v / XV, seg = v - pix * XV;
+          const int py = pix / p.hw, px = pix - py * p.hw;
+          const bool ok = v < nxv && (unsigned)(iy0 + py) < (unsigned)p.Hi && (unsigned)(ix0 + px) < (unsigned)p.Wi && ci0 + seg * 8 < p.Cin;
+          const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rbx, ok ? xbase + (py * (int)p.x_sh + px * (int)p.x_sw + seg * 8) * 2 : OOB, 0, 0);
+          tmp[u] = uint4{q.x, q.y, q.z, q.w};
+          dst[u] = v < nxv ? pix * PX + seg * 16 : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (dst[u] >= 0) *reinterpret_cast<uint4*>(dX + dst[u]) = tmp[u];
+      }
+    };
+    if (ntl > 0) load_tile(split, 0);
+    __syncthreads();
+    for (int i = 0; i < ntl; ++i) {
+      if (i + 1 < ntl) load_tile(split + (i + 1) * p.ksplit, (i + 1) & 1);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ------------------------------------------------------------------ MFMA waves (2 x 2 over co x ci)
+  const int wr = wave >> 1, wc = wave & 1;
+  f4_t acc[NT][COF][CIF];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < COF; ++i)
+#pragma unroll
+      for (int j = 0; j < CIF; ++j) acc[t][i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
+  // transpose-read lane map (see conv_wgrad.hip): within a 16-lane group lane (4*k'+q) supplies the address of pixel (8g + k') (+4h),
+  // channels base+4q..4q+3, and receives the 4 consecutive pixels of channel base + (lane&15)
+  const int g = lane >> 4, kq = (lane & 15) >> 2, q = lane & 3;
+  const int dlane = (8 * g + kq) * PD + (wr * 16 * COF + q * 4) * 2;
+  const int xlane = (8 * g + kq) * p.stride * PX + (wc * 16 * CIF + q * 4) * 2;
+  __syncthreads();                                    // first tile staged
+  for (int i = 0; i < ntl; ++i) {
+    const char* bD = sD + (i & 1) * p.dbuf_bytes + dlane;
+    const char* bX = sX + (i & 1) * p.xbuf_bytes + xlane;
+    for (int r = 0; r < p.TH; ++r) {
+      h8_t fa[COF];
+#pragma unroll
+      for (int f = 0; f < COF; ++f)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const fp16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+              (__attribute__((address_space(3))) fp16x4_t*)(bD + (r * TW + 4 * h) * PD + f * 32));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fa[f][4 * h + e] = (half_t)va[e];
+        }
+      const int rowoff = r * p.stride * p.hw;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        h8_t fb[CIF];
+        const int poff = (rowoff + p.tap_off[t]) * PX;
+#pragma unroll
+        for (int f = 0; f < CIF; ++f)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                (__attribute__((address_space(3))) fp16x4_t*)(bX + poff + 4 * h * p.stride * PX + f * 32));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fb[f][4 * h + e] = (half_t)vb[e];
+          }
+#pragma unroll
+        for (int ii = 0; ii < COF; ++ii)
+#pragma unroll
+          for (int jj = 0; jj < CIF; ++jj)
+            acc[t][ii][jj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[ii], fb[jj], acc[t][ii][jj], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // acc[t][i][j][r] = D[row(co) = wr*16*COF + i*16 + 4*(lane>>4) + r][col(ci) = wc*16*CIF + j*16 + (lane&15)]
+  const int CoP = p.tiles_co * CO_T, CiP = p.tiles_ci * CI_T;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < COF; ++i)
+#pragma unroll
+      for (int j = 0; j < CIF; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = co0 + wr * 16 * COF + i * 16 + 4 * (lane >> 4) + r;
+          const int ci = ci0 + wc * 16 * CIF + j * 16 + (lane & 15);
+          if (p.ws) p.ws[(((int64_t)(split * NT + t) * CoP) + co) * CiP + ci] = acc[t][i][j][r];
+          else if (co < p.cout_w && ci < p.cin_w) atomicAdd(p.dw + ((int64_t)co * p.cin_w + ci) * NT + t, acc[t][i][j][r]);
+        }
+}
+
+template <int NT, int COF, int CIF>
+int launch(const WgT& k, int out_tiles, int smem, hipStream_t st) {
+  auto kern = wgrad_tile_kernel<NT, COF, CIF>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3(out_tiles, k.ksplit), dim3(THREADS), smem, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+template <int NT>
+int launch_nt(const WgT& k, int cof, int cif, int out_tiles, int smem, hipStream_t st) {
+  if (cof == 2 && cif == 2) return launch<NT, 2, 2>(k, out_tiles, smem, st);
+  if (cof == 2 && cif == 1) return launch<NT, 2, 1>(k, out_tiles, smem, st);
+  if (cof == 1 && cif == 2) return launch<NT, 1, 2>(k, out_tiles, smem, st);
+  return launch<NT, 1, 1>(k, out_tiles, smem, st);
+}
+
+}  // namespace wgt
+
+static int g_wgt_off = -1;
+int myolo_wgrad_tile_set(const char* name, int value) {
+  if (!strcmp(name, "wgrad_tile_off")) { g_wgt_off = value; return 0; }
+  return MYOLO_EINVAL;
+}
+
+// returns -1 when the layer does not qualify; `out_ks` / `out_cop` / `out_cip`: split count and padded block dims of the workspace
+// slices (for conv_wgrad.hip's reduce launch) when d->ws is used
+int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, int* out_cop, int* out_cip, int* used_ws) {
+  using namespace wgt;
+  if (g_wgt_off < 0) g_wgt_off = getenv("MYOLO_NO_WGRAD_TILE") != nullptr;
+  if (g_wgt_off || d->x.dtype != MYOLO_F16 || d->db || d->up_shift != 0) return -1;
+  if (d->ntaps != 1 && d->ntaps != 9) return -1;
+  if (d->stride != 1 && d->stride != 2) return -1;
+  const int cout_w = d->cout > 0 ? d->cout : d->dy.c, cin_w = d->cin > 0 ? d->cin : d->x.c;
+  if (cout_w > d->dy.c || cin_w > d->x.c) return MYOLO_EINVAL;
+  int mindy = 0, maxdy = 0, mindx = 0, maxdx = 0;
+  for (int t = 0; t < d->ntaps; ++t) {
+    mindy = d->tap_dy[t] < mindy ? d->tap_dy[t] : mindy; maxdy = d->tap_dy[t] > maxdy ? d->tap_dy[t] : maxdy;
+    mindx = d->tap_dx[t] < mindx ? d->tap_dx[t] : mindx; maxdx = d->tap_dx[t] > maxdx ? d->tap_dx[t] : maxdx;
+  }
+  const int s = d->stride;
+  const int cof = cout_w > 32 ? 2 : 1, cif = cin_w > 32 ? 2 : 1;
+  const int CO_T = 32 * cof, CI_T = 32 * cif;
+  const int PD = CO_T * 2 + 16, PX = CI_T * 2 + 16;
+  const int hw = (TW - 1) * s + 1 + (maxdx - mindx);
+  // tallest tile whose two buffer pairs fit in LDS (<= 144 KB), at most 8 rows and not taller than the map
+  int th = 0, hh = 0, smem = 0, dbuf = 0, xbuf = 0;
+  for (int t = 8; t >= 1; --t) {
+    if (t > d->dy.h && t > 1) continue;
+    const int h2 = (t - 1) * s + 1 + (maxdy - mindy);
+    const int db_ = (t * TW * PD + 15) / 16 * 16, xb_ = (h2 * hw * PX + 15) / 16 * 16;
+    const int sm = 2 * (db_ + xb_);
+    if (sm <= 144 * 1024) { th = t; hh = h2; smem = sm; dbuf = db_; xbuf = xb_; break; }
+  }
+  if (!th) return -1;
+  WgT k;
+  k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw; k.Hi = d->x.h; k.Wi = d->x.w; k.Cin = d->x.c;
+  k.dy = (const char*)d->dy.ptr; k.d_sn = d->dy.sn; k.d_sh = d->dy.sh; k.d_sw = d->dy.sw;
+  k.Ho = d->dy.h; k.Wo = d->dy.w; k.Cout = d->dy.c; k.N = d->dy.n;
+  k.dw = d->dw; k.ntaps = d->ntaps; k.stride = s;
+  k.mindy = mindy; k.mindx = mindx; k.hw = hw; k.hh = hh; k.TH = th;
+  for (int t = 0; t < 9; ++t) k.tap_off[t] = t < d->ntaps ? (d->tap_dy[t] - mindy) * hw + (d->tap_dx[t] - mindx) : 0;
+  k.tiles_x = (k.Wo + TW - 1) / TW; k.tiles_y = (k.Ho + th - 1) / th;
+  const int64_t nt = (int64_t)k.N * k.tiles_x * k.tiles_y;
+  if (nt <= 0 || nt > 0x3fffffff) return -1;
+  k.ntiles = (int)nt;
+  k.cout_w = cout_w; k.cin_w = cin_w;
+  k.tiles_co = (cout_w + CO_T - 1) / CO_T; k.tiles_ci = (cin_w + CI_T - 1) / CI_T;
+  const int out_tiles = k.tiles_co * k.tiles_ci;
+  auto span = [&](const myolo_tensor& t) -> int64_t {
+    return (((int64_t)t.n - 1) * t.sn + ((int64_t)t.h - 1) * t.sh + ((int64_t)t.w - 1) * t.sw + t.c) * 2;
+  };
+  const int64_t xb = span(d->x), db = span(d->dy);
+  if (xb >= 0x3ffe0000LL || db >= 0x3ffe0000LL) return -1;
+  k.x_bytes = (int)xb; k.d_bytes = (int)db;
+  k.dbuf_bytes = dbuf; k.xbuf_bytes = xbuf;
+  // split-K over tiles: one workgroup per CU at most (the buffers take > 80 KB), at least ~6 tiles per workgroup
+  static const int tgt = getenv("MYOLO_WGRAD_TILE_WG") ? atoi(getenv("MYOLO_WGRAD_TILE_WG")) : 192;
+  int ks = d->ksplit > 0 ? d->ksplit : (tgt + out_tiles - 1) / out_tiles;
+  const int max_ks = (k.ntiles + 5) / 6;
+  if (ks > max_ks) ks = max_ks;
+  if (ks < 1) ks = 1;
+  const int CoP = k.tiles_co * CO_T, CiP = k.tiles_ci * CI_T;
+  const int64_t slice_bytes = (int64_t)k.ntaps * CoP * CiP * sizeof(float);
+  k.ws = nullptr;
+  if (d->ws && k.ntaps > 1 && d->ws_bytes >= slice_bytes * 2 && ks > 1 && (((uintptr_t)d->ws) & 15) == 0) {
+    const int64_t fit = d->ws_bytes / slice_bytes;
+    if (ks > fit) ks = (int)fit;
+    k.ws = d->ws;
+  }
+  k.ksplit = ks;
+  *out_ks = ks; *out_cop = CoP; *out_cip = CiP; *used_ws = k.ws != nullptr;
+  hipStream_t st = (hipStream_t)stream;
+  if (k.ntaps == 9) return launch_nt<9>(k, cof, cif, out_tiles, smem, st);
+  return launch_nt<1>(k, cof, cif, out_tiles, smem, st);
+}

@@ -130,5 +130,42 @@ static inline int grid_for(int64_t work_items, int threads, int max_blocks = 204
   return (int)b;
 }
 
+// weight panel [BN][ntaps*cin_pad] of one N tile -> LDS (64-byte blocks, 16-byte segment XOR-ed with H[(row>>2)&3], H = {0,2,3,1}; row
+// pitch = odd number of 64-byte blocks): U independent 16-byte loads are in flight per thread before the first LDS store (a
+// load -> store loop serialises on one L2 round trip per iteration: ~1 us x 18 iterations for a 3x3 64->64 panel)
+template <int BN, int NT>
+__device__ __forceinline__ void stage_weight_panel(char* sB, const char* w, int tn, int pitchB, int cin_pad, int ntaps, int wtaps,
+                                                   const int* tap_w, int tid) {
+  constexpr int U = 8;
+  const int vec_per_tap = cin_pad / 8;
+  const int vec_per_row = ntaps * vec_per_tap;
+  const int total = BN * vec_per_row;
+  for (int base = 0; base < total; base += NT * U) {
+    uint4 tmp[U];
+    int dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int v = base + u * NT + tid;
+      const bool ok = v < total;
+      const int vv = ok ? v : 0;
+      const int r = vv / vec_per_row; const int q = vv - r * vec_per_row;
+      const int t = q / vec_per_tap; const int s2 = q - t * vec_per_tap;
+      tmp[u] = ldg16(w + ((int64_t)((tn * BN + r) * wtaps + tap_w[t]) * cin_pad + s2 * 8) * 2);
+      const int g = t * vec_per_tap + s2;
+      const int sw = (0x78 >> (((r >> 2) & 3) * 2)) & 3;
+      dst[u] = ok ? r * pitchB + (g >> 2) * 64 + (((g & 3) ^ sw) << 4) : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (dst[u] >= 0) *reinterpret_cast<uint4*>(sB + dst[u]) = tmp[u];
+  }
+}
+
 // conv_stream.hip: streaming variant of myolo_conv; -1 = layer does not qualify
 int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream);
+// conv_halo.hip: LDS-staged input tiles for k x k stride-1 convolutions; -1 = layer does not qualify
+int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_halo_set(const char* name, int value);
+// conv_wgrad_tile.hip: weight gradient over LDS-staged spatial tiles; -1 = layer does not qualify
+int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, int* out_cop, int* out_cip, int* used_ws);
+int myolo_wgrad_tile_set(const char* name, int value);

@@ -17,7 +17,10 @@ from ._lib import Tensor as CT
 
 # MYOLO_GRAPH_TRAIN=0: training launch lists are enqueued call by call instead of replayed as hipGraphs (see Plan.run_fwd / run_bwd)
 GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '1') != '0'
-BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '6'))
+BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
+# 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
+# forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
+GRAPH_BWD = os.environ.get('MYOLO_GRAPH_BWD', 'seg')
 
 SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
@@ -755,7 +758,7 @@ class Plan:
                 tv.place(b, 0)
         for b in self.bufs:
             b.alloc(dev, self.training)
-        self._arena = [torch.zeros(1 << 20, dtype=torch.float32, device=dev) for _ in range(2)]
+        self._arena = [torch.zeros(1 << 22, dtype=torch.float32, device=dev) for _ in range(2)]
         self._used = [0, 0]
         if self.training:
             tot = sum(p.numel() for p in self.params)
@@ -880,6 +883,9 @@ class Plan:
     def _bwd_segments(self, reducer):
         """cut points of the backward op list (descending op index): [(hi, lo, [buckets ready after op lo])] -- a bucket boundary
         always ends a segment, the rest is balanced by launch count"""
+        cache = self.__dict__.setdefault('_seg_cache', {})
+        if id(reducer) in cache:
+            return cache[id(reducer)]
         pending = list(self.grad_buckets(reducer)) if reducer is not None else []
         n = len(self.ops)
         cuts = {0}
@@ -902,6 +908,7 @@ class Plan:
             ready = [(a, b) for a, b, r in pending if lo <= r < hi] if lo > 0 else [(a, b) for a, b, r in pending if r < hi]
             segs.append((hi, lo, ready))
             hi = lo
+        cache[id(reducer)] = segs
         return segs
 
     def _seg_main(self, st, hi, lo, with_side):
@@ -927,6 +934,9 @@ class Plan:
             return True
         try:
             caps = []
+            if GRAPH_BWD == 'fork' and reducer is None:
+                g['bwd'], g['bwd_key'] = [(self._capture(lambda s: self._bwd_eager(None)), 'fork')], (id(reducer), use_side)
+                return True
             for hi, lo, _ in self._bwd_segments(reducer):
                 gm = self._capture(lambda s, hi=hi, lo=lo: self._seg_main(s, hi, lo, use_side))
                 gs = None
@@ -941,46 +951,67 @@ class Plan:
             g['failed'] = True
             return False
 
-    def run_bwd(self, reducer=None):
-        """backward launch list.  Weight-gradient kernels go to a side HIP stream: they only feed the optimizer, so they
-        overlap with the latency-bound dgrad / BatchNorm chain on the main stream (many of those launches fill < 1 CU wave)."""
+    def _bwd_eager(self, reducer):
+        """the backward launch list call by call on the CURRENT stream (also the body of the 'fork' capture): weight-gradient launches
+        are forked to the side stream behind an event each, gradient slices go to the reducer as soon as they are final"""
         cuda = self.flat_grad.is_cuda
         main = torch.cuda.current_stream() if cuda else None
-        use_side = cuda and self.use_side_stream
-        side = self._side_stream() if use_side else None
-        g = self.__dict__.get('_graphs')
-        graphed = self.graphable() and g is not None and 'fwd' in g and not g.get('failed')
-        segs = self._bwd_segments(reducer)
-        if graphed and 'bwd' not in g:
-            graphed = self.capture_bwd(reducer)
-        if graphed and g.get('bwd_key') != (id(reducer), use_side):
-            graphed = False                                   # reducer attached / detached after the capture: eager this time
+        side = self._side_stream() if (cuda and self.use_side_stream) else None
         self._zero_bwd()
         if side is not None:
             side.wait_stream(main)                            # the zero fills above
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
         st = L.stream_ptr()
-        for k, (hi, lo, ready) in enumerate(segs):
-            if graphed:
-                gm, gs = g['bwd'][k]
-                gm.replay()
-                if gs is not None:
-                    ev = torch.cuda.Event()
-                    ev.record(main)
-                    side.wait_event(ev)
-                    with torch.cuda.stream(side):
-                        gs.replay()
-            else:
-                for i in range(hi - 1, lo - 1, -1):
-                    for c in self.ops[i].bwd_calls:
-                        if c.side and side is not None:
-                            ev = torch.cuda.Event()
-                            ev.record(main)
-                            side.wait_event(ev)
-                            c(side_ptr)
-                        else:
-                            c(st)
+        for hi, lo, ready in self._bwd_segments(reducer):
+            for i in range(hi - 1, lo - 1, -1):
+                for c in self.ops[i].bwd_calls:
+                    if c.side and side is not None:
+                        ev = torch.cuda.Event()
+                        ev.record(main)
+                        side.wait_event(ev)
+                        c(side_ptr)
+                    else:
+                        c(st)
             if ready:                                         # every kernel writing into these slices has been enqueued
+                if side is not None:
+                    main.wait_stream(side)
+                for a, b in ready:
+                    reducer.reduce_slice(self.flat_grad, a, b)
+        if side is not None:
+            main.wait_stream(side)
+        if reducer is not None:
+            reducer.finish(self.flat_grad)
+
+    def run_bwd(self, reducer=None):
+        """backward launch list.  Weight-gradient kernels go to a side HIP stream: they only feed the optimizer, so they
+        overlap with the latency-bound dgrad / BatchNorm chain on the main stream (many of those launches fill < 1 CU wave)."""
+        g = self.__dict__.get('_graphs')
+        graphed = self.graphable() and g is not None and 'fwd' in g and not g.get('failed')
+        if graphed and 'bwd' not in g:
+            graphed = self.capture_bwd(reducer)
+        use_side = self.flat_grad.is_cuda and self.use_side_stream
+        if graphed and g.get('bwd_key') != (id(reducer), use_side):
+            graphed = False                                   # reducer attached / detached after the capture: eager this time
+        if not graphed:
+            self._bwd_eager(reducer)
+            return
+        if g['bwd'][0][1] == 'fork':
+            g['bwd'][0][0].replay()
+            return
+        main = torch.cuda.current_stream()
+        side = self._side_stream() if use_side else None
+        self._zero_bwd()
+        if side is not None:
+            side.wait_stream(main)
+        for (hi, lo, ready), (gm, gs) in zip(self._bwd_segments(reducer), g['bwd']):
+            gm.replay()
+            if gs is not None:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    gs.replay()
+            if ready:
                 if side is not None:
                     main.wait_stream(side)
                 for a, b in ready:

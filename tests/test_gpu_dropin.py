@@ -131,8 +131,10 @@ def test_train_py_loop_body_with_stock_sgd_amp_ddp_then_checkpoint_roundtrip(dro
 
 
 def test_stock_sgd_step_equals_fused_sgd_step():
-    """one loss-scaled fp16 joint step from the same weights: stock torch.optim.SGD + torch.cuda.amp.GradScaler vs the library's
-    FusedSGD + GradScaler (one multi-tensor launch): same parameter update"""
+    """two loss-scaled joint steps from the same weights: stock torch.optim.SGD + torch.cuda.amp.GradScaler vs the library's
+    FusedSGD + GradScaler (one multi-tensor launch, unscale folded in): same parameter update.  Run in fp32 arithmetic (autocast
+    off) so that the two runs are comparable at 1e-3 -- two fp16 runs of this random-weight network differ by 5-20 % per gradient
+    tensor from the storage noise alone (atomics reorder the BatchNorm sums), which says nothing about the optimizers."""
     from torch.cuda import amp
     from multiyolov5_amd import synth
     from multiyolov5_amd.models.yolo import Model
@@ -157,14 +159,15 @@ def test_stock_sgd_step_equals_fused_sgd_step():
         mk = synth.seg_targets(B, H, W, 19, seed=1).to(DEV)
         w0 = {k: p.detach().clone() for k, p in m.named_parameters()}
         for _ in range(2):
-            with amp.autocast(enabled=True):
+            with amp.autocast(enabled=False):
                 det, seg = m(x)
                 loss, _ = ComputeLoss(m)(det, t)
                 sl = SegmentationLosses()(seg, mk) * B
             scaler.scale(loss * 0.6 + sl * 0.35).backward()
             scaler.step(opt); scaler.update(); opt.zero_grad()
+        assert scaler.get_scale() == 256.0
         res.append({k: (p.detach() - w0[k]).float() for k, p in m.named_parameters()})
     bad = []
     for k in res[0]:
-        check(f'dropin/sgd/{k}', res[1][k], res[0][k], 3e-2, collect=bad)     # fp16 run-to-run (atomics order) noise on the update
-    assert len(bad) <= 2, '\n'.join(bad[:10])
+        check(f'dropin/sgd/{k}', res[1][k], res[0][k], 6e-3, collect=bad)      # two fp32 runs: measured <= 2.2e-3 (atomics reorder the sums)
+    assert not bad, '\n'.join(bad[:10])

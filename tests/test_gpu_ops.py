@@ -124,8 +124,28 @@ def force_stream_kernel():
     """route every qualifying fp16 conv through the streaming kernel (conv_stream.hip), whatever the map size"""
     from multiyolov5_amd import _lib
     _lib.check(_lib.lib().myolo_set_option(b'stream_min_tiles', 1))
+    _lib.check(_lib.lib().myolo_set_option(b'halo_off', 1))          # (the k x k layers would otherwise go to the LDS-halo kernel)
     yield
     _lib.check(_lib.lib().myolo_set_option(b'stream_min_tiles', 2048))
+    _lib.check(_lib.lib().myolo_set_option(b'halo_off', 0))
+
+
+@pytest.fixture
+def force_halo_kernel():
+    """route every qualifying fp16 k x k stride-1 conv through the LDS-halo kernel (conv_halo.hip), whatever the map size"""
+    from multiyolov5_amd import _lib
+    _lib.check(_lib.lib().myolo_set_option(b'halo_min_tiles', 1))
+    yield
+    _lib.check(_lib.lib().myolo_set_option(b'halo_min_tiles', 16))
+
+
+@pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
+@pytest.mark.parametrize('name', ['conv3x3_small', 'conv3x3', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'rfb2_global', 'rfb1', 'aspp', 'aspps',
+                                  'ffm_k3', 'arm'])
+def test_block_halo_kernel(name, training, force_halo_kernel):
+    """the block parity cases with the LDS-halo conv kernel forced on (ragged tiles, dilation 2/3/5/7/9, 5x5, residual, accumulate in
+    the dgrad fan-in, BatchNorm statistics, 48-channel padding) -- at the default threshold it serves maps of >= 16 tiles"""
+    test_block(name, training, torch.float16)
 
 
 @pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
