@@ -45,9 +45,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
     if (gamma) {
       // the copies are combined and E[x^2] - mean^2 is formed in fp64: the fp32 partial sums are exact to ~1e-7 each, the
       // cancellation (|mean| >> std channels) happens in double
-      double ssum = 0.0, qsum = 0.0;
-#pragma unroll 8
-      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { ssum += (double)stats[k * 2 * C + c]; qsum += (double)stats[k * 2 * C + C + c]; }
+      float sf[4] = {0.f, 0.f, 0.f, 0.f}, qf[4] = {0.f, 0.f, 0.f, 0.f};      // 4 independent chains: 64 loads in flight, short add chains
+#pragma unroll
+      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { sf[k & 3] += stats[k * 2 * C + c]; qf[k & 3] += stats[k * 2 * C + C + c]; }
+      const double ssum = ((double)sf[0] + (double)sf[1]) + ((double)sf[2] + (double)sf[3]);
+      const double qsum = ((double)qf[0] + (double)qf[1]) + ((double)qf[2] + (double)qf[3]);
       const double meand = ssum / (double)M;
       double vard = qsum / (double)M - meand * meand;
       const float mean = (float)meand;
@@ -251,7 +253,8 @@ extern "C" int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const
   if (G > 256) return MYOLO_EINVAL;
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int grid = grid_for(M, PPB * 2);                 // two pixels per thread and pass
+  const int grid = grid_for(M, PPB * 2, 1024);           // two pixels per thread and pass; <= 4 workgroups per CU: each one's
+                                                         // prologue sums the MYOLO_STAT_COPIES partial statistics of every channel
   const size_t smem = (size_t)2 * y->c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
@@ -302,7 +305,7 @@ extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tens
   if (G > 256) return MYOLO_EINVAL;
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int grid = grid_for(M, PPB * 2);
+  const int grid = grid_for(M, PPB * 2, 1024);
   const size_t smem = (size_t)4 * y->c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)

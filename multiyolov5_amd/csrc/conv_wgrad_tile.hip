@@ -259,7 +259,7 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   k.x_bytes = (int)xb; k.d_bytes = (int)db;
   k.dbuf_bytes = dbuf; k.xbuf_bytes = xbuf;
   // split-K over tiles: one workgroup per CU at most (the buffers take > 80 KB), at least ~6 tiles per workgroup
-  static const int tgt = getenv("MYOLO_WGRAD_TILE_WG") ? atoi(getenv("MYOLO_WGRAD_TILE_WG")) : 192;
+  static const int tgt = getenv("MYOLO_WGRAD_TILE_WG") ? atoi(getenv("MYOLO_WGRAD_TILE_WG")) : 128;
   int ks = d->ksplit > 0 ? d->ksplit : (tgt + out_tiles - 1) / out_tiles;
   const int max_ks = (k.ntiles + 5) / 6;
   if (ks > max_ks) ks = max_ks;

@@ -25,22 +25,11 @@ def _free_port():
     return p
 
 
-@pytest.fixture
-def dropin():
-    import multiyolov5_amd.dropin as d
-    d.install()
-    yield d
-    d.uninstall()
-
-
-@pytest.fixture
-def world1():
+def _world1():
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()), RANK='0', WORLD_SIZE='1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     torch.cuda.set_device(0)
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device(DEV))       # backend 'nccl' == RCCL (train.py:619)
-    yield
-    dist.destroy_process_group()
 
 
 def _groups(model):                                            # train.py:121-137
@@ -55,7 +44,22 @@ def _groups(model):                                            # train.py:121-13
     return pg0, pg1, pg2
 
 
-def test_train_py_loop_body_with_stock_sgd_amp_ddp_then_checkpoint_roundtrip(dropin, world1, tmp_path):
+def test_train_py_loop_body_with_stock_sgd_amp_ddp_then_checkpoint_roundtrip(tmp_path):
+    """runs in its own process (like the gloo tests): a process group / RCCL communicator and the sys.modules rebinding are process
+    state, and tests that follow an in-process RCCL init in the same interpreter were observed to fail at random"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f'import sys; sys.path.insert(0, {root!r}); import tests.test_gpu_dropin as t; import pathlib; '
+            f't._ddp_loop_body(pathlib.Path({str(tmp_path)!r})); print("__DDP_BODY_OK__")')
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and '__DDP_BODY_OK__' in r.stdout, r.stdout[-3000:] + r.stderr[-6000:]
+
+
+def _ddp_loop_body(tmp_path):
+    import multiyolov5_amd.dropin as _d
+    _d.install()
+    _world1()
     from torch.cuda import amp
     from torch.nn.parallel import DistributedDataParallel as DDP
     from models.yolo import Model                                                     # train.py:20 under the rebinding
@@ -128,6 +132,7 @@ def test_train_py_loop_body_with_stock_sgd_amp_ddp_then_checkpoint_roundtrip(dro
         (p1, _), s1 = live(x)
     check('dropin/ckpt/pred', p2, p1, 1e-5)
     check('dropin/ckpt/seg', s2, s1, 1e-5)
+    dist.destroy_process_group()
 
 
 def test_stock_sgd_step_equals_fused_sgd_step():
