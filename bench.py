@@ -225,16 +225,17 @@ def conv_kernel_timing(trainer, nsteps=3):
     return tot_b, tot_f, tot_t, len(rec) // nsteps
 
 
-def infer_fps(args, dev, frames=30, warm=5):
-    """detect.py path (detect.py:144-193): fused eval forward at 1x3x1024x2048 fp16 + NMS + seg upsample/argmax."""
+def infer_fps(args, dev, frames=30, warm=5, H=1024, W=2048):
+    """detect.py path (detect.py:144-193): fused eval forward at 1x3xHxW fp16 (hipGraph replay) + NMS + seg upsample/argmax."""
     from multiyolov5_amd.models.yolo import Model
     from multiyolov5_amd.utils.general import non_max_suppression, seg_argmax
     from multiyolov5_amd import synth
     m = Model(os.path.join(ROOT, 'multiyolov5_amd', 'cfg', 'yolov5s_city_seg.yaml'))
     synth.randomize_(m, seed=0)
     m = m.to(dev).half().fuse().eval()
-    img = synth.images(1, 1024, 2048, seed=7).to(dev, torch.float16)
-    pred_syn = synth.nms_pred(1, 129024, 10, seed=3, img_w=2048, img_h=1024).to(dev, torch.float16)
+    img = synth.images(1, H, W, seed=7).to(dev, torch.float16)
+    na = 3 * ((H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32))          # 129 024 at 1024x2048, 32 256 at 512x1024
+    pred_syn = synth.nms_pred(1, na, 10, seed=3, img_w=W, img_h=H).to(dev, torch.float16)
 
     def frame():
         with torch.no_grad():
@@ -242,7 +243,7 @@ def infer_fps(args, dev, frames=30, warm=5):
             # random-init heads give no candidates above conf 0.25: NMS is fed the synthetic prediction
             # tensor of the same shape/dtype so that suppression actually happens
             det = non_max_suppression(pred_syn, 0.25, 0.45)
-            lab = seg_argmax(out[1], 1024, 2048)
+            lab = seg_argmax(out[1], H, W)
         return det, lab
     for _ in range(warm):
         frame()
@@ -255,10 +256,49 @@ def infer_fps(args, dev, frames=30, warm=5):
 
 
 def cpu_baseline(args):
-    """the oracle (CPU restatement of the reference path, torch CPU fp32) timed on this box's host cores on a bounded
-    sample: BASELINE configs[0]-style joint step (fwd + both losses + bwd) at 2x3x512x1024."""
+    """the oracle (CPU restatement of the reference path, torch CPU fp32; kind "port": the reference itself is not on the GPU box)
+    timed on this box's host cores on a bounded sample: BASELINE configs[0] -- yolov5s_city_seg with the BASE head, joint step (fwd +
+    both losses + bwd) at 2x3x512x1024 -- plus the same sample on the benchmarked config's own head."""
     from oracle import cpu_bench
-    return cpu_bench.joint_step(cfg=args.cfg, batch=2, H=args.img[0], W=args.img[1], budget_s=20.0)
+    r = cpu_bench.joint_step(cfg='yolov5s_city_seg_base.yaml', batch=2, H=args.img[0], W=args.img[1], budget_s=12.0)
+    r['workload'] = 'BASELINE configs[0]: yolov5s_city_seg base head, 2x3x512x1024 fp32 joint step (oracle port of the reference CPU path)'
+    if args.cfg != 'yolov5s_city_seg_base.yaml':
+        o = cpu_bench.joint_step(cfg=args.cfg, batch=2, H=args.img[0], W=args.img[1], budget_s=10.0)
+        r['same_head_as_bench'] = {'value': o['value'], 'unit': o['unit'], 'sample': o['sample']}
+    return r
+
+
+def whole_step_roofline(tr, ms):
+    """algorithmic bytes of conv (fwd + dgrad) + weight-gradient + BatchNorm launches of one step / step time"""
+    from multiyolov5_amd import engine as E
+    plans = [h.plan for h in tr.model.__dict__.get('_plans', {}).values() if h.plan.training]
+    if not plans:
+        return None
+    by = E.plan_algorithmic_bytes(plans[0])
+    tot = sum(by.values())
+    return {'bound': 'hbm', 'achieved': tot / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': tot, 'by_family': by,
+            'what': 'conv + dgrad + weight-gradient + BatchNorm launches (every operand once) over the WHOLE step time'}
+
+
+def second_config_rate(args, world, rank, dev, cfg='yolov5m_city_seg_lab.yaml', batch=8, steps=10, warm=4):
+    """BASELINE configs[3] per-GPU share: yolov5m + Lab head, bs 8 per GPU, the same joint step"""
+    import copy
+    a = copy.copy(args)
+    a.cfg, a.batch = cfg, batch
+    tr = Trainer(a, world, rank, dev)
+    for _ in range(warm):
+        tr.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    r = {'value': batch / dt, 'unit': 'images/s', 'ms_per_step': dt * 1e3,
+         'workload': f'{cfg} bs={batch}/GPU {args.img[1]}x{args.img[0]} {args.dtype} joint train step (BASELINE configs[3] per-GPU share)'}
+    r['whole_step_roofline'] = whole_step_roofline(tr, dt * 1e3)
+    return r
 
 
 def main():
@@ -313,17 +353,27 @@ def main():
                 traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/' + os.path.basename(pmc) + ': ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
-                               'kernel': 'myolo_conv launches of one step: conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad)',
+                               'kernel': 'myolo_conv launches of one step: conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad)',
                                'launches_per_step': n,
                                'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
                                'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,
                                'conv_time_frac_of_step': t / (ms * 1e-3)}
+        if args.stage == 'train':
+            out['whole_step_roofline'] = whole_step_roofline(tr, ms)
         if args.stage == 'train' and not args.no_infer:
             try:
                 out['detect_fps'] = {'value': infer_fps(args, dev), 'unit': 'frames/s',
                                      'workload': 'pspv5s fused fp16 1x3x1024x2048 fwd + NMS(129024 cand) + x8 upsample+argmax'}
+                out['detect_fps_1024x512'] = {'value': infer_fps(args, dev, H=512, W=1024), 'unit': 'frames/s',
+                                              'workload': 'pspv5s fused fp16 1x3x512x1024 fwd + NMS(32256 cand) + x8 upsample+argmax '
+                                                          '(the resolution of BASELINE.md\'s ~141 FPS point, unstated NVIDIA GPU)'}
             except Exception as e:                       # the secondary metric must not take the primary line down
                 out['detect_fps'] = {'value': None, 'error': repr(e)}
+            try:
+                if args.cfg == 'yolov5s_city_seg.yaml':
+                    out['train_m_lab'] = second_config_rate(args, world, rank, dev)
+            except Exception as e:
+                out['train_m_lab'] = {'value': None, 'error': repr(e)}
         if args.stage == 'train' and not args.no_infer:
             try:                                         # SURVEY 8(d) definition (ii); secondary, must not take the primary line down
                 out['train_py_step'] = train_py_rate(tr)

@@ -301,6 +301,11 @@ int myolo_match_predictions(const float* pred, int n, const float* labels, int m
  * as torch computes them: bit-identical normalisation). */
 int myolo_frame_pack(const uint8_t* frame_hwc, int h0, int w0, int swap_rb, int top, int left, int H, int W, int pad_value,
                      void* out_nchw, int out_dtype, const void* lut256, void* stream);
+/* the same with the frame resampled to (rh, rw) first -- letterbox's cv2.resize(img, new_unpad, interpolation=cv2.INTER_LINEAR)
+ * (datasets.py:843-844) on 8-bit images: OpenCV's 1/2048 fixed-point bilinear (exact 2x down-scale = 2x2 box average), then border,
+ * channel swap, HWC->CHW and the /255 table as in myolo_frame_pack */
+int myolo_frame_resize_pack(const uint8_t* frame_hwc, int h0, int w0, int rh, int rw, int swap_rb, int top, int left, int H, int W,
+                            int pad_value, void* out_nchw, int out_dtype, const void* lut256, void* stream);
 /* detect.py:193-194: mask = colormap[label] (channel-reversed when swap_rb = `label2image(...)[:, :, ::-1]`), dst =
  * cv2.addWeighted(mask, alpha, im0, beta, gamma) on uint8 (float32 products and sums rounded separately, round-half-even,
  * saturated).  labels u8|i64 [h,w] (clamped to [0,ncls)); colormap_rgb device uint8[ncls][3]; mask_hwc / dst_hwc: either may be NULL. */

@@ -111,6 +111,8 @@ _PROTOS = {
     'myolo_scaler_update': (C.c_int, [P, P, P, C.c_float, C.c_float, C.c_int, P]),
     'myolo_match_predictions': (C.c_int, [P, C.c_int, P, C.c_int, P, C.c_int, P, P, C.c_int64, P]),
     'myolo_frame_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P]),
+    'myolo_frame_resize_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P,
+                                          C.c_int, P, P]),
     'myolo_seg_blend': (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P, P, P]),
     'myolo_nms': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                             C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint64, P]),

@@ -1113,3 +1113,43 @@ def conv_call_bytes(call):
 def conv_call_flops(call):
     d = _conv_desc_of(call)
     return 2.0 * d.y.n * d.y.h * d.y.w * d.y.c * d.ntaps * d.x.c
+
+
+def _tensor_bytes(t, c=None):
+    es = 2 if t.dtype == L.F16 else 4
+    return t.n * t.h * t.w * (t.c if c is None else c) * es
+
+
+def call_algorithmic_bytes(call):
+    """algorithmic HBM bytes of one C-ABI launch of the training step (bench.py whole-step roofline): every operand read once, every
+    result written once -- conv / dgrad: input + weights + output; wgrad: x + dy + fp32 gradient; BatchNorm forward: raw + out
+    (+ residual); backward reduce: gout + raw; backward apply: gout + raw + dy (+ residual gradient).  None for other launches."""
+    n = call.name
+    if n == 'myolo_conv':
+        return conv_call_bytes(call)
+    if n == 'myolo_conv_wgrad':
+        d = call.args[0]._obj
+        return _tensor_bytes(d.x) + _tensor_bytes(d.dy) + d.ntaps * max(d.cout, 1) * max(d.cin, 1) * 4
+    a = [x._obj if hasattr(x, '_obj') else x for x in call.args]
+    if n == 'myolo_bn_act_fwd':
+        y, res = a[0], a[11]
+        return _tensor_bytes(y) * 2 + (_tensor_bytes(res) if res.ptr else 0)
+    if n == 'myolo_bn_act_bwd_reduce':
+        return _tensor_bytes(a[0]) * 2
+    if n == 'myolo_bn_act_bwd_apply':
+        g, gres = a[0], a[10]
+        return _tensor_bytes(g) * 3 + (_tensor_bytes(gres) if gres.ptr else 0)
+    return None
+
+
+def plan_algorithmic_bytes(plan):
+    """{family: bytes} over the forward + backward launch lists of a training plan"""
+    out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
+    fam = {'myolo_conv': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
+           'myolo_bn_act_bwd_apply': 'batchnorm'}
+    for op in plan.ops:
+        for c in list(op.fwd_calls) + list(op.bwd_calls):
+            b = call_algorithmic_bytes(c)
+            if b is not None:
+                out[fam[c.name]] += b
+    return out

@@ -3,8 +3,9 @@
 
 The geometry (`letterbox_params`) is the reference's arithmetic verbatim in meaning; the pixels are moved by ONE libmyolo
 kernel (`myolo_frame_pack`): the uint8 frame crosses PCIe once (3 bytes/pixel instead of the 6-12 of a host-normalised tensor)
-and no intermediate HWC / float image exists.  Resampling (`cv2.resize`, datasets.py:843-844) is not implemented: frames whose
-scale ratio is 1 (camera frames at a network resolution, the detect.py benchmark case) need none; anything else raises.
+and no intermediate HWC / float image exists.  Frames that letterbox resamples (`cv2.resize(img, new_unpad, INTER_LINEAR)`,
+datasets.py:843-844) go through `myolo_frame_resize_pack`: OpenCV's 8-bit fixed-point bilinear restated in the kernel (cv2 is not
+installed here, so that resampler is "parity unpinned" like copyMakeBorder; oracle/frame_ref.py holds the same restatement in numpy).
 """
 import ctypes as C
 
@@ -62,15 +63,17 @@ def frame_to_input(im0, new_shape=640, color=(114, 114, 114), auto=True, scaleFi
         raise NotImplementedError('letterbox border: one grey level (the reference always pads with 114)')
     h0, w0 = int(im0.shape[0]), int(im0.shape[1])
     new_unpad, ratio, (dw, dh), (top, bottom, left, right) = letterbox_params((h0, w0), new_shape, auto, scaleFill, scaleup, stride)
-    if (w0, h0) != tuple(new_unpad):
-        raise NotImplementedError(f'letterbox would resample {w0}x{h0} -> {new_unpad[0]}x{new_unpad[1]} (cv2.resize INTER_LINEAR, '
-                                  'datasets.py:843-844): only ratio-1 frames are handled on the device')
-    H, W = h0 + top + bottom, w0 + left + right
+    rw, rh = int(new_unpad[0]), int(new_unpad[1])
+    H, W = rh + top + bottom, rw + left + right
     dtype = torch.float16 if half else torch.float32
     if out is None:
         out = torch.empty(1, 3, H, W, dtype=dtype, device=im0.device)
     elif tuple(out.shape) != (1, 3, H, W) or out.dtype != dtype or not out.is_contiguous():
         raise L.MyoloError('out must be a contiguous [1,3,H,W] tensor of the requested dtype')
-    L.check(L.lib().myolo_frame_pack(L.ptr(im0), h0, w0, int(bool(bgr)), top, left, H, W, int(color[0]), L.ptr(out), L.DT[dtype],
-                                     L.ptr(_lut(im0.device, dtype)), L.stream_ptr()), 'myolo_frame_pack')
+    if (w0, h0) == (rw, rh):
+        L.check(L.lib().myolo_frame_pack(L.ptr(im0), h0, w0, int(bool(bgr)), top, left, H, W, int(color[0]), L.ptr(out), L.DT[dtype],
+                                         L.ptr(_lut(im0.device, dtype)), L.stream_ptr()), 'myolo_frame_pack')
+    else:
+        L.check(L.lib().myolo_frame_resize_pack(L.ptr(im0), h0, w0, rh, rw, int(bool(bgr)), top, left, H, W, int(color[0]), L.ptr(out),
+                                                L.DT[dtype], L.ptr(_lut(im0.device, dtype)), L.stream_ptr()), 'myolo_frame_resize_pack')
     return out, ratio, (dw, dh)

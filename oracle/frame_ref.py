@@ -12,6 +12,37 @@ import numpy as np
 import torch
 
 
+def cv_resize_linear_u8(img, dsize):
+    """cv2.resize(img, (w, h), interpolation=cv2.INTER_LINEAR) for uint8 HxWxC, restated from OpenCV's resize.cpp ("parity unpinned":
+    cv2 is not installed): float32 source coordinate fx = (dx + 0.5) * scale - 0.5 (scale in double), coefficients rounded half-to-even
+    to 1/2048 fixed point, horizontal pass in int32, vertical pass (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2; x
+    borders reset (fx = 0), y rows clamped; an exact 2x down-scale takes resize()'s INTER_AREA-fast branch ((a + b + c + d + 2) >> 2)."""
+    h0, w0 = img.shape[:2]
+    rw, rh = int(dsize[0]), int(dsize[1])
+    src = img.astype(np.int64)
+    if w0 == 2 * rw and h0 == 2 * rh:
+        return ((src[0::2, 0::2] + src[0::2, 1::2] + src[1::2, 0::2] + src[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    fx = ((np.arange(rw, dtype=np.float64) + 0.5) * (w0 / rw) - 0.5).astype(np.float32)
+    sx = np.floor(fx).astype(np.int64)
+    fx = fx - sx.astype(np.float32)
+    lo, hi = sx < 0, sx >= w0 - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    sx = np.where(lo, 0, np.where(hi, w0 - 1, sx))
+    x1 = np.minimum(sx + 1, w0 - 1)
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    fy = ((np.arange(rh, dtype=np.float64) + 0.5) * (h0 / rh) - 0.5).astype(np.float32)
+    sy = np.floor(fy).astype(np.int64)
+    fy = fy - sy.astype(np.float32)
+    y0, y1 = np.clip(sy, 0, h0 - 1), np.clip(sy + 1, 0, h0 - 1)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int64)
+    hrow = src[:, sx] * a0[None, :, None] + src[:, x1] * a1[None, :, None]            # [h0, rw, C] int
+    r0, r1 = hrow[y0], hrow[y1]
+    out = (((b0[:, None, None] * (r0 >> 4)) >> 16) + ((b1[:, None, None] * (r1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
 def letterbox(img, new_shape=(640, 640), color=(114, 114, 114), auto=True, scaleFill=False, scaleup=True, stride=32):
     shape = img.shape[:2]
     if isinstance(new_shape, int):
@@ -31,7 +62,8 @@ def letterbox(img, new_shape=(640, 640), color=(114, 114, 114), auto=True, scale
     dw /= 2
     dh /= 2
     if shape[::-1] != new_unpad:
-        raise NotImplementedError('cv2.resize branch')
+        img = cv_resize_linear_u8(img, new_unpad)               # datasets.py:843-844
+        shape = img.shape[:2]
     top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
     left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
     out = np.empty((shape[0] + top + bottom, shape[1] + left + right, 3), np.uint8)

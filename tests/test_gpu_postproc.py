@@ -130,7 +130,10 @@ def test_seg_metrics_match_reference_golden_and_oracle():
 
 
 @pytest.mark.parametrize('half', [True, False], ids=['f16', 'f32'])
-@pytest.mark.parametrize('shape,new_shape', [((1024, 2048), 2048), ((1000, 2048), 2048), ((37, 64), 64), ((64, 50), 64)])
+@pytest.mark.parametrize('shape,new_shape', [((1024, 2048), 2048), ((1000, 2048), 2048), ((37, 64), 64), ((64, 50), 64),
+                                             # frames letterbox resamples (cv2.resize INTER_LINEAR, datasets.py:843-844):
+                                             ((720, 1280), 640), ((1080, 1920), 1024), ((1024, 2048), 1024), ((240, 320), 640),
+                                             ((333, 500), 416), ((97, 61), 128)])
 def test_frame_to_input_matches_reference_steps(shape, new_shape, half):
     """letterbox border + BGR->RGB + HWC->CHW + /255 (datasets.py:818-848,185; detect.py:135-139) in one kernel: bit-identical to
     the reference's own numpy/torch steps (oracle.frame_ref), incl. odd padding splits"""
@@ -156,10 +159,21 @@ def test_frame_to_input_matches_reference_steps(shape, new_shape, half):
         assert torch.equal(got[0], lut[idx])
 
 
-def test_frame_to_input_rejects_resampling():
+def test_frame_to_input_resamples_like_the_8bit_fixed_point_restatement():
+    """the resampling branch is really taken (1280x720 -> 640x360 = the exact-2x box average; 1920x1080 -> 1024x576 general bilinear)
+    and is bit-identical, pixel for pixel, to oracle.frame_ref.cv_resize_linear_u8"""
     from multiyolov5_amd.utils.datasets import frame_to_input
-    with pytest.raises(NotImplementedError):
-        frame_to_input(torch.zeros(720, 1280, 3, dtype=torch.uint8, device=DEV), 640)
+    from oracle import frame_ref
+    for (h, w), ns in (((720, 1280), 640), ((1080, 1920), 1024)):
+        im0 = np.random.RandomState(h).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        got, ratio, pad = frame_to_input(torch.from_numpy(im0).to(DEV), ns, stride=32, half=True, auto=False)
+        assert got.shape == (1, 3, ns, ns) and ratio[0] == ns / w
+        rh, rw = int(round(h * ratio[1])), int(round(w * ratio[0]))
+        res = frame_ref.cv_resize_linear_u8(im0, (rw, rh))
+        top = int(round(pad[1] - 0.1))
+        inner = (got[0, :, top:top + rh, :rw] * 255).round().to(torch.uint8).cpu().numpy()       # RGB planes back to bytes
+        np.testing.assert_array_equal(inner, res[:, :, ::-1].transpose(2, 0, 1))
+        assert float(got[0, :, 0, 0].float().mean()) == pytest.approx(114 / 255, abs=1e-3)       # border rows
 
 
 @pytest.mark.parametrize('ldt', [torch.uint8, torch.int64], ids=['u8', 'i64'])

@@ -237,3 +237,23 @@ def test_block_restatement_matches_reference_classes(name):
     with torch.no_grad():
         ye = BLOCK_FNS[name](model_ref.Ctx({'m.' + k: v for k, v in sd2.items()}, False), 'm', torch.from_numpy(g[f'{name}/x']))
     np.testing.assert_allclose(ye.numpy(), g[f'{name}/eval_out'], rtol=1e-4, atol=2e-5)
+
+
+def test_cv_resize_restatement_properties():
+    """oracle.frame_ref.cv_resize_linear_u8 (cv2 is absent: "parity unpinned") -- the properties OpenCV's 8-bit INTER_LINEAR has by
+    construction: identity at equal size, constants stay constant, exact 2x = 2x2 box average rounded half up, a horizontal ramp stays
+    monotone, values stay inside the source range, and upscaling by 2 reproduces the 1/4-3/4 weights"""
+    from oracle import frame_ref
+    rs = np.random.RandomState(0)
+    im = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    np.testing.assert_array_equal(frame_ref.cv_resize_linear_u8(im, (53, 37)), im)
+    c = np.full((20, 30, 3), 77, np.uint8)
+    assert (frame_ref.cv_resize_linear_u8(c, (47, 13)) == 77).all()
+    im2 = rs.randint(0, 256, (40, 64, 3)).astype(np.uint8)
+    box = ((im2[0::2, 0::2].astype(int) + im2[0::2, 1::2] + im2[1::2, 0::2] + im2[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+    np.testing.assert_array_equal(frame_ref.cv_resize_linear_u8(im2, (32, 20)), box)
+    ramp = np.tile(np.arange(0, 256, 4, dtype=np.uint8)[None, :, None], (8, 1, 3))
+    r = frame_ref.cv_resize_linear_u8(ramp, (41, 5)).astype(int)
+    assert (np.diff(r[0, :, 0]) >= 0).all() and r.min() >= ramp.min() and r.max() <= ramp.max()
+    row = np.array([[0, 200]], np.uint8)[:, :, None].repeat(3, 2)                     # 1x2 -> 1x4: weights (1,0) (.75,.25) (.25,.75) (0,1)
+    np.testing.assert_array_equal(frame_ref.cv_resize_linear_u8(row, (4, 1))[0, :, 0], [0, 50, 150, 200])
