@@ -103,6 +103,12 @@ typedef struct myolo_conv_desc {
 } myolo_conv_desc;
 int myolo_conv(const myolo_conv_desc* d, void* stream);
 
+/* dgrad of a STRIDE-2 convolution.  `parity[k]`, k = 2*py + px, is the stride-1 sub-convolution producing the input-gradient pixels
+ * (2a+py, 2b+px) from dy and the transposed weights (the taps with (p + pad - k*d) % 2 == 0; y = the strided parity view of gx).  With
+ * all n == 4 parities over one dy / one weight tensor the four run as ONE launch (dy staged once, every gx row written whole);
+ * otherwise, or when the layer does not qualify (fp32, weight panel too large), each is a myolo_conv. */
+int myolo_conv_dgrad_s2(const myolo_conv_desc* const* parity, int n, void* stream);
+
 /* wgrad: dw_oihw[co][ci][t] += sum_{n,oy,ox} dy[n,oy,ox,co] * x[n, (oy*stride+tap_dy[t])>>up, (ox*stride+tap_dx[t])>>up, ci]
  * (into an OIHW fp32 gradient buffer = Parameter.grad layout; split-K partials go through `ws` when given, else fp32 atomics).
  * db (optional, fp32[cout]) += sum dy. */

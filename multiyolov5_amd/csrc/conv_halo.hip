@@ -38,6 +38,9 @@ struct ConvH {
   int x_bytes, y_bytes, r_bytes;
   int xbuf_bytes;                    // bytes of one halo buffer
   int dbg;                           // profiling only (set_option "halo_dbg"): 1 no stores, 2 no global loads, 4 no MFMA, 8 no panel
+  // S2 (fused dgrad of a stride-2 convolution): wave w owns output parity class (w>>1, w&1) with its own tap list
+  int cls_ntaps[4], cls_off[4][4], cls_w[4][4];
+  int Hfull, Wfull;                  // extent of the full gradient tensor (y_* describe it: strides of the whole tensor)
 };
 
 __device__ __forceinline__ int swzB(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // weight panel: H = {0,2,3,1}
@@ -45,7 +48,11 @@ __device__ __forceinline__ int xoff(int pix, int seg) { return pix * 64 + ((seg 
 
 // MF: 16-pixel fragments per wave (4: tile 8 x 32, 2: tile 4 x 32); NVT: staging vectors per thread and chunk
 // EPI 0: raw output (+ BatchNorm statistics); EPI 1: scale/shift + activation (eval).  EXTRA: residual / accumulate loads.
-template <int BN, int MF, int NVT, int EPI, int EXTRA>
+// S2 = 1: the dgrad of a STRIDE-2 convolution, all four output parities in one launch.  gx[2a+py][2b+px] = sum over the taps of parity
+//   class (py,px) of dy[a+oy_t][b+ox_t] . W^T[t] (1, 2, 2 and 4 taps for a 3x3): the output tile is still 8 x 32 pixels of gx, wave w
+//   owns parity (w>>1, w&1) = 4 rows x 16 pixels, the dy halo is 5 x 17 pixels per 32-channel chunk, every gx row is written once
+//   with all its pixels (the per-parity launches of round 1 each re-read dy and wrote every other 64-byte pixel of gx).
+template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0>
 __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   constexpr int NF = BN / 16;
   constexpr int TH = MF * 2;          // 4 waves x (MF/2) rows x 2 fragments per row
@@ -65,7 +72,8 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
       sT[c] = (p.scale && cg < p.Cout) ? p.scale[cg] : 1.0f;
       sT[BN + c] = (p.shift && cg < p.Cout) ? p.shift[cg] : 0.0f;
     }
-  for (int t = tid; t < p.ntaps; t += THREADS) sTap[t] = p.tap_off[t];
+  if (S2) { if (tid < 16) { sTap[tid] = p.cls_off[tid >> 2][tid & 3]; sTap[16 + tid] = p.cls_w[tid >> 2][tid & 3]; } }
+  else for (int t = tid; t < p.ntaps; t += THREADS) sTap[t] = p.tap_off[t];
 
   constexpr int OOB = 0x7fff0000;
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   auto decode_issue = [&]() {
     const int n = i_tile / tiles_per_img; const int r = i_tile - n * tiles_per_img;
     const int ty = r / p.tiles_x, tx = r - ty * p.tiles_x;
-    const int hy0 = ty * TH - p.oy0, hx0 = tx * TW - p.ox0;
+    const int hy0 = S2 ? ty * (TH / 2) - p.oy0 : ty * TH - p.oy0, hx0 = S2 ? tx * (TW / 2) - p.ox0 : tx * TW - p.ox0;
     i_base = (n * (int)p.x_sn + hy0 * (int)p.x_sh + hx0 * (int)p.x_sw) * 2;
     i_mask = 0;
 #pragma unroll
@@ -148,15 +156,16 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   // this lane's pixel inside the halo tile for each of its fragments, at tap offset 0
   int pbase[MF];
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) pbase[mf] = (wave * (MF / 2) + (mf >> 1)) * p.hw + (mf & 1) * 16 + l15;
+  for (int mf = 0; mf < MF; ++mf) pbase[mf] = S2 ? mf * p.hw + l15 : (wave * (MF / 2) + (mf >> 1)) * p.hw + (mf & 1) * 16 + l15;
 
   auto epilogue = [&](int tile) {
     const int n = tile / tiles_per_img; const int r0 = tile - n * tiles_per_img;
     const int ty = r0 / p.tiles_x, tx = r0 - ty * p.tiles_x;
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
-      const int oy = ty * TH + wave * (MF / 2) + (mf >> 1), ox = tx * TW + (mf & 1) * 16 + l15;
-      const bool mok = oy < p.Ho && ox < p.Wo && !(p.dbg & 1);
+      const int oy = S2 ? ty * TH + 2 * mf + (wave >> 1) : ty * TH + wave * (MF / 2) + (mf >> 1);
+      const int ox = S2 ? tx * TW + 2 * l15 + (wave & 1) : tx * TW + (mf & 1) * 16 + l15;
+      const bool mok = (S2 ? (oy < p.Hfull && ox < p.Wfull) : (oy < p.Ho && ox < p.Wo)) && !(p.dbg & 1);
       const int yoff = (n * (int)p.y_sn + oy * (int)p.y_sh + ox * (int)p.y_sw) * 2;
       const int roff = EXTRA ? (n * (int)p.r_sn + oy * (int)p.r_sh + ox * (int)p.r_sw) * 2 : 0;
 #pragma unroll
@@ -195,8 +204,9 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   };
 
   auto load_frags = [&](int t, const char* xb, uint4* fa, uint4* fb) {
-    const int toff = sTap[t];
-    const char* brow = sB + l15 * p.pitchB + (t * p.cin_pad + c_kc * KCH) * 2 + ((lq ^ swzB(l15)) << 4);
+    const int toff = S2 ? sTap[wave * 4 + t] : sTap[t];
+    const int tw = S2 ? sTap[16 + wave * 4 + t] : t;           // S2: the panel holds all weight taps in natural order
+    const char* brow = sB + l15 * p.pitchB + (tw * p.cin_pad + c_kc * KCH) * 2 + ((lq ^ swzB(l15)) << 4);
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) fb[nf] = *reinterpret_cast<const uint4*>(brow + nf * 16 * p.pitchB);
 #pragma unroll
@@ -228,15 +238,16 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
     }
     const char* xb = sX + buf * p.xbuf_bytes;
     uint4 fa0[MF], fb0[NF], fa1[MF], fb1[NF];
+    const int nt = S2 ? __builtin_amdgcn_readfirstlane(p.cls_ntaps[wave]) : p.ntaps;
     load_frags(0, xb, fa0, fb0);
-    int t = (p.dbg & 4) ? p.ntaps : 0;
-    for (; t + 1 < p.ntaps; t += 2) {
+    int t = (p.dbg & 4) ? nt : 0;
+    for (; t + 1 < nt; t += 2) {
       load_frags(t + 1, xb, fa1, fb1);
       mma(fa0, fb0);
-      if (t + 2 < p.ntaps) load_frags(t + 2, xb, fa0, fb0);
+      if (t + 2 < nt) load_frags(t + 2, xb, fa0, fb0);
       mma(fa1, fb1);
     }
-    if ((p.ntaps & 1) && !(p.dbg & 4)) mma(fa0, fb0);
+    if ((nt & 1) && !(p.dbg & 4)) mma(fa0, fb0);
     if (++c_kc == kchunks) { c_kc = 0; epilogue(c_tile); c_tile += sstride; }
     if (more) commit(buf ^ 1);
     __syncthreads();
@@ -267,9 +278,9 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   }
 }
 
-template <int BN, int MF, int NVT, int EPI, int EXTRA>
+template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0>
 int launch4(const ConvH& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
-  auto kern = conv_halo_kernel<BN, MF, NVT, EPI, EXTRA>;
+  auto kern = conv_halo_kernel<BN, MF, NVT, EPI, EXTRA, S2>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -391,4 +402,106 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   if (bn == 64) return mf == 4 ? launch2<64, 4>(k, nvt, grid_x, ntile_n, smem, st) : launch2<64, 2>(k, nvt, grid_x, ntile_n, smem, st);
   return mf == 4 ? launch2<32, 4>(k, nvt, grid_x, ntile_n, smem, st) : launch2<32, 2>(k, nvt, grid_x, ntile_n, smem, st);
+}
+
+// ---- fused dgrad of a stride-2 convolution: the four parity sub-convolutions the host derives (engine.taps_dgrad) in ONE launch ----
+static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream) {
+  using namespace halo;
+  if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
+  static const int s2_off = getenv("MYOLO_NO_HALO_S2") != nullptr;
+  if (g_halo_off || s2_off) return -1;
+  const myolo_conv_desc* d0 = d4[0];
+  if (!d0 || d0->x.dtype != MYOLO_F16 || d0->y.dtype != MYOLO_F16 || (d0->y.c & 3) || d0->cin_pad % KCH) return -1;
+  if ((d0->y.sh & 1) || (d0->y.sw & 1)) return -1;
+  const int64_t fsh = d0->y.sh / 2, fsw = d0->y.sw / 2;
+  int minoy = 1 << 20, maxoy = -(1 << 20), minox = 1 << 20, maxox = -(1 << 20);
+  for (int k = 0; k < 4; ++k) {
+    const myolo_conv_desc* d = d4[k];
+    if (!d || !d->x.ptr || !d->y.ptr || !d->w) return -1;
+    if (d->x.ptr != d0->x.ptr || d->x.n != d0->x.n || d->x.h != d0->x.h || d->x.w != d0->x.w || d->x.c != d0->x.c ||
+        d->x.sn != d0->x.sn || d->x.sh != d0->x.sh || d->x.sw != d0->x.sw || d->x.dtype != MYOLO_F16)
+      return -1;
+    if (d->w != d0->w || d->cin_pad != d0->cin_pad || d->cout_pad != d0->cout_pad || d->wtaps != d0->wtaps) return -1;
+    if (d->stride != 1 || d->up_shift != 0 || d->ntaps < 1 || d->ntaps > 4 || d->det_no > 0) return -1;
+    if (d->scale || d->shift || d->act != MYOLO_ACT_NONE || d->res.ptr || d->stats || d->accumulate != d0->accumulate) return -1;
+    const int py = k >> 1, px = k & 1;
+    if (d->y.dtype != MYOLO_F16 || d->y.c != d0->y.c || d->y.n != d0->y.n || d->y.sn != d0->y.sn || d->y.sh != d0->y.sh || d->y.sw != d0->y.sw)
+      return -1;
+    if ((const char*)d->y.ptr != (const char*)d0->y.ptr + (py * fsh + px * fsw) * 2) return -1;
+    for (int t = 0; t < d->ntaps; ++t) {
+      minoy = d->tap_dy[t] < minoy ? d->tap_dy[t] : minoy; maxoy = d->tap_dy[t] > maxoy ? d->tap_dy[t] : maxoy;
+      minox = d->tap_dx[t] < minox ? d->tap_dx[t] : minox; maxox = d->tap_dx[t] > maxox ? d->tap_dx[t] : maxox;
+      if (d->tap_w[t] < 0 || d->tap_w[t] >= d->wtaps) return -1;
+    }
+  }
+  const int Hfull = d4[0]->y.h + d4[2]->y.h, Wfull = d4[0]->y.w + d4[1]->y.w;
+  if (d4[1]->y.h != d4[0]->y.h || d4[3]->y.h != d4[2]->y.h || d4[2]->y.w != d4[0]->y.w || d4[3]->y.w != d4[1]->y.w) return -1;
+  if (d4[0]->y.h < d4[2]->y.h || d4[0]->y.w < d4[1]->y.w) return -1;
+  const int hh = 4 + (maxoy - minoy), hw = 16 + (maxox - minox);
+  const int nvec = hh * hw * 4;
+  if (nvec > 6 * THREADS) return -1;
+  const int K = d0->wtaps * d0->cin_pad;
+  const int pitch = halo_panel_pitch(K);
+  const int xbuf = hh * hw * 64;
+  int bn = 0, smem = 0;
+  const int bns[2] = {64, 32};
+  for (int bi = 0; bi < 2 && !bn; ++bi) {
+    if (d0->cout_pad % bns[bi]) continue;
+    const int sm = bns[bi] * pitch + 2 * bns[bi] * 4 + 32 * 4 + 2 * xbuf;
+    if (sm <= 160 * 1024) { bn = bns[bi]; smem = sm; }
+  }
+  if (!bn) return -1;
+  ConvH k;
+  memset(&k, 0, sizeof(k));
+  k.x = (const char*)d0->x.ptr; k.x_sn = d0->x.sn; k.x_sh = d0->x.sh; k.x_sw = d0->x.sw;
+  k.Hi = d0->x.h; k.Wi = d0->x.w; k.Cin = d0->x.c;
+  k.y = (char*)d0->y.ptr; k.y_sn = d0->y.sn; k.y_sh = fsh; k.y_sw = fsw;
+  k.Ho = Hfull; k.Wo = Wfull; k.Hfull = Hfull; k.Wfull = Wfull; k.Cout = d0->y.c; k.N = d0->y.n;
+  k.w = (const char*)d0->w; k.cin_pad = d0->cin_pad; k.cout_pad = d0->cout_pad; k.wtaps = d0->wtaps; k.ntaps = d0->wtaps;
+  for (int t = 0; t < MYOLO_MAX_TAPS; ++t) { k.tap_off[t] = 0; k.tap_w[t] = t < d0->wtaps ? t : 0; }      // panel: every weight tap, natural order
+  for (int c = 0; c < 4; ++c) {
+    k.cls_ntaps[c] = d4[c]->ntaps;
+    for (int t = 0; t < 4; ++t) {
+      const bool in = t < d4[c]->ntaps;
+      k.cls_off[c][t] = in ? (d4[c]->tap_dy[t] - minoy) * hw + (d4[c]->tap_dx[t] - minox) : 0;
+      k.cls_w[c][t] = in ? d4[c]->tap_w[t] : 0;
+    }
+  }
+  k.ox0 = -minox; k.oy0 = -minoy; k.hw = hw; k.hh = hh; k.nvec = nvec; k.xbuf_bytes = xbuf;
+  k.act = MYOLO_ACT_NONE; k.accumulate = d0->accumulate; k.dbg = g_halo_dbg;
+  k.tiles_x = (Wfull + TW - 1) / TW; k.tiles_y = (Hfull + 7) / 8;
+  const int64_t nt = (int64_t)k.N * k.tiles_x * k.tiles_y;
+  if (nt <= 0 || nt > 0x3fffffff) return -1;
+  k.ntiles = (int)nt;
+  k.tiles_per_xcd = (k.ntiles + 7) / 8;
+  k.pitchB = pitch;
+  const int64_t xb = (((int64_t)d0->x.n - 1) * d0->x.sn + ((int64_t)d0->x.h - 1) * d0->x.sh + ((int64_t)d0->x.w - 1) * d0->x.sw + d0->x.c) * 2;
+  const int64_t yb = (((int64_t)k.N - 1) * k.y_sn + ((int64_t)Hfull - 1) * fsh + ((int64_t)Wfull - 1) * fsw + k.Cout) * 2;
+  if (xb >= 0x3ffe0000LL || yb >= 0x3ffe0000LL) return -1;
+  k.x_bytes = (int)xb; k.y_bytes = (int)yb; k.r_bytes = 0;
+  const int ntile_n = d0->cout_pad / bn;
+  int per_cu = (160 * 1024) / (smem + 512);
+  if (per_cu > 2) per_cu = 2;
+  if (per_cu < 1) per_cu = 1;
+  int per_xcd = 32 * per_cu / ntile_n;
+  if (per_xcd < 1) per_xcd = 1;
+  if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
+  const int grid_x = per_xcd * 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (bn == 64)
+    return k.accumulate ? launch4<64, 4, 6, 0, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<64, 4, 6, 0, 0, 1>(k, grid_x, ntile_n, smem, st);
+  return k.accumulate ? launch4<32, 4, 6, 0, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<32, 4, 6, 0, 0, 1>(k, grid_x, ntile_n, smem, st);
+}
+
+extern "C" int myolo_conv_dgrad_s2(const myolo_conv_desc* const* parity, int n, void* stream) {
+  if (!parity || n < 1 || n > 4) return MYOLO_EINVAL;
+  if (n == 4) {
+    const int r = halo_s2_try(parity, stream);
+    if (r != -1) return r;
+  }
+  for (int i = 0; i < n; ++i) {               // not fusable (fp32, big K, odd layout ...): the sub-convolutions one by one
+    const int r = myolo_conv(parity[i], stream);
+    if (r) return r;
+  }
+  return 0;
 }

@@ -352,6 +352,7 @@ class ConvOp(Op):
             w = self.weight
             plan.add_pack_job(w, self.wpack_t, self.cout, self.cin, ntaps, cout_pad_t, cin_pad_t, 1)
             self.dg = []
+            par = []                                     # stride 2: the parity sub-convolutions, fused into one launch when all four exist
             s = self.s
             gx_full = self.x.desc(grad=True)
             es = 2 if dt == torch.float16 else 4
@@ -374,7 +375,13 @@ class ConvOp(Op):
                     fill_taps(g, tdy, tdx, tw)
                     g.act, g.accumulate, g.res = L.ACT_NONE, self.acc_x, null_tensor()
                     self.dg.append(g)
-                    calls.append(Call('myolo_conv', (C.byref(g),)))
+                    if s == 2:
+                        par.append(g)
+                    else:
+                        calls.append(Call('myolo_conv', (C.byref(g),)))
+            if par:
+                self.dg_arr = (C.POINTER(L.ConvDesc) * len(par))(*[C.pointer(g) for g in par])
+                calls.append(Call('myolo_conv_dgrad_s2', (self.dg_arr, len(par))))
         # wgrad
         wd = L.WgradDesc()
         wd.x, wd.dy = self.x.desc(), dy_desc
@@ -1101,7 +1108,16 @@ def _conv_desc_of(call):
     return call.args[0]._obj
 
 
+def _s2_descs(call):
+    return [call.args[0][i].contents for i in range(call.args[1])]
+
+
 def conv_call_bytes(call):
+    if call.name == 'myolo_conv_dgrad_s2':       # the four parity sub-convolutions of a stride-2 dgrad: dy and the weights once, gx once
+        ds = _s2_descs(call)
+        es = 2 if ds[0].x.dtype == L.F16 else 4
+        d0 = ds[0]
+        return (d0.x.n * d0.x.h * d0.x.w * d0.x.c + sum(d.y.n * d.y.h * d.y.w * d.y.c for d in ds) + d0.y.c * d0.wtaps * d0.x.c) * es
     d = _conv_desc_of(call)
     es = 2 if d.x.dtype == L.F16 else 4
     xin = d.x.n * d.x.h * d.x.w * d.x.c
@@ -1111,6 +1127,8 @@ def conv_call_bytes(call):
 
 
 def conv_call_flops(call):
+    if call.name == 'myolo_conv_dgrad_s2':
+        return sum(2.0 * d.y.n * d.y.h * d.y.w * d.y.c * d.ntaps * d.x.c for d in _s2_descs(call))
     d = _conv_desc_of(call)
     return 2.0 * d.y.n * d.y.h * d.y.w * d.y.c * d.ntaps * d.x.c
 
@@ -1125,7 +1143,7 @@ def call_algorithmic_bytes(call):
     result written once -- conv / dgrad: input + weights + output; wgrad: x + dy + fp32 gradient; BatchNorm forward: raw + out
     (+ residual); backward reduce: gout + raw; backward apply: gout + raw + dy (+ residual gradient).  None for other launches."""
     n = call.name
-    if n == 'myolo_conv':
+    if n in ('myolo_conv', 'myolo_conv_dgrad_s2'):
         return conv_call_bytes(call)
     if n == 'myolo_conv_wgrad':
         d = call.args[0]._obj
@@ -1145,7 +1163,7 @@ def call_algorithmic_bytes(call):
 def plan_algorithmic_bytes(plan):
     """{family: bytes} over the forward + backward launch lists of a training plan"""
     out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
-    fam = {'myolo_conv': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
+    fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
            'myolo_bn_act_bwd_apply': 'batchnorm'}
     for op in plan.ops:
         for c in list(op.fwd_calls) + list(op.bwd_calls):

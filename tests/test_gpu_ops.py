@@ -140,7 +140,7 @@ def force_halo_kernel():
 
 
 @pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
-@pytest.mark.parametrize('name', ['conv3x3_small', 'conv3x3', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'rfb2_global', 'rfb1', 'aspp', 'aspps',
+@pytest.mark.parametrize('name', ['conv3x3_small', 'conv3x3', 'conv3x3s2', 'conv3x3s2_odd', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'rfb2_global', 'rfb1', 'aspp', 'aspps',
                                   'ffm_k3', 'arm'])
 def test_block_halo_kernel(name, training, force_halo_kernel):
     """the block parity cases with the LDS-halo conv kernel forced on (ragged tiles, dilation 2/3/5/7/9, 5x5, residual, accumulate in
