@@ -193,6 +193,13 @@ int launch(const WgT& k, int out_tiles, int smem, hipStream_t st) {
 }
 template <int NT>
 int launch_nt(const WgT& k, int cof, int cif, int out_tiles, int smem, hipStream_t st) {
+  if constexpr (NT == 1) {           // 1x1: one accumulator set, room for 128-wide blocks (x and dy are read once per 128 channels)
+    if (cof == 4 && cif == 4) return launch<NT, 4, 4>(k, out_tiles, smem, st);
+    if (cof == 4 && cif == 2) return launch<NT, 4, 2>(k, out_tiles, smem, st);
+    if (cof == 2 && cif == 4) return launch<NT, 2, 4>(k, out_tiles, smem, st);
+    if (cof == 4 && cif == 1) return launch<NT, 4, 1>(k, out_tiles, smem, st);
+    if (cof == 1 && cif == 4) return launch<NT, 1, 4>(k, out_tiles, smem, st);
+  }
   if (cof == 2 && cif == 2) return launch<NT, 2, 2>(k, out_tiles, smem, st);
   if (cof == 2 && cif == 1) return launch<NT, 2, 1>(k, out_tiles, smem, st);
   if (cof == 1 && cif == 2) return launch<NT, 1, 2>(k, out_tiles, smem, st);
@@ -223,7 +230,8 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
     mindx = d->tap_dx[t] < mindx ? d->tap_dx[t] : mindx; maxdx = d->tap_dx[t] > maxdx ? d->tap_dx[t] : maxdx;
   }
   const int s = d->stride;
-  const int cof = cout_w > 32 ? 2 : 1, cif = cin_w > 32 ? 2 : 1;
+  const int big = d->ntaps == 1 ? 4 : 2;          // widest block per workgroup: 128 channels for 1x1, 64 for 3x3 (9 accumulator sets)
+  const int cof = cout_w > 64 ? big : (cout_w > 32 ? 2 : 1), cif = cin_w > 64 ? big : (cin_w > 32 ? 2 : 1);
   const int CO_T = 32 * cof, CI_T = 32 * cif;
   const int PD = CO_T * 2 + 16, PX = CI_T * 2 + 16;
   const int hw = (TW - 1) * s + 1 + (maxdx - mindx);

@@ -15,8 +15,9 @@ import torch
 from . import _lib as L
 from ._lib import Tensor as CT
 
-# MYOLO_GRAPH_TRAIN=0: training launch lists are enqueued call by call instead of replayed as hipGraphs (see Plan.run_fwd / run_bwd)
-GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '1') != '0'
+# MYOLO_GRAPH_TRAIN=1: training launch lists are replayed as hipGraphs instead of enqueued call by call (see Plan.run_fwd / run_bwd).
+# Opt-in: the step is bound by the main stream'''s kernel time, not by the host (measured r2: eager 10.48 ms, graphs 10.59 ms per step)
+GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '0') != '0'
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
