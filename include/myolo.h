@@ -85,6 +85,25 @@ int myolo_focus_pack(const void* img_nchw, int src_dtype, int n, int h, int w, f
  *                  MYOLO_STAT_COPIES (32) interleaved copies [copy][2][cout] (copy = workgroup id % 32; the consumer adds the
  *                  copies): stats is fp32[8*2*cout], zeroed by the caller   (training-mode BatchNorm statistics)
  *   det_no  > 0 : y is written in Detect's permuted layout [n, na, h, w, det_no] (yolo.py:214)           */
+/* BatchNorm-backward statistics produced by the launch that COMPLETES an activation gradient (the reduce pass of
+ * myolo_bn_act_bwd_reduce folded into the epilogue of the dgrad that writes the last contribution to gout):
+ *   for output channels [c0, c1) of the launch:  dsum[copy][0..C) += sum dz,  dsum[copy][C..2C) += sum dz*xhat,   C = c1 - c0,
+ *   dz = gout * act'(z), z = (y - mean)*invstd*gamma + beta, xhat = (y - mean)*invstd, gout = the value the launch stores (after
+ *   `accumulate`, rounded to the storage type), y = raw conv output of the normalised layer at the same pixel.
+ * Segments whose bounds are not multiples of the kernel's N tile (or launches served by a kernel without this epilogue) are handled
+ * by an internal myolo_bn_act_bwd_reduce launch over the stored gout: the caller gets `dsum` either way. */
+#define MYOLO_MAX_BNB 4
+typedef struct myolo_bn_bwd_seg {
+  int32_t c0, c1;            /* channel range inside the launch's output y */
+  myolo_tensor y;            /* raw conv output of the normalised layer: [N,Ho,Wo,c1-c0], same pixels as the launch's y */
+  const float* saved;        /* fp32[2*C]: mean, invstd (myolo_bn_act_fwd) */
+  const float* gamma;
+  const float* beta;
+  float*  dsum;              /* fp32[MYOLO_STAT_COPIES*2*C], zeroed by the caller */
+  int32_t act;
+  int32_t reserved;
+} myolo_bn_bwd_seg;
+
 typedef struct myolo_conv_desc {
   myolo_tensor x;            /* [N,Hi,Wi,Cin] (source dims; logical dims are <<up_shift) */
   myolo_tensor y;            /* [N,Ho,Wo,Cout] */
@@ -99,7 +118,8 @@ typedef struct myolo_conv_desc {
   myolo_tensor res;          /* res.ptr == NULL: none */
   float*  stats;             /* fp32[MYOLO_STAT_COPIES*2*cout] or NULL */
   int32_t det_no;
-  int32_t reserved;
+  int32_t nbnb;              /* number of entries of `bnb` (0..MYOLO_MAX_BNB) */
+  const myolo_bn_bwd_seg* bnb;   /* BatchNorm-backward statistics to produce for (slices of) y, or NULL */
 } myolo_conv_desc;
 int myolo_conv(const myolo_conv_desc* d, void* stream);
 

@@ -21,13 +21,18 @@ class Tensor(C.Structure):
                 ('sn', C.c_int64), ('sh', C.c_int64), ('sw', C.c_int64), ('dtype', C.c_int32), ('reserved', C.c_int32)]
 
 
+class BnBwdSeg(C.Structure):
+    _fields_ = [('c0', C.c_int32), ('c1', C.c_int32), ('y', Tensor), ('saved', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('dsum', C.c_void_p), ('act', C.c_int32), ('reserved', C.c_int32)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('x', Tensor), ('y', Tensor), ('w', C.c_void_p),
                 ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('wtaps', C.c_int32),
                 ('ntaps', C.c_int32), ('stride', C.c_int32), ('up_shift', C.c_int32),
                 ('tap_dy', C.c_int32 * MAX_TAPS), ('tap_dx', C.c_int32 * MAX_TAPS), ('tap_w', C.c_int32 * MAX_TAPS),
                 ('scale', C.c_void_p), ('shift', C.c_void_p), ('act', C.c_int32), ('accumulate', C.c_int32),
-                ('res', Tensor), ('stats', C.c_void_p), ('det_no', C.c_int32), ('reserved', C.c_int32)]
+                ('res', Tensor), ('stats', C.c_void_p), ('det_no', C.c_int32), ('nbnb', C.c_int32), ('bnb', C.POINTER(BnBwdSeg))]
 
 
 class WgradDesc(C.Structure):

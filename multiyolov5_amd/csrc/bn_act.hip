@@ -317,3 +317,18 @@ extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tens
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
+
+// fallback of myolo_conv_desc.bnb: one reduce launch per segment over the gradient the conv launch(es) just stored
+int myolo_bnb_fallback(const myolo_conv_desc* d, const myolo_tensor* gout_full, void* stream) {
+  if (!d->bnb) return 0;
+  const int es = gout_full->dtype == MYOLO_F16 ? 2 : 4;
+  for (int i = 0; i < d->nbnb; ++i) {
+    const myolo_bn_bwd_seg& s = d->bnb[i];
+    myolo_tensor g = *gout_full;
+    g.ptr = (char*)gout_full->ptr + (int64_t)s.c0 * es;
+    g.c = s.c1 - s.c0;
+    const int r = myolo_bn_act_bwd_reduce(&g, &s.y, s.saved, s.gamma, s.beta, s.act, s.dsum, stream);
+    if (r) return r;
+  }
+  return 0;
+}

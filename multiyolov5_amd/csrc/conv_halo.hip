@@ -41,6 +41,7 @@ struct ConvH {
   // S2 (fused dgrad of a stride-2 convolution): wave w owns output parity class (w>>1, w&1) with its own tap list
   int cls_ntaps[4], cls_off[4][4], cls_w[4][4];
   int Hfull, Wfull;                  // extent of the full gradient tensor (y_* describe it: strides of the whole tensor)
+  BnbArgs bnb;                       // BatchNorm-backward statistics folded into the epilogue (BNS)
 };
 
 __device__ __forceinline__ int swzB(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // weight panel: H = {0,2,3,1}
@@ -52,14 +53,15 @@ __device__ __forceinline__ int xoff(int pix, int seg) { return pix * 64 + ((seg 
 //   class (py,px) of dy[a+oy_t][b+ox_t] . W^T[t] (1, 2, 2 and 4 taps for a 3x3): the output tile is still 8 x 32 pixels of gx, wave w
 //   owns parity (w>>1, w&1) = 4 rows x 16 pixels, the dy halo is 5 x 17 pixels per 32-channel chunk, every gx row is written once
 //   with all its pixels (the per-parity launches of round 1 each re-read dy and wrote every other 64-byte pixel of gx).
-template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0>
+// BNS = 1 (with EPI 0): the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb)
+template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0, int BNS = 0>
 __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   constexpr int NF = BN / 16;
   constexpr int TH = MF * 2;          // 4 waves x (MF/2) rows x 2 fragments per row
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sB = smem;                                                        // [BN][pitchB] weight panel
-  float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [2][BN] scale, shift
-  int* sTap = reinterpret_cast<int*>(sT + 2 * BN);                        // [MAX_TAPS] halo pixel offset of each tap
+  float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [4][BN]: scale, shift (EPI 1) | mean, invstd, sc, sh (BNS)
+  int* sTap = reinterpret_cast<int*>(sT + 4 * BN);                        // [MAX_TAPS] halo pixel offset of each tap
   char* sX = reinterpret_cast<char*>(sTap + 32);                          // [2][xbuf_bytes]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -72,6 +74,22 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
       sT[c] = (p.scale && cg < p.Cout) ? p.scale[cg] : 1.0f;
       sT[BN + c] = (p.shift && cg < p.Cout) ? p.shift[cg] : 0.0f;
     }
+  int sgi = -1;                          // BNS: the segment this N tile belongs to (segments are multiples of BN wide)
+  if (BNS) {
+    for (int i = 0; i < p.bnb.n; ++i)
+      if (tn * BN >= p.bnb.seg[i].c0 && tn * BN < p.bnb.seg[i].c1) sgi = i;
+    if (sgi >= 0) {
+      const BnbSeg& sg = p.bnb.seg[sgi];
+      const int Cs = sg.c1 - sg.c0;
+      for (int c = tid; c < BN; c += THREADS) {
+        const int ci = tn * BN + c - sg.c0;
+        const bool in = ci < Cs;
+        const float mean = in ? sg.saved[ci] : 0.f, istd = in ? sg.saved[Cs + ci] : 0.f;
+        const float sc = in ? sg.gamma[ci] * istd : 0.f;
+        sT[c] = mean; sT[BN + c] = istd; sT[2 * BN + c] = sc; sT[3 * BN + c] = in ? sg.beta[ci] - mean * sc : 0.f;
+      }
+    }
+  }
   if (S2) { if (tid < 16) { sTap[tid] = p.cls_off[tid >> 2][tid & 3]; sTap[16 + tid] = p.cls_w[tid >> 2][tid & 3]; } }
   else for (int t = tid; t < p.ntaps; t += THREADS) sTap[t] = p.tap_off[t];
 
@@ -177,7 +195,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
         for (int r = 0; r < 4; ++r) {
           const float v0 = acc[mf][nf][r];
           acc[mf][nf][r] = 0.f;
-          if (EPI == 0) { v[r] = v0; if (mok) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; } }
+          if (EPI == 0) { v[r] = v0; if (mok && !BNS) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; } }
           else v[r] = act_f(v0 * sT[cl + r] + sT[BN + cl + r], p.act);
         }
         const bool ok = mok && c0 < p.Cout;
@@ -199,6 +217,22 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
         __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2_t*>(&o), ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
+        if (BNS) {
+          if (sgi >= 0) {                // (wave-uniform) dz = gout * act'(z) of the normalised layer, from its raw output at this pixel
+            const BnbSeg& sg = p.bnb.seg[sgi];
+            const bool okb = ok && c0 < sg.c1;
+            const char* yp = okb ? sg.y + ((int64_t)n * sg.y_sn + (int64_t)oy * sg.y_sh + (int64_t)ox * sg.y_sw + (c0 - sg.c0)) * 2 : zero_page();
+            const u32x2_t yr = ldg8(yp);
+            const h4_t yh = *reinterpret_cast<const h4_t*>(&yr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yv = (float)yh[r], g = okb ? (float)o[r] : 0.f;
+              const float dz = g * act_grad_f(fmaf(yv, sT[2 * BN + cl + r], sT[3 * BN + cl + r]), sg.act);
+              st_s[nf][r] += dz;
+              st_q[nf][r] += dz * (yv - sT[cl + r]) * sT[BN + cl + r];
+            }
+          }
+        }
       }
     }
   };
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
     __syncthreads();
   }
 
-  if (EPI == 0 && p.stats) {
+  if (EPI == 0 && (BNS ? sgi >= 0 : p.stats != nullptr)) {
     float* red = reinterpret_cast<float*>(sX);         // [4 waves][2*BN]; the loop ended with a barrier
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
@@ -273,14 +307,20 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
       const float a = red[t] + red[2 * BN + t] + red[4 * BN + t] + red[6 * BN + t];
       const int cl = t < BN ? t : t - BN;
       const int c = tn * BN + cl;
-      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
+      if (BNS) {
+        const BnbSeg& sg = p.bnb.seg[sgi];
+        const int Cs = sg.c1 - sg.c0, ci = c - sg.c0;
+        if (ci < Cs) atomicAdd(sg.dsum + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * Cs + (t < BN ? ci : Cs + ci), a);
+      } else if (c < p.Cout) {
+        atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
+      }
     }
   }
 }
 
-template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0>
+template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0, int BNS = 0>
 int launch4(const ConvH& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
-  auto kern = conv_halo_kernel<BN, MF, NVT, EPI, EXTRA, S2>;
+  auto kern = conv_halo_kernel<BN, MF, NVT, EPI, EXTRA, S2, BNS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -293,6 +333,8 @@ template <int BN, int MF, int NVT>
 int launch3(const ConvH& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
   const bool raw = !k.scale && !k.shift && k.act == MYOLO_ACT_NONE;
   const bool extra = k.res != nullptr || k.accumulate;
+  if (raw && k.bnb.n > 0)
+    return extra ? launch4<BN, MF, NVT, 0, 1, 0, 1>(k, grid_x, ntile_n, smem, st) : launch4<BN, MF, NVT, 0, 0, 0, 1>(k, grid_x, ntile_n, smem, st);
   if (raw) return extra ? launch4<BN, MF, NVT, 0, 1>(k, grid_x, ntile_n, smem, st) : launch4<BN, MF, NVT, 0, 0>(k, grid_x, ntile_n, smem, st);
   return extra ? launch4<BN, MF, NVT, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<BN, MF, NVT, 1, 0>(k, grid_x, ntile_n, smem, st);
 }
@@ -321,8 +363,9 @@ int myolo_conv_halo_set(const char* name, int value) {
 }
 
 // returns -1 when the layer does not qualify (caller falls back to the other kernels), else a hipError_t / 0
-int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream) {
+int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   using namespace halo;
+  *bnb_done = 0;
   if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
   if (g_halo_min_tiles < 0) g_halo_min_tiles = getenv("MYOLO_HALO_MIN_TILES") ? atoi(getenv("MYOLO_HALO_MIN_TILES")) : 16;
   if (g_halo_off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
@@ -356,7 +399,7 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream) {
       const int nvt_ = (nvec + THREADS - 1) / THREADS;
       if (nvt_ > 10) continue;
       const int xb = hh_ * hw_ * 64;
-      const int sm = b * pitch + 2 * b * 4 + 32 * 4 + 2 * xb;
+      const int sm = b * pitch + 4 * b * 4 + 32 * 4 + 2 * xb;
       if (sm > 160 * 1024) continue;
       bn = b; mf = m; hh = hh_; hw = hw_; nvt = nvt_; xbuf = xb; smem = sm;
     }
@@ -376,6 +419,8 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream) {
   k.scale = d->scale; k.shift = d->shift; k.act = d->act; k.accumulate = d->accumulate;
   k.res = (const char*)d->res.ptr; k.r_sn = d->res.sn; k.r_sh = d->res.sh; k.r_sw = d->res.sw;
   k.stats = d->stats; k.dbg = g_halo_dbg;
+  k.bnb.n = 0;
+  if (d->bnb && d->nbnb > 0 && !d->stats && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && bnb_aligned(d, bn)) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
   const int th = mf * 2;
   k.tiles_x = (k.Wo + TW - 1) / TW; k.tiles_y = (k.Ho + th - 1) / th;
   const int64_t nt = (int64_t)k.N * k.tiles_x * k.tiles_y;
@@ -405,8 +450,9 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream) {
 }
 
 // ---- fused dgrad of a stride-2 convolution: the four parity sub-convolutions the host derives (engine.taps_dgrad) in ONE launch ----
-static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream) {
+static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream, int* bnb_done, myolo_tensor* full) {
   using namespace halo;
+  *bnb_done = 0;
   if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
   static const int s2_off = getenv("MYOLO_NO_HALO_S2") != nullptr;
   if (g_halo_off || s2_off) return -1;
@@ -447,7 +493,7 @@ static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream) {
   const int bns[2] = {64, 32};
   for (int bi = 0; bi < 2 && !bn; ++bi) {
     if (d0->cout_pad % bns[bi]) continue;
-    const int sm = bns[bi] * pitch + 2 * bns[bi] * 4 + 32 * 4 + 2 * xbuf;
+    const int sm = bns[bi] * pitch + 4 * bns[bi] * 4 + 32 * 4 + 2 * xbuf;
     if (sm <= 160 * 1024) { bn = bns[bi]; smem = sm; }
   }
   if (!bn) return -1;
@@ -488,6 +534,16 @@ static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream) {
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
   const int grid_x = per_xcd * 8;
   hipStream_t st = (hipStream_t)stream;
+  if (d0->bnb && d0->nbnb > 0) {
+    myolo_conv_desc tmp = *d0;               // (bnb channel ranges refer to the full gradient tensor: same channels in every parity)
+    tmp.y.c = d0->y.c;
+    if (bnb_aligned(&tmp, bn)) { bnb_fill(&k.bnb, d0); *bnb_done = 1; }
+  }
+  if (k.bnb.n > 0) {
+    if (bn == 64)
+      return k.accumulate ? launch4<64, 4, 6, 0, 1, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<64, 4, 6, 0, 0, 1, 1>(k, grid_x, ntile_n, smem, st);
+    return k.accumulate ? launch4<32, 4, 6, 0, 1, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<32, 4, 6, 0, 0, 1, 1>(k, grid_x, ntile_n, smem, st);
+  }
   if (bn == 64)
     return k.accumulate ? launch4<64, 4, 6, 0, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<64, 4, 6, 0, 0, 1>(k, grid_x, ntile_n, smem, st);
   return k.accumulate ? launch4<32, 4, 6, 0, 1, 1>(k, grid_x, ntile_n, smem, st) : launch4<32, 4, 6, 0, 0, 1>(k, grid_x, ntile_n, smem, st);
@@ -495,13 +551,32 @@ static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream) {
 
 extern "C" int myolo_conv_dgrad_s2(const myolo_conv_desc* const* parity, int n, void* stream) {
   if (!parity || n < 1 || n > 4) return MYOLO_EINVAL;
+  const myolo_conv_desc* d0 = parity[0];
+  const bool want_bnb = d0 && d0->bnb && d0->nbnb > 0;
+  // the whole gradient tensor the parity views interleave (for the statistics fallback)
+  myolo_tensor full = d0 ? d0->y : myolo_tensor{};
+  if (d0 && n == 4 && parity[1] && parity[2]) {
+    full.h = parity[0]->y.h + parity[2]->y.h; full.w = parity[0]->y.w + parity[1]->y.w;
+    full.sh = d0->y.sh / 2; full.sw = d0->y.sw / 2;
+  }
   if (n == 4) {
-    const int r = halo_s2_try(parity, stream);
-    if (r != -1) return r;
+    int done = 0;
+    const int r = halo_s2_try(parity, stream, &done, &full);
+    if (r != -1) {
+      if (r) return r;
+      return (want_bnb && !done) ? myolo_bnb_fallback(d0, &full, stream) : 0;
+    }
   }
   for (int i = 0; i < n; ++i) {               // not fusable (fp32, big K, odd layout ...): the sub-convolutions one by one
-    const int r = myolo_conv(parity[i], stream);
+    if (!parity[i]) return MYOLO_EINVAL;
+    myolo_conv_desc sub = *parity[i];
+    sub.bnb = nullptr; sub.nbnb = 0;          // (a parity launch sees a quarter of the pixels: the statistics follow below)
+    const int r = myolo_conv(&sub, stream);
     if (r) return r;
+  }
+  if (want_bnb) {
+    if (n != 4) return MYOLO_EINVAL;          // statistics need the complete tensor
+    return myolo_bnb_fallback(d0, &full, stream);
   }
   return 0;
 }

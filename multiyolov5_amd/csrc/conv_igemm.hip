@@ -34,6 +34,7 @@ struct ConvK {
   const float* scale; const float* shift; int act; int accumulate;
   const char* res; int64_t r_sn, r_sh, r_sw;
   float* stats; int det_no; int M; int ntile_m; int tiles_per_xcd; int bm;
+  BnbArgs bnb; int bn_off;           // BNS: statistics segments; byte offset of the [4][BN] constant table / reduction area in LDS
 };
 
 }  // namespace
@@ -63,7 +64,9 @@ template <> struct Mma<float> {
 // share each CU instead of one
 // KS = 64-byte K sub-chunks per step (1 or 2): a 128-byte step halves the per-step overhead (barrier, ~110 scalar/vector
 // address instructions) per MFMA; each sub-chunk is its own swizzled [rows][64 B] plane in LDS.
-template <typename T, int BN, int BM, int KS>
+// BNS = 1: the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb), computed on the final
+// (accumulated, storage-rounded) values in the store loop; thread t always serves channel vector t % (BN/SEG)
+template <typename T, int BN, int BM, int KS, int BNS = 0>
 __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
   constexpr int MF = BM / 64;        // 16-row fragments per wave; also A rows staged per thread
   constexpr int SEG = ET<T>::SEG;   // elements per 16 B
@@ -105,6 +108,28 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
   }
 
   const char* wbase = p.w + (int64_t)(tn * BN) * p.wtaps * p.cin_pad * ES;
+
+  int sgi = -1;
+  float* sBN = reinterpret_cast<float*>(smem + p.bn_off);       // [4][BN] mean, invstd, sc, sh (outside the A/B/C staging area)
+  float bs0[SEG], bs1[SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) { bs0[i] = 0.f; bs1[i] = 0.f; }
+  if (BNS) {
+    for (int i = 0; i < p.bnb.n; ++i)
+      if (tn * BN >= p.bnb.seg[i].c0 && tn * BN < p.bnb.seg[i].c1) sgi = i;
+    if (sgi >= 0) {
+      const BnbSeg& sg = p.bnb.seg[sgi];
+      const int Cs = sg.c1 - sg.c0;
+      for (int c = tid; c < BN; c += THREADS) {
+        const int ci = tn * BN + c - sg.c0;
+        const bool in = ci < Cs;
+        const float mean = in ? sg.saved[ci] : 0.f, istd = in ? sg.saved[Cs + ci] : 0.f;
+        const float sc = in ? sg.gamma[ci] * istd : 0.f;
+        sBN[c] = mean; sBN[BN + c] = istd; sBN[2 * BN + c] = sc; sBN[3 * BN + c] = in ? sg.beta[ci] - mean * sc : 0.f;
+      }
+    }
+    // (visible to the store loop: every tile's epilogue starts with a barrier)
+  }
 
   for (int tslot = bslot; tslot < p.tiles_per_xcd; tslot += bstride) {
     const int tm = xcd * p.tiles_per_xcd + tslot;
@@ -229,8 +254,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float v0 = acc[mf][nf][r];
-          st_s[nf] += v0;
-          st_q[nf] += v0 * v0;
+          if (!BNS) { st_s[nf] += v0; st_q[nf] += v0 * v0; }
           float v = v0 * e_scale[nf] + e_shift[nf];
           v = act_f(v, p.act);
           const int row = wave * (16 * MF) + mf * 16 + 4 * (lane >> 4) + r;
@@ -274,7 +298,25 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
           for (int i = 0; i < SEG; ++i) f[i] += g[i];
         }
-        stg16(yp, Vec<T>::pack(f));
+        const uint4 packed = Vec<T>::pack(f);
+        stg16(yp, packed);
+        if (BNS) {
+          if (sgi >= 0) {
+            const BnbSeg& sg = p.bnb.seg[sgi];
+            if (c0 < sg.c1) {
+              float gq[SEG], yv[SEG];
+              Vec<T>::unpack(packed, gq);            // gout as stored (what the apply pass will read back)
+              Vec<T>::unpack(ldg16(sg.y + ((int64_t)n * sg.y_sn + (int64_t)oy * sg.y_sh + (int64_t)ox * sg.y_sw + (c0 - sg.c0)) * ES), yv);
+              const int cl = cs * SEG;
+#pragma unroll
+              for (int i = 0; i < SEG; ++i) {
+                const float dz = gq[i] * act_grad_f(fmaf(yv[i], sBN[2 * BN + cl + i], sBN[3 * BN + cl + i]), sg.act);
+                bs0[i] += dz;
+                bs1[i] += dz * (yv[i] - sBN[cl + i]) * sBN[BN + cl + i];
+              }
+            }
+          }
+        }
       } else {
         T* ys = reinterpret_cast<T*>(yp);
         const T* rs = p.res ? reinterpret_cast<const T*>(p.res + ((int64_t)n * p.r_sn + (int64_t)oy * p.r_sh + (int64_t)ox * p.r_sw + c0) * ES) : nullptr;
@@ -289,7 +331,26 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
     __syncthreads();
   }
 
-  if (p.stats) {
+  if (BNS) {
+    if (sgi >= 0) {
+      // threads with the same channel vector (tid % VPR) meet in LDS; one atomic per channel and sum per workgroup
+      constexpr int VPRc = BN / SEG;
+      float* red = reinterpret_cast<float*>(smem);     // [THREADS / VPR][2][BN]   (the last tile's epilogue ended with a barrier)
+      const int cs = tid % VPRc, rr = tid / VPRc;
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) { red[(rr * 2) * BN + cs * SEG + i] = bs0[i]; red[(rr * 2 + 1) * BN + cs * SEG + i] = bs1[i]; }
+      __syncthreads();
+      const BnbSeg& sg = p.bnb.seg[sgi];
+      const int Cs = sg.c1 - sg.c0;
+      for (int t = tid; t < 2 * BN; t += THREADS) {
+        const int which = t / BN, cl = t - which * BN;
+        float a = 0.f;
+        for (int q = 0; q < THREADS / VPRc; ++q) a += red[(q * 2 + which) * BN + cl];
+        const int ci = tn * BN + cl - sg.c0;
+        if (ci < Cs) atomicAdd(sg.dsum + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * Cs + which * Cs + ci, a);
+      }
+    }
+  } else if (p.stats) {
     // lanes -> wave (rows of the fragment) -> workgroup (LDS) -> one coalesced atomic per channel per workgroup
     float* red = reinterpret_cast<float*>(smem);       // [4 waves][2*BN]; the last tile's epilogue ended with a barrier
 #pragma unroll
@@ -309,14 +370,19 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
   }
 }
 
-template <typename T, int BN, int BM, int KS>
-int launch_conv3(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
+template <typename T, int BN, int BM, int KS, int BNS>
+int launch_conv4(ConvK k, int grid_x, int ntile_n, hipStream_t st) {
   constexpr int ES = (int)sizeof(T);
+  constexpr int SEG = 16 / ES;
   constexpr int AB = 2 * KS * (BM * 64 + BN * 64);
   constexpr int CB = BM * (BN * ES + 16);
   constexpr int SB = 4 * 2 * BN * 4;             // statistics reduction [4 waves][2*BN] floats
-  const int smem = (AB > CB ? AB : CB) > SB ? (AB > CB ? AB : CB) : SB;
-  auto kern = conv_igemm_kernel<T, BN, BM, KS>;
+  constexpr int RB = BNS ? (THREADS / (BN / SEG)) * 2 * BN * 4 : 0;   // BNS reduction [threads per channel vector][2][BN]
+  int smem = (AB > CB ? AB : CB) > SB ? (AB > CB ? AB : CB) : SB;
+  if (RB > smem) smem = RB;
+  k.bn_off = smem;
+  if (BNS) smem += 4 * BN * 4;
+  auto kern = conv_igemm_kernel<T, BN, BM, KS, BNS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -324,6 +390,10 @@ int launch_conv3(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;
+}
+template <typename T, int BN, int BM, int KS>
+int launch_conv3(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
+  return k.bnb.n > 0 ? launch_conv4<T, BN, BM, KS, 1>(k, grid_x, ntile_n, st) : launch_conv4<T, BN, BM, KS, 0>(k, grid_x, ntile_n, st);
 }
 
 template <typename T, int BN, int BM>
@@ -350,11 +420,24 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   if (d->x.c % seg || d->x.sw % seg || d->x.sh % seg || d->x.sn % seg || ((uintptr_t)d->x.ptr & 15)) return MYOLO_EINVAL;
   if (d->det_no > 0 && (d->y.c % d->det_no)) return MYOLO_EINVAL;
   if (d->res.ptr && d->res.dtype != dt) return MYOLO_EINVAL;
+  const bool want_bnb = d->bnb != nullptr && d->nbnb > 0;
+  if (want_bnb) {
+    if (d->nbnb > MYOLO_MAX_BNB || d->det_no > 0) return MYOLO_EINVAL;
+    for (int i = 0; i < d->nbnb; ++i) {
+      const myolo_bn_bwd_seg& sg = d->bnb[i];
+      if (sg.c0 < 0 || sg.c1 <= sg.c0 || sg.c1 > d->y.c || sg.c0 % seg || sg.c1 % seg || !sg.y.ptr || !sg.saved || !sg.gamma || !sg.beta ||
+          !sg.dsum || sg.y.dtype != dt || sg.y.c != sg.c1 - sg.c0 || sg.y.n != d->y.n || sg.y.h != d->y.h || sg.y.w != d->y.w)
+        return MYOLO_EINVAL;
+    }
+  }
   if (dt == MYOLO_F16) {
-    int r = myolo_conv_halo_try(d, stream);    // k x k stride-1 layers: input halo tiles staged in LDS (conv_halo.hip)
-    if (r != -1) return r;
-    r = myolo_conv_stream_try(d, stream);      // HBM-bound 1x1 / strided layers: the streaming kernel (conv_stream.hip)
-    if (r != -1) return r;
+    int done = 0;
+    int r = myolo_conv_halo_try(d, stream, &done);    // k x k stride-1 layers: input halo tiles staged in LDS (conv_halo.hip)
+    if (r == -1) r = myolo_conv_stream_try(d, stream, &done);      // HBM-bound 1x1 / strided layers: the streaming kernel (conv_stream.hip)
+    if (r != -1) {
+      if (r) return r;
+      return (want_bnb && !done) ? myolo_bnb_fallback(d, &d->y, stream) : 0;
+    }
   }
   ConvK k;
   k.x = (const char*)d->x.ptr; k.x_sn = d->x.sn; k.x_sh = d->x.sh; k.x_sw = d->x.sw;
@@ -367,6 +450,7 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   k.scale = d->scale; k.shift = d->shift; k.act = d->act; k.accumulate = d->accumulate;
   k.res = (const char*)d->res.ptr; k.r_sn = d->res.sn; k.r_sh = d->res.sh; k.r_sw = d->res.sw;
   k.stats = d->stats; k.det_no = d->det_no;
+  k.bnb.n = 0; k.bn_off = 0;
   const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
   if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
   k.M = (int)M;
@@ -381,13 +465,18 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
   const int grid_x = per_xcd * 8;
   hipStream_t st = (hipStream_t)stream;
+  const bool fold = want_bnb && !d->stats && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && bnb_aligned(d, bn);
+  if (fold) bnb_fill(&k.bnb, d);
+  int r;
   if (dt == MYOLO_F16) {
-    if (bn == 128) return launch_conv<half_t, 128>(k, grid_x, ntile_n, st);
-    if (bn == 64) return launch_conv<half_t, 64>(k, grid_x, ntile_n, st);
-    return launch_conv<half_t, 32>(k, grid_x, ntile_n, st);
+    if (bn == 128) r = launch_conv<half_t, 128>(k, grid_x, ntile_n, st);
+    else if (bn == 64) r = launch_conv<half_t, 64>(k, grid_x, ntile_n, st);
+    else r = launch_conv<half_t, 32>(k, grid_x, ntile_n, st);
   } else {
-    if (bn == 128) return launch_conv<float, 128>(k, grid_x, ntile_n, st);
-    if (bn == 64) return launch_conv<float, 64>(k, grid_x, ntile_n, st);
-    return launch_conv<float, 32>(k, grid_x, ntile_n, st);
+    if (bn == 128) r = launch_conv<float, 128>(k, grid_x, ntile_n, st);
+    else if (bn == 64) r = launch_conv<float, 64>(k, grid_x, ntile_n, st);
+    else r = launch_conv<float, 32>(k, grid_x, ntile_n, st);
   }
+  if (r) return r;
+  return (want_bnb && !fold) ? myolo_bnb_fallback(d, &d->y, stream) : 0;
 }

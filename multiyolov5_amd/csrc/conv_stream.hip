@@ -32,12 +32,14 @@ struct ConvS {
   const char* res; int64_t r_sn, r_sh, r_sw;
   float* stats; int M; int ntiles; int tiles_per_xcd; int pitchB; int xdense, ydense; int dbg;
   int x_bytes, y_bytes, r_bytes;     // byte spans of the views (buffer descriptors)
+  BnbArgs bnb;                       // BatchNorm-backward statistics folded into the epilogue (BNS); segment tensors are pixel-dense
 };
 
 __device__ __forceinline__ int swz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // H = {0,2,3,1}
 
 // EPI 0: raw output (+ BatchNorm statistics) -- the training forward and every dgrad;  EPI 1: scale/shift + activation (eval)
-template <int BN, int KB, int EPI, int EXTRA>
+// BNS = 1 (with EPI 0): the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb)
+template <int BN, int KB, int EPI, int EXTRA, int BNS = 0>
 __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
   constexpr int NF = BN / 16;
   constexpr int KCH = 32 * KB;                 // halves per A chunk
@@ -50,14 +52,30 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
   // (the weight panel is staged further down, BEHIND the first activation loads: both are ~2 us round trips at kernel start)
   // epilogue constants live in LDS: a global load inside the epilogue would sit BEHIND the prefetched activations in the
   // in-order vmcnt queue and drain the whole pipeline every tile
-  float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [2][BN] scale, shift
+  float* sT = reinterpret_cast<float*>(smem + (size_t)BN * p.pitchB);     // [4][BN]: scale, shift (EPI 1) | mean, invstd, sc, sh (BNS)
   if (EPI == 1)
     for (int c = tid; c < BN; c += THREADS) {
       const int cg = tn * BN + c;
       sT[c] = (p.scale && cg < p.Cout) ? p.scale[cg] : 1.0f;
       sT[BN + c] = (p.shift && cg < p.Cout) ? p.shift[cg] : 0.0f;
     }
-  int* sTap = reinterpret_cast<int*>(sT + 2 * BN);                        // [2][MAX_TAPS] tap_dy, tap_dx
+  int sgi = -1;
+  if (BNS) {
+    for (int i = 0; i < p.bnb.n; ++i)
+      if (tn * BN >= p.bnb.seg[i].c0 && tn * BN < p.bnb.seg[i].c1) sgi = i;
+    if (sgi >= 0) {
+      const BnbSeg& sg = p.bnb.seg[sgi];
+      const int Cs = sg.c1 - sg.c0;
+      for (int c = tid; c < BN; c += THREADS) {
+        const int ci = tn * BN + c - sg.c0;
+        const bool in = ci < Cs;
+        const float mean = in ? sg.saved[ci] : 0.f, istd = in ? sg.saved[Cs + ci] : 0.f;
+        const float sc = in ? sg.gamma[ci] * istd : 0.f;
+        sT[c] = mean; sT[BN + c] = istd; sT[2 * BN + c] = sc; sT[3 * BN + c] = in ? sg.beta[ci] - mean * sc : 0.f;
+      }
+    }
+  }
+  int* sTap = reinterpret_cast<int*>(sT + 4 * BN);                        // [2][MAX_TAPS] tap_dy, tap_dx
   for (int t = tid; t < p.ntaps; t += THREADS) { sTap[t] = p.tap_dy[t]; sTap[MYOLO_MAX_TAPS + t] = p.tap_dx[t]; }
   __syncthreads();
 
@@ -189,7 +207,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
         for (int r = 0; r < 4; ++r) {
           const float v0 = acc[mf][nf][r];
           acc[mf][nf][r] = 0.f;
-          if (EPI == 0) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; v[r] = v0; }
+          if (EPI == 0) { if (!BNS) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; } v[r] = v0; }
           else v[r] = act_f(v0 * sT[cl + r] + sT[BN + cl + r], p.act);
         }
         const bool ok = mok && c0 < p.Cout;       // Cout % 4 == 0 (checked on the host): whole 8-byte groups only
@@ -211,6 +229,22 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
         __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2_t*>(&o), ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
+        if (BNS) {
+          if (sgi >= 0) {                // (wave-uniform) dz = gout * act'(z) of the normalised layer, from its raw output at pixel m
+            const BnbSeg& sg = p.bnb.seg[sgi];
+            const bool okb = ok && c0 < sg.c1;
+            const char* yp = okb ? sg.y + ((int64_t)m * sg.y_sw + (c0 - sg.c0)) * 2 : zero_page();
+            const u32x2_t yr = ldg8(yp);
+            const h4_t yh = *reinterpret_cast<const h4_t*>(&yr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float yv = (float)yh[r], g = okb ? (float)o[r] : 0.f;
+              const float dz = g * act_grad_f(fmaf(yv, sT[2 * BN + cl + r], sT[3 * BN + cl + r]), sg.act);
+              st_s[nf][r] += dz;
+              st_q[nf][r] += dz * (yv - sT[cl + r]) * sT[BN + cl + r];
+            }
+          }
+        }
       }
     }
   };
@@ -250,7 +284,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
     }
   }
 
-  if (EPI == 0 && p.stats) {
+  if (EPI == 0 && (BNS ? sgi >= 0 : p.stats != nullptr)) {
     // per-channel sums: lanes -> wave (shuffles over the 16 pixel lanes) -> workgroup (LDS) -> ONE coalesced atomic per
     // channel per workgroup.  (Per-wave atomics on the same 2*Cout addresses cost ~400 us per launch.)
     __syncthreads();                                   // every wave is done with the weight panel
@@ -275,14 +309,20 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
       for (int w = 0; w < WAVES; ++w) a += red[w * 2 * BN + t];
       const int cl = t < BN ? t : t - BN;
       const int c = tn * BN + cl;
-      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
+      if (BNS) {
+        const BnbSeg& sg = p.bnb.seg[sgi];
+        const int Cs = sg.c1 - sg.c0, ci = c - sg.c0;
+        if (ci < Cs) atomicAdd(sg.dsum + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * Cs + (t < BN ? ci : Cs + ci), a);
+      } else if (c < p.Cout) {
+        atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + (t < BN ? c : p.Cout + c), a);
+      }
     }
   }
 }
 
-template <int BN, int KB, int EPI, int EXTRA>
+template <int BN, int KB, int EPI, int EXTRA, int BNS = 0>
 int launch3(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
-  auto kern = conv_stream_kernel<BN, KB, EPI, EXTRA>;
+  auto kern = conv_stream_kernel<BN, KB, EPI, EXTRA, BNS>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
@@ -294,6 +334,8 @@ int launch3(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
 template <int BN, int KB, int EPI>
 int launch2(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
   const bool extra = k.res != nullptr || k.accumulate;
+  if (EPI == 0 && k.bnb.n > 0)
+    return extra ? launch3<BN, KB, 0, 1, 1>(k, grid_x, ntile_n, smem, st) : launch3<BN, KB, 0, 0, 1>(k, grid_x, ntile_n, smem, st);
   return extra ? launch3<BN, KB, EPI, 1>(k, grid_x, ntile_n, smem, st) : launch3<BN, KB, EPI, 0>(k, grid_x, ntile_n, smem, st);
 }
 template <int BN, int KB>
@@ -326,8 +368,9 @@ extern "C" int myolo_set_option(const char* name, int value) {
 
 }
 
-int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
+int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   using namespace stream;
+  *bnb_done = 0;
   if (g_stream_min_tiles < 0) g_stream_min_tiles = getenv("MYOLO_STREAM_MIN_TILES") ? atoi(getenv("MYOLO_STREAM_MIN_TILES")) : 2048;
   if (g_stream_off < 0) g_stream_off = getenv("MYOLO_NO_STREAM") != nullptr;
   const int min_tiles = g_stream_min_tiles;
@@ -341,7 +384,7 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   for (int i = 0; i < 2; ++i) {
     const int b = cands[i];
     if (d->cout_pad % b) continue;
-    if (b * panel_pitch(K) + 2 * b * 4 + 256 <= 144 * 1024) { bn = b; break; }
+    if (b * panel_pitch(K) + 4 * b * 4 + 256 <= 144 * 1024) { bn = b; break; }
   }
   if (!bn) return -1;
   if (d->cout_pad / bn > 8) return -1;                 // A would be re-streamed too often: the tiled kernel wins (6 N tiles of the
@@ -357,6 +400,15 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   k.scale = d->scale; k.shift = d->shift; k.act = d->act; k.accumulate = d->accumulate;
   k.res = (const char*)d->res.ptr; k.r_sn = d->res.sn; k.r_sh = d->res.sh; k.r_sw = d->res.sw;
   k.stats = d->stats;
+  k.bnb.n = 0;
+  if (d->bnb && d->nbnb > 0 && !d->stats && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && bnb_aligned(d, bn)) {
+    bool dense_ok = true;                      // the epilogue addresses the segment tensors by linear pixel index
+    for (int i = 0; i < d->nbnb; ++i) {
+      const myolo_tensor& t = d->bnb[i].y;
+      dense_ok = dense_ok && t.sh == (int64_t)t.w * t.sw && t.sn == (int64_t)t.h * t.sh && t.n == d->y.n && t.h == d->y.h && t.w == d->y.w;
+    }
+    if (dense_ok) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
+  }
   const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
   if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
   k.M = (int)M;
@@ -377,7 +429,7 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream) {
   const int64_t xb = span(d->x), yb = span(d->y), rb = d->res.ptr ? span(d->res) : 0;
   if (xb >= 0x7ffe0000LL || yb >= 0x7ffe0000LL || rb >= 0x7ffe0000LL) return -1;      // 32-bit buffer offsets
   k.x_bytes = (int)xb; k.y_bytes = (int)yb; k.r_bytes = (int)rb;
-  int smem = bn * k.pitchB + 2 * bn * 4 + 2 * MYOLO_MAX_TAPS * 4;
+  int smem = bn * k.pitchB + 4 * bn * 4 + 2 * MYOLO_MAX_TAPS * 4;
   if (smem < WAVES * 2 * bn * 4) smem = WAVES * 2 * bn * 4;
   const int ntile_n = d->cout_pad / bn;
   int per_cu = (160 * 1024) / (smem + 1024);

@@ -81,6 +81,8 @@ __device__ __forceinline__ uint4 ldg16(const void* p) {
   const u32x4_t v = *(const g_u32x4_t*)(p);
   return uint4{v.x, v.y, v.z, v.w};
 }
+typedef __attribute__((address_space(1))) u32x2_t g_u32x2_t;
+__device__ __forceinline__ u32x2_t ldg8(const void* p) { return *(const g_u32x2_t*)(p); }
 __device__ __forceinline__ void stg16(void* p, const uint4& v) {
   *(g_u32x4_t*)(p) = u32x4_t{v.x, v.y, v.z, v.w};
 }
@@ -161,10 +163,33 @@ __device__ __forceinline__ void stage_weight_panel(char* sB, const char* w, int 
   }
 }
 
+// ---- BatchNorm-backward statistics in a dgrad epilogue (myolo_conv_desc.bnb) ----
+struct BnbSeg {              // device-side copy of one myolo_bn_bwd_seg
+  int c0, c1;
+  const char* y; int64_t y_sn, y_sh, y_sw;
+  const float* saved; const float* gamma; const float* beta; float* dsum; int act;
+};
+struct BnbArgs { int n; BnbSeg seg[MYOLO_MAX_BNB]; };
+// host: true when every segment starts and ends on a multiple of `bn` (so that one N tile belongs to one segment)
+static inline bool bnb_aligned(const myolo_conv_desc* d, int bn) {
+  for (int i = 0; i < d->nbnb; ++i)
+    if (d->bnb[i].c0 % bn || (d->bnb[i].c1 % bn && d->bnb[i].c1 != d->y.c)) return false;
+  return true;
+}
+static inline void bnb_fill(BnbArgs* a, const myolo_conv_desc* d) {
+  a->n = d->bnb ? d->nbnb : 0;
+  for (int i = 0; i < a->n; ++i) {
+    const myolo_bn_bwd_seg& s = d->bnb[i];
+    a->seg[i] = BnbSeg{s.c0, s.c1, (const char*)s.y.ptr, s.y.sn, s.y.sh, s.y.sw, s.saved, s.gamma, s.beta, s.dsum, s.act};
+  }
+}
+// bn_act.hip: the reduce pass over the STORED gout for every segment of d (fallback when the conv kernel cannot fold it)
+int myolo_bnb_fallback(const myolo_conv_desc* d, const myolo_tensor* gout_full, void* stream);
+
 // conv_stream.hip: streaming variant of myolo_conv; -1 = layer does not qualify
-int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 // conv_halo.hip: LDS-staged input tiles for k x k stride-1 convolutions; -1 = layer does not qualify
-int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 int myolo_conv_halo_set(const char* name, int value);
 // conv_wgrad_tile.hip: weight gradient over LDS-staged spatial tiles; -1 = layer does not qualify
 int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, int* out_cop, int* out_cip, int* used_ws);

@@ -39,6 +39,7 @@ class Buf:
         self.t = None
         self.g = None
         self.gwritten = []      # list of (c0, c1) ranges of the gradient twin already written this backward
+        self.gwriters = []      # (c0, c1, op | None) in backward execution order
 
     def alloc(self, device, with_grad):
         if self.t is None:
@@ -105,10 +106,13 @@ class Op:
         pass
 
 
-def claim(tv):
-    """Gradient write planning for tv: returns (accumulate_flag, [zero-fill TV ranges needed first])."""
+def claim(tv, writer=None):
+    """Gradient write planning for tv: returns (accumulate_flag, [zero-fill TV ranges needed first]).  `writer` (an Op whose dgrad
+    launch does the write) is remembered per range: the LAST writer of a BatchNorm layer's output gradient can fold that layer's
+    backward sums into its epilogue (Plan._plan_bn_stats)."""
     b = tv.buf
     lo, hi = tv.coff, tv.coff + tv.c
+    b.gwriters.append((lo, hi, writer))
     covered = [(a, z) for a, z in b.gwritten if a < hi and z > lo]
     if not covered:
         b.gwritten.append((lo, hi))
@@ -210,13 +214,15 @@ class ConvOp(Op):
         self.acc_x = 0
         self.zero_first = []
         self.res_acc = 0
+        self.reduce_by = None        # the op whose dgrad launch produces this layer's BatchNorm-backward sums (else: own reduce launch)
+        self.bnb_targets = []        # [(layer op, c0, c1)]: BatchNorm layers whose output gradient this op's dgrad completes
 
     def plan_bwd(self, plan):
         if self.res is not None and self.res.requires_grad:
             self.res_acc, z = claim(self.res)
             self.zero_first += [(self.res, a, b) for a, b in z]
         if self.x.requires_grad:
-            self.acc_x, z = claim(self.x)
+            self.acc_x, z = claim(self.x, writer=self)
             self.zero_first += [(self.x, a, b) for a, b in z]
 
     def build(self, plan):
@@ -324,8 +330,9 @@ class ConvOp(Op):
             if has_bn:
                 bn = self.bn
                 self.dsum = plan.f32_bwd_zero(L.STAT_COPIES * 2 * self.cout)
-                calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
-                                                              L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
+                if self.reduce_by is None:       # (else the dgrad that wrote the last piece of `gout` already left the sums in dsum)
+                    calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
+                                                                  L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
                 calls.append(Call('myolo_bn_act_bwd_apply', (
                     C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
                     L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
@@ -355,6 +362,14 @@ class ConvOp(Op):
             self.dg = []
             par = []                                     # stride 2: the parity sub-convolutions, fused into one launch when all four exist
             s = self.s
+            bnb = None
+            if self.bnb_targets:                         # BatchNorm layers whose gout this dgrad completes: their reduce pass rides along
+                bnb = (L.BnBwdSeg * len(self.bnb_targets))()
+                for i, (lay, c0, c1) in enumerate(self.bnb_targets):
+                    bnb[i].c0, bnb[i].c1, bnb[i].y = c0, c1, lay.yv.desc()
+                    bnb[i].saved, bnb[i].gamma, bnb[i].beta = lay.saved.data_ptr(), lay.bn.weight.data_ptr(), lay.bn.bias.data_ptr()
+                    bnb[i].dsum, bnb[i].act = lay.dsum.data_ptr(), lay.act
+                self.bnb_arr = bnb
             gx_full = self.x.desc(grad=True)
             es = 2 if dt == torch.float16 else 4
             for py in range(s):
@@ -375,6 +390,8 @@ class ConvOp(Op):
                     g.cin_pad, g.cout_pad, g.wtaps, g.ntaps, g.stride, g.up_shift = cin_pad_t, cout_pad_t, ntaps, len(tdy), 1, 0
                     fill_taps(g, tdy, tdx, tw)
                     g.act, g.accumulate, g.res = L.ACT_NONE, self.acc_x, null_tensor()
+                    if bnb is not None and (s == 1 or not par):
+                        g.nbnb, g.bnb = len(bnb), C.cast(bnb, C.POINTER(L.BnBwdSeg))
                     self.dg.append(g)
                     if s == 2:
                         par.append(g)
@@ -777,8 +794,11 @@ class Plan:
                 off += p.numel()
             for b in self.bufs:
                 b.gwritten = []
+            for b in self.bufs:
+                b.gwriters = []
             for op in reversed(self.ops):
                 op.plan_bwd(self)
+            self._plan_bn_stats()
         self._pg_first_op = {}
         for i, op in enumerate(self.ops):
             self._building = i
@@ -788,6 +808,33 @@ class Plan:
         self.built = True
         if torch.device(self.device).type == 'cuda':     # a CPU-device plan is a dry build (shape/launch-list checks only)
             self.prepare()
+
+    def _plan_bn_stats(self):
+        """fold `bn_act_bwd_reduce` of a Conv+BatchNorm layer into the dgrad launch that writes the LAST contribution to its output
+        gradient (the values are final in that launch's epilogue): possible when that last writer is a convolution's dgrad covering
+        the layer's whole channel range, over the same pixels.  MYOLO_BN_STATS_IN_DGRAD=0 keeps the separate reduce launches."""
+        if os.environ.get('MYOLO_BN_STATS_IN_DGRAD', '1') == '0':
+            return
+        max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
+        for op in self.ops:
+            if not isinstance(op, ConvOp) or op.bn is None or op.det:
+                continue
+            o = op.out
+            if o.n * o.h * o.w * o.c > max_elems:      # big maps: the separate reduce pass streams at 3-4 TB/s, cheaper than 8-byte epilogue loads
+                continue
+            lo, hi = o.coff, o.coff + o.c
+            ws = [(a, z, w) for a, z, w in o.buf.gwriters if a < hi and z > lo]
+            if not ws:
+                continue
+            a, z, w = ws[-1]
+            if not isinstance(w, ConvOp) or w is op or a > lo or z < hi or len(w.bnb_targets) >= 4:
+                continue
+            if (w.x.n, w.x.h, w.x.w) != (o.n, o.h, o.w) or w.x.buf is not o.buf:
+                continue
+            if w.s not in (1, 2) or (w.s == 2 and w.k != 3):
+                continue
+            op.reduce_by = w
+            w.bnb_targets.append((op, lo - w.x.coff, hi - w.x.coff))
 
     def prepare(self):
         st = L.stream_ptr()

@@ -30,21 +30,23 @@ def test_struct_layouts_match_header():
     from multiyolov5_amd import _lib
     assert ctypes.sizeof(_lib.Tensor) == 56
     # myolo_conv_desc: x, y (56 each), w (8), 6 ints, 3 tap tables of 25 ints (-> 500, 8-aligned: +4 pad), scale, shift (8 each),
-    # act + accumulate (8), res (56), stats (8), det_no + reserved (8)
-    assert ctypes.sizeof(_lib.ConvDesc) == 56 * 2 + 8 + 6 * 4 + 3 * 25 * 4 + 4 + 8 + 8 + 8 + 56 + 8 + 8
+    # act + accumulate (8), res (56), stats (8), det_no + nbnb (8), bnb (8)
+    assert ctypes.sizeof(_lib.ConvDesc) == 56 * 2 + 8 + 6 * 4 + 3 * 25 * 4 + 4 + 8 + 8 + 8 + 56 + 8 + 8 + 8
     # the C compiler's view of include/myolo.h (gcc is part of the image): sizes and a few offsets of the descriptor structs
     import shutil, subprocess, tempfile
     if shutil.which('gcc'):
         src = ('#include <stdio.h>\n#include <stddef.h>\n#include "myolo.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(myolo_tensor), '
                'sizeof(myolo_conv_desc), sizeof(myolo_wgrad_desc), offsetof(myolo_conv_desc, scale), offsetof(myolo_conv_desc, res), '
-               'offsetof(myolo_wgrad_desc, ws));return 0;}\n')
+               'offsetof(myolo_wgrad_desc, ws));printf("%zu %zu %zu\\n", sizeof(myolo_bn_bwd_seg), offsetof(myolo_conv_desc, bnb), '
+               'offsetof(myolo_bn_bwd_seg, dsum));return 0;}\n')
         with tempfile.TemporaryDirectory() as td:
             open(os.path.join(td, 'a.c'), 'w').write(src)
             inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
             subprocess.check_call(['gcc', '-I', inc, os.path.join(td, 'a.c'), '-o', os.path.join(td, 'a')])
             sizes = [int(v) for v in subprocess.check_output([os.path.join(td, 'a')]).split()]
         assert sizes == [ctypes.sizeof(_lib.Tensor), ctypes.sizeof(_lib.ConvDesc), ctypes.sizeof(_lib.WgradDesc),
-                         _lib.ConvDesc.scale.offset, _lib.ConvDesc.res.offset, _lib.WgradDesc.ws.offset], sizes
+                         _lib.ConvDesc.scale.offset, _lib.ConvDesc.res.offset, _lib.WgradDesc.ws.offset,
+                         ctypes.sizeof(_lib.BnBwdSeg), _lib.ConvDesc.bnb.offset, _lib.BnBwdSeg.dsum.offset], sizes
     # invalid descriptors are rejected on the host before any launch (no GPU needed)
     d = _lib.ConvDesc()
     assert _lib.lib().myolo_conv(ctypes.byref(d), None) == -22

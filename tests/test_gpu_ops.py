@@ -254,3 +254,81 @@ def test_block_vs_reference_class_golden(name, dtype):
         ye = mod(torch.from_numpy(g[f'{name}/x']).to(DEV, dtype))
     check(f'gold/{name}/eval_out', ye, g[f'{name}/eval_out'], tol, collect=bad)
     assert not bad, '\n'.join(bad)
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.float32], ids=['f16', 'f32'])
+@pytest.mark.parametrize('case', ['1x1', '3x3', '3x3_acc', '1x1_two_segments', '1x1_smallmap', 's2'])
+def test_bn_backward_sums_in_dgrad_epilogue_match_the_reduce_pass(case, dt):
+    """myolo_conv_desc.bnb (the BatchNorm-backward reduce pass folded into the dgrad that completes gout) through the raw C ABI: the sums
+    the conv launch leaves in `dsum` equal what myolo_bn_act_bwd_reduce computes from the gradient that launch stored -- for the
+    streaming, LDS-halo and LDS-tiled kernels, with `accumulate`, with two 32-channel segments (narrower than a 64-wide N tile: the
+    library falls back to its internal reduce launch) and for the fused stride-2 dgrad"""
+    import ctypes as C
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd import engine as E
+    lib = L.lib()
+    torch.manual_seed(0)
+    n, cin, cout = 2, 64, 64
+    k = 1 if case.startswith('1x1') else 3
+    H, W = (8, 16) if case == '1x1_smallmap' else (48, 64)
+    s2 = case == 's2'
+    acc = case == '3x3_acc'
+    es = 2 if dt == torch.float16 else 4
+
+    def td(t, c0=0, c=None):
+        nn, h, w, cc = t.shape
+        return L.Tensor(t.data_ptr() + c0 * es, nn, h, w, cc if c is None else c, h * w * cc, w * cc, cc, L.DT[dt], 0)
+    x = (torch.randn(n, H, W, cin, device=DEV) * 0.3).to(dt)                 # "dy" of the consumer layer
+    wt = torch.randn(cout, cin, k, k, device=DEV) * (1.0 / (cin * k * k) ** 0.5)
+    cin_pad, cout_pad = E.rup(cin, E.KC[dt]), E.rup(cout, 32)
+    wp = torch.zeros(cout_pad, k * k, cin_pad, device=DEV, dtype=dt)
+    L.check(lib.myolo_pack_weight(L.ptr(wt), L.F32, cout, cin, k, k, L.ptr(wp), L.DT[dt], cout_pad, cin_pad, 0, None, L.stream_ptr()))
+    Ho, Wo = (2 * H, 2 * W) if s2 else (H, W)
+    gx = (torch.randn(n, Ho, Wo, cout, device=DEV) * 0.1).to(dt) if acc else torch.zeros(n, Ho, Wo, cout, device=DEV, dtype=dt)
+    segs = [(0, 32), (32, 64)] if case == '1x1_two_segments' else [(0, 64)]
+    yraw = [(torch.randn(n, Ho, Wo, c1 - c0, device=DEV)).to(dt) for c0, c1 in segs]
+    saved = [torch.cat([torch.randn(c1 - c0, device=DEV) * 0.2, torch.rand(c1 - c0, device=DEV) + 0.5]) for c0, c1 in segs]
+    gam = [torch.rand(c1 - c0, device=DEV) + 0.5 for c0, c1 in segs]
+    bet = [torch.randn(c1 - c0, device=DEV) * 0.1 for c0, c1 in segs]
+    dsum = [torch.zeros(L.STAT_COPIES * 2 * (c1 - c0), device=DEV) for c0, c1 in segs]
+    bnb = (L.BnBwdSeg * len(segs))()
+    for i, (c0, c1) in enumerate(segs):
+        bnb[i].c0, bnb[i].c1, bnb[i].y = c0, c1, td(yraw[i])
+        bnb[i].saved, bnb[i].gamma, bnb[i].beta, bnb[i].dsum, bnb[i].act = saved[i].data_ptr(), gam[i].data_ptr(), bet[i].data_ptr(), \
+            dsum[i].data_ptr(), L.ACT_SILU
+
+    def desc(ydesc, taps):
+        d = L.ConvDesc()
+        d.x, d.y, d.w = td(x), ydesc, wp.data_ptr()
+        d.cin_pad, d.cout_pad, d.wtaps, d.ntaps, d.stride, d.up_shift = cin_pad, cout_pad, k * k, len(taps[0]), 1, 0
+        E.fill_taps(d, *taps)
+        d.res, d.act, d.accumulate = E.null_tensor(), L.ACT_NONE, int(acc)
+        return d
+    keep = []
+    if s2:
+        full = td(gx)
+        par = []
+        for py in range(2):
+            for px in range(2):
+                taps = E.taps_dgrad(3, 1, 1, 2, py, px)
+                sub = L.Tensor(full.ptr + (py * full.sh + px * full.sw) * es, n, (Ho - py + 1) // 2, (Wo - px + 1) // 2, cout,
+                               full.sn, full.sh * 2, full.sw * 2, full.dtype, 0)
+                par.append(desc(sub, taps))
+        par[0].nbnb, par[0].bnb = len(segs), C.cast(bnb, C.POINTER(L.BnBwdSeg))
+        arr = (C.POINTER(L.ConvDesc) * 4)(*[C.pointer(g) for g in par])
+        keep += [par, arr]
+        L.check(lib.myolo_conv_dgrad_s2(arr, 4, L.stream_ptr()), 'myolo_conv_dgrad_s2')
+    else:
+        d = desc(td(gx), E.taps_fwd(k, 1, k // 2))
+        d.nbnb, d.bnb = len(segs), C.cast(bnb, C.POINTER(L.BnBwdSeg))
+        L.check(lib.myolo_conv(C.byref(d), L.stream_ptr()), 'myolo_conv')
+    torch.cuda.synchronize()
+    for i, (c0, c1) in enumerate(segs):
+        ref = torch.zeros_like(dsum[i])
+        gd, yd = td(gx, c0, c1 - c0), td(yraw[i])
+        L.check(lib.myolo_bn_act_bwd_reduce(C.byref(gd), C.byref(yd), L.ptr(saved[i]), L.ptr(gam[i]), L.ptr(bet[i]), L.ACT_SILU, L.ptr(ref),
+                                            L.stream_ptr()))
+        got = dsum[i].view(L.STAT_COPIES, 2, c1 - c0).sum(0)
+        want = ref.view(L.STAT_COPIES, 2, c1 - c0).sum(0)
+        assert float(want.abs().max()) > 1e-3
+        check(f'bnb/{case}/{dt}/seg{i}', got, want, 2e-4)
