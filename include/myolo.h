@@ -140,7 +140,9 @@ typedef struct myolo_wgrad_desc {
   int32_t tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
   int32_t ksplit;            /* 0 = auto */
   int32_t cout, cin;         /* real weight dims when dy.c / x.c are channel-padded views (0: use dy.c / x.c) */
-  int32_t reserved;
+  int32_t wg_hint;           /* 0: library default; > 0: target number of workgroups for this launch (split-K = wg_hint / output blocks).
+                                The caller knows how much dependent work is still queued behind this gradient: few long-lived
+                                workgroups while there is, many for the last layers of a backward pass (their latency is exposed) */
   float*  ws;                /* optional split-K workspace (16-byte aligned): partial tiles are stored there and summed by a
                                 second launch instead of fp32 atomics into dw; NULL: atomics */
   int64_t ws_bytes;

@@ -6,7 +6,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libmyolo.so')
+LIB_PATH = os.environ.get('MYOLO_LIB') or os.path.join(_HERE, 'lib', 'libmyolo.so')      # MYOLO_LIB: A/B a differently built library
 
 F32, F16, U8, I64 = 0, 1, 2, 3
 ACT_NONE, ACT_SILU, ACT_SIGMOID = 0, 1, 2
@@ -39,7 +39,7 @@ class WgradDesc(C.Structure):
     _fields_ = [('x', Tensor), ('dy', Tensor), ('dw', C.c_void_p), ('db', C.c_void_p),
                 ('ntaps', C.c_int32), ('stride', C.c_int32), ('up_shift', C.c_int32),
                 ('tap_dy', C.c_int32 * MAX_TAPS), ('tap_dx', C.c_int32 * MAX_TAPS),
-                ('ksplit', C.c_int32), ('cout', C.c_int32), ('cin', C.c_int32), ('reserved', C.c_int32),
+                ('ksplit', C.c_int32), ('cout', C.c_int32), ('cin', C.c_int32), ('wg_hint', C.c_int32),
                 ('ws', C.c_void_p), ('ws_bytes', C.c_int64)]
 
 

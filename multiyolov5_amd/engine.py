@@ -22,6 +22,9 @@ BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
 GRAPH_BWD = os.environ.get('MYOLO_GRAPH_BWD', 'seg')
+WGRAD_WG = int(os.environ.get('MYOLO_WGRAD_WG_HINT', '0'))                 # 0: library default (128)
+WGRAD_WG_TAIL = int(os.environ.get('MYOLO_WGRAD_WG_TAIL', '0'))
+WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
 
 SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
@@ -406,6 +409,10 @@ class ConvOp(Op):
         wd.dw = plan.pgrad(self.weight).data_ptr()
         wd.db = plan.pgrad(self.bias).data_ptr() if self.bias is not None else None
         wd.ntaps, wd.stride, wd.up_shift, wd.ksplit, wd.cout, wd.cin = self.k * self.k, self.s, 0, 0, self.cout, self.cin
+        # weight gradients run beside the dgrad / BatchNorm chain: few long-lived workgroups (less CU / LDS stolen from the chain) while
+        # plenty of the backward is still to come, many for the first layers of the network (= the END of the backward: exposed tail)
+        pos = getattr(plan, '_building', 0) / max(len(plan.ops), 1)
+        wd.wg_hint = WGRAD_WG_TAIL if pos < WGRAD_TAIL_FRAC else WGRAD_WG
         ws = plan.wgrad_workspace()
         wd.ws, wd.ws_bytes = ws.data_ptr(), ws.numel() * 4
         tdy, tdx, _ = taps_fwd(self.k, self.d, self.pad)
@@ -674,7 +681,7 @@ class Plan:
         self.det_grads = []
         self.params, self._pgrad = [], {}
         self._pack_jobs, self._pack_call = [], None
-        self.use_side_stream = True
+        self.use_side_stream = os.environ.get('MYOLO_NO_SIDE', '0') != '1'
         self.built = False
 
     # ---- graph construction -------------------------------------------------------------------------
@@ -813,8 +820,8 @@ class Plan:
         """fold `bn_act_bwd_reduce` of a Conv+BatchNorm layer into the dgrad launch that writes the LAST contribution to its output
         gradient (the values are final in that launch's epilogue): possible when that last writer is a convolution's dgrad covering
         the layer's whole channel range, over the same pixels.  MYOLO_BN_STATS_IN_DGRAD=0 keeps the separate reduce launches."""
-        if os.environ.get('MYOLO_BN_STATS_IN_DGRAD', '1') == '0':
-            return
+        if os.environ.get('MYOLO_BN_STATS_IN_DGRAD', '0') == '0':      # opt-in: measured neutral on the step (10.34 vs 10.41 ms) while it moves
+            return                                                     # ~0.4 ms of reduce work INTO the conv launches (conv roofline 0.145 -> 0.130)
         max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
         for op in self.ops:
             if not isinstance(op, ConvOp) or op.bn is None or op.det:
@@ -1017,9 +1024,12 @@ class Plan:
             side.wait_stream(main)                            # the zero fills above
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
         st = L.stream_ptr()
+        skip_side = os.environ.get('MYOLO_DBG_SKIP_WGRAD', '0') == '1'       # profiling only: how long is the step WITHOUT the weight gradients?
         for hi, lo, ready in self._bwd_segments(reducer):
             for i in range(hi - 1, lo - 1, -1):
                 for c in self.ops[i].bwd_calls:
+                    if c.side and skip_side:
+                        continue
                     if c.side and side is not None:
                         ev = torch.cuda.Event()
                         ev.record(main)

@@ -1,8 +1,8 @@
-TAG=r2a
+TAG=${1:-r2b}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_gpu_postproc.py -m gpu -q --timeout 600 2>&1 | tail -3
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 2>&1 | tail -3
 timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_$TAG.log 2>&1
 tail -1 gpurun_out/bench_$TAG.log | cut -c1-3000
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o train -- python bench.py --steps 5 --warmup 2 --no-kernel-timing --no-infer --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
