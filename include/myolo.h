@@ -65,8 +65,9 @@ int myolo_pack_weight(const void* w_oihw, int src_dtype, int cout, int cin, int 
                       void* dst, int dst_dtype, int rows_pad, int cols_pad, int transpose,
                       const float* row_scale, void* stream);
 
-/* all weight packs of a plan in one launch.  jobs: device int64 [njobs][10] = {src, dst, cout, cin, ntaps, rows_pad,
- * cols_pad, transpose, src_dtype, dst_dtype}; chunks: device int32 [nchunks][2] = {job, first packed element}. */
+/* all weight packs of a plan in one launch.  jobs: device int64 [njobs][12] = {src, dst, cout, cin, ntaps, rows_pad,
+ * cols_pad, transpose, src_dtype, dst_dtype, src2, cout2}; chunks: device int32 [nchunks][2] = {job, first packed element}.
+ * src2 (0 = none): a second OIHW tensor [cout2][cin][taps] of the same dtype stacked behind src along cout. */
 int myolo_pack_weights_mt(const int64_t* jobs, const int32_t* chunks, int nchunks, int chunk_elems, void* stream);
 
 /* Focus slicing + cat (common.py:550) fused with the image cast: NCHW [n,3,h,w] (f32|f16|u8, value*mul)
@@ -171,6 +172,33 @@ int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tensor* y, cons
                            float* dgamma, float* dbeta, const myolo_tensor* dy,
                            const myolo_tensor* gres, int gres_accumulate, void* stream);
 
+/* The same three passes over the output of ONE convolution whose channels [0, c_split) and [c_split, c) belong to two BatchNorm
+ * modules (C3.cv2 | C3.cv1 run as one launch on their common input, common.py:137): the first parameter set (gamma, beta, running_*,
+ * nbt, dgamma, dbeta) serves the low channels, `split` the high ones; stats / saved / dsum stay one array over all c channels.
+ * split == NULL: identical to the plain entry points. */
+typedef struct myolo_bn_split {
+  int32_t c_split;               /* multiple of the 16-byte vector */
+  int32_t reserved;
+  const float* gamma2;
+  const float* beta2;
+  float* running_mean2;
+  float* running_var2;
+  int64_t* nbt2;
+  float* dgamma2;
+  float* dbeta2;
+} myolo_bn_split;
+int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                           float* saved, float eps, float momentum, int act,
+                           const myolo_tensor* res, const myolo_tensor* out, const myolo_bn_split* split, void* stream);
+int myolo_bn_act_bwd_reduce_split(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                  const float* gamma, const float* beta, int act, float* dsum,
+                                  const myolo_bn_split* split, void* stream);
+int myolo_bn_act_bwd_apply_split(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                 const float* gamma, const float* beta, int act, const float* dsum,
+                                 float* dgamma, float* dbeta, const myolo_tensor* dy,
+                                 const myolo_tensor* gres, int gres_accumulate, const myolo_bn_split* split, void* stream);
+
 /* ---- pooling / resampling / glue -------------------------------------------------------------- */
 /* SPP: three stride-1 max pools k=5,9,13, -inf padding (common.py:170).  idx (optional, u8 [3][n,h,w,c])
  * records the first-max window offset for backward. */
@@ -251,6 +279,16 @@ int myolo_seg_ce_fwd(const void* logits, int dtype, int n, int c, int h, int w, 
 int myolo_seg_ce_fwd_grad(const void* logits, void* grad, int dtype, int n, int c, int h, int w, const int64_t* target,
                           int ignore_index, double* acc, float* loss, void* stream);
 int myolo_seg_ce_scale(const double* acc, const float* gout, float* scale, void* stream);
+/* The head's final nn.Upsample (bilinear, align_corners=True, yolo.py:163) + the mean cross entropy + its gradient + the transposed
+ * upsample in ONE pass over the LOW-resolution class logits `low` ([n,h,w,19] view): the [N,19,H,W] logits are recomputed per pixel
+ * in registers (rounded to `low`'s dtype, like the tensor the reference's loss reads) and neither they nor their gradient touch HBM.
+ * acc / loss as myolo_seg_ce_fwd; glow32: dense fp32 [n,h,w,19], zeroed here, receives d(sum of pixel losses)/d(low) -- the
+ * classifier's gradient up to the scalar gout/acc[1] (myolo_seg_ce_scale), applied by myolo_seg_lowgrad_apply:
+ *   glow (+)= glow32 * scale[0]   (glow: the [n,h,w,19] gradient view; scale optional).
+ * MYOLO_EINVAL for a class count other than 19 (callers take myolo_seg_upsample_fwd + myolo_seg_ce_fwd_grad instead). */
+int myolo_seg_upce_fwd_grad(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, double* acc,
+                            float* loss, float* glow32, void* stream);
+int myolo_seg_lowgrad_apply(const float* glow32, const myolo_tensor* glow, int accumulate, const float* scale, void* stream);
 /* OhemCELoss.forward_once (utils/loss.py:321-328) on the per-pixel losses: mean of losses > thresh, or, if fewer than
  * n_min = acc[1]//16 qualify, mean of the n_min largest (device radix select, no host sync).
  * st: double[5] scratch, ws: uint32[2052] scratch, loss: float[1], sel: float[4] selection record for the backward. */

@@ -26,6 +26,12 @@ class BnBwdSeg(C.Structure):
                 ('dsum', C.c_void_p), ('act', C.c_int32), ('reserved', C.c_int32)]
 
 
+class BnSplit(C.Structure):
+    _fields_ = [('c_split', C.c_int32), ('reserved', C.c_int32), ('gamma2', C.c_void_p), ('beta2', C.c_void_p),
+                ('running_mean2', C.c_void_p), ('running_var2', C.c_void_p), ('nbt2', C.c_void_p), ('dgamma2', C.c_void_p),
+                ('dbeta2', C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('x', Tensor), ('y', Tensor), ('w', C.c_void_p),
                 ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('wtaps', C.c_int32),
@@ -78,6 +84,9 @@ _PROTOS = {
     'myolo_bn_act_fwd': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, P]),
     'myolo_bn_act_bwd_reduce': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P]),
     'myolo_bn_act_bwd_apply': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P, P, TP, TP, C.c_int, P]),
+    'myolo_bn_act_fwd_split': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, C.POINTER(BnSplit), P]),
+    'myolo_bn_act_bwd_reduce_split': (C.c_int, [TP, TP, P, P, P, C.c_int, P, C.POINTER(BnSplit), P]),
+    'myolo_bn_act_bwd_apply_split': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P, P, TP, TP, C.c_int, C.POINTER(BnSplit), P]),
     'myolo_spp_pool_fwd': (C.c_int, [TP, TP, TP, TP, P, P]),
     'myolo_spp_pool_bwd': (C.c_int, [TP, TP, TP, P, TP, C.c_int, P]),
     'myolo_copy_up_fwd': (C.c_int, [TP, TP, C.c_int, P]),
@@ -97,6 +106,8 @@ _PROTOS = {
     'myolo_dropout_bwd': (C.c_int, [TP, P, TP, C.c_float, C.c_int, P]),
     'myolo_seg_upsample_fwd': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, P]),
     'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P, P]),
+    'myolo_seg_upce_fwd_grad': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
+    'myolo_seg_lowgrad_apply': (C.c_int, [P, TP, C.c_int, P, P]),
     'myolo_seg_ce_fwd_grad': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
     'myolo_seg_ce_scale': (C.c_int, [P, P, P, P]),
     'myolo_seg_argmax': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, P]),

@@ -7,6 +7,12 @@
 
 namespace {
 
+// second parameter set for channels >= cs (two BatchNorm modules normalising the halves of ONE merged convolution: C3's cv2 | cv1)
+struct BnSplit {
+  int cs;
+  const float* gamma2; const float* beta2; float* rm2; float* rv2; int64_t* nbt2; float* dgamma2; float* dbeta2;
+};
+
 struct PixDec {  // linear pixel -> (n,y,x) of a view
   int hw, w;
   __device__ PixDec(const myolo_tensor& t) : hw(t.h * t.w), w(t.w) {}
@@ -35,7 +41,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* rm, float* rv, int64_t* nbt, float* saved, float eps,
-                                                         float mom, int act, myolo_tensor res, myolo_tensor out, int G, int PPB) {
+                                                         float mom, int act, myolo_tensor res, myolo_tensor out, int G, int PPB,
+                                                         BnSplit sp) {
   constexpr int SEG = ET<T>::SEG;
   extern __shared__ float tab[];  // [2*C]: scale, shift
   const int C = y.c;
@@ -55,14 +62,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
       const float mean = (float)meand;
       float var = vard > 0.0 ? (float)vard : 0.f;
       const float invstd = rsqrtf(var + eps);
-      sc = gamma[c] * invstd;
-      sh = beta[c] - mean * sc;
+      const bool lo = c < sp.cs;
+      const int cc = lo ? c : c - sp.cs;
+      sc = (lo ? gamma : sp.gamma2)[cc] * invstd;
+      sh = (lo ? beta : sp.beta2)[cc] - mean * sc;
       if (blockIdx.x == 0) {
         if (saved) { saved[c] = mean; saved[C + c] = invstd; }
-        if (rm) {
-          rm[c] = (1.f - mom) * rm[c] + mom * mean;
+        float* rmp = lo ? rm : sp.rm2; float* rvp = lo ? rv : sp.rv2;
+        if (rmp) {
+          rmp[cc] = (1.f - mom) * rmp[cc] + mom * mean;
           const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
-          rv[c] = (1.f - mom) * rv[c] + mom * unb;
+          rvp[cc] = (1.f - mom) * rvp[cc] + mom * unb;
         }
       }
     }
@@ -70,6 +80,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
     tab[C + c] = sh;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && gamma) *nbt += 1;
+  if (blockIdx.x == 0 && threadIdx.x == 1 && sp.nbt2 && gamma && sp.cs < C) *sp.nbt2 += 1;
   __syncthreads();
   const int cg = threadIdx.x % G, pl = threadIdx.x / G;
   float sc[SEG], sh[SEG];
@@ -108,7 +119,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
                                                                 const float* __restrict__ saved,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, int act, float* dsum,
-                                                                int G, int PPB) {
+                                                                int G, int PPB, BnSplit sp) {
   constexpr int SEG = ET<T>::SEG;
   extern __shared__ float red[];  // [PPB][G*SEG*2]
   const int C = y.c;
@@ -119,7 +130,9 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
   for (int i = 0; i < SEG; ++i) {
     const int c = cg * SEG + i;
     mean[i] = saved[c]; istd[i] = saved[C + c];
-    sc[i] = gamma[c] * istd[i]; sh[i] = beta[c] - mean[i] * sc[i];
+    const bool lo = c < sp.cs;
+    const int cc = lo ? c : c - sp.cs;
+    sc[i] = (lo ? gamma : sp.gamma2)[cc] * istd[i]; sh[i] = (lo ? beta : sp.beta2)[cc] - mean[i] * sc[i];
     s0[i] = 0.f; s1[i] = 0.f;
   }
   const PixDec pd(y);
@@ -161,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
                                                                const float* __restrict__ beta, int act,
                                                                const float* __restrict__ dsum, float* dgamma,
                                                                float* dbeta, myolo_tensor dy, myolo_tensor gres,
-                                                               int gres_acc, int G, int PPB) {
+                                                               int gres_acc, int G, int PPB, BnSplit sp) {
   constexpr int SEG = ET<T>::SEG;
   // dx = sc*(dz - k0 - xhat*k1), dz = gout*act'(y*sc + sh), xhat = (y - mean)*invstd, k = dsum/M
   //    = sc*dz + cb*y + cd   with cb = -sc*k1*invstd, cd = -sc*k0 - cb*mean
@@ -171,16 +184,19 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     if (gamma) {
       const float mean = saved[c], istd = saved[C + c];
-      const float sc = gamma[c] * istd;
+      const bool lo = c < sp.cs;
+      const int cc = lo ? c : c - sp.cs;
+      const float sc = (lo ? gamma : sp.gamma2)[cc] * istd;
       float d0 = 0.f, d1 = 0.f;
 #pragma unroll
       for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { d0 += dsum[k * 2 * C + c]; d1 += dsum[k * 2 * C + C + c]; }
       const float k0 = d0 / (float)M, k1 = d1 / (float)M;
       const float cb = -sc * k1 * istd;
-      tab[c] = sc; tab[C + c] = beta[c] - mean * sc; tab[2 * C + c] = cb; tab[3 * C + c] = -sc * k0 - cb * mean;
+      tab[c] = sc; tab[C + c] = (lo ? beta : sp.beta2)[cc] - mean * sc; tab[2 * C + c] = cb; tab[3 * C + c] = -sc * k0 - cb * mean;
       if (blockIdx.x == 0) {
-        if (dgamma) dgamma[c] += d1;
-        if (dbeta) dbeta[c] += d0;
+        float* dgp = lo ? dgamma : sp.dgamma2; float* dbp = lo ? dbeta : sp.dbeta2;
+        if (dgp) dgp[cc] += d1;
+        if (dbp) dbp[cc] += d0;
       }
     } else {
       tab[c] = 1.f; tab[C + c] = 0.f; tab[2 * C + c] = 0.f; tab[3 * C + c] = 0.f;
@@ -238,14 +254,33 @@ inline bool vec_ok(const myolo_tensor* t) {
          t->sh % seg == 0 && t->sn % seg == 0 && ((uintptr_t)t->ptr & 15) == 0;
 }
 
+// host view of myolo_bn_split -> kernel argument (no split: cs = C, every channel takes the first parameter set)
+inline bool split_ok(const myolo_bn_split* sp, int C, int seg, bool need_params) {
+  if (!sp) return true;
+  if (sp->c_split <= 0 || sp->c_split >= C || sp->c_split % seg) return false;
+  return !need_params || (sp->gamma2 && sp->beta2);
+}
+inline BnSplit mk_split(const myolo_bn_split* sp, int C) {
+  BnSplit b{};
+  b.cs = C;
+  if (sp) {
+    b.cs = sp->c_split;
+    b.gamma2 = sp->gamma2; b.beta2 = sp->beta2; b.rm2 = sp->running_mean2; b.rv2 = sp->running_var2; b.nbt2 = sp->nbt2;
+    b.dgamma2 = sp->dgamma2; b.dbeta2 = sp->dbeta2;
+  }
+  return b;
+}
+
 }  // namespace
 
-extern "C" int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
+extern "C" int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
                                 float* running_mean, float* running_var, int64_t* nbt, float* saved, float eps,
                                 float momentum, int act, const myolo_tensor* res, const myolo_tensor* out,
-                                void* stream) {
+                                const myolo_bn_split* split, void* stream) {
   if (!y || !out || !vec_ok(y) || !vec_ok(out) || !same_shape(y, out)) return MYOLO_EINVAL;
   if (gamma && (!stats || !beta)) return MYOLO_EINVAL;
+  if (split && (!gamma || !split_ok(split, y->c, y->dtype == MYOLO_F16 ? 8 : 4, true))) return MYOLO_EINVAL;
+  const BnSplit bs = mk_split(split, y->c);
   myolo_tensor r{};
   if (res && res->ptr) { if (!vec_ok(res) || !same_shape(res, y)) return MYOLO_EINVAL; r = *res; }
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
@@ -259,18 +294,29 @@ extern "C" int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
     hipLaunchKernelGGL(bn_act_fwd_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
-                       running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB);
+                       running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB, bs);
   else
     hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
-                       running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB);
+                       running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB, bs);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
-                                       const float* gamma, const float* beta, int act, float* dsum, void* stream) {
+extern "C" int myolo_bn_act_fwd(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, int64_t* nbt, float* saved, float eps,
+                                float momentum, int act, const myolo_tensor* res, const myolo_tensor* out,
+                                void* stream) {
+  return myolo_bn_act_fwd_split(y, stats, gamma, beta, running_mean, running_var, nbt, saved, eps, momentum, act, res, out,
+                                nullptr, stream);
+}
+
+extern "C" int myolo_bn_act_bwd_reduce_split(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                             const float* gamma, const float* beta, int act, float* dsum,
+                                             const myolo_bn_split* split, void* stream) {
   if (!gout || !y || !vec_ok(gout) || !vec_ok(y) || !same_shape(gout, y) || !saved || !gamma || !beta || !dsum)
     return MYOLO_EINVAL;
+  if (!split_ok(split, y->c, y->dtype == MYOLO_F16 ? 8 : 4, true)) return MYOLO_EINVAL;
+  const BnSplit bs = mk_split(split, y->c);
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
   const int G = y->c / seg;
   if (G > 256) return MYOLO_EINVAL;
@@ -283,21 +329,28 @@ extern "C" int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_ten
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
-                       beta, act, dsum, G, PPB);
+                       beta, act, dsum, G, PPB, bs);
   else
     hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
-                       beta, act, dsum, G, PPB);
+                       beta, act, dsum, G, PPB, bs);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
 
-extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
-                                      const float* gamma, const float* beta, int act, const float* dsum,
-                                      float* dgamma, float* dbeta, const myolo_tensor* dy, const myolo_tensor* gres,
-                                      int gres_accumulate, void* stream) {
+extern "C" int myolo_bn_act_bwd_reduce(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                       const float* gamma, const float* beta, int act, float* dsum, void* stream) {
+  return myolo_bn_act_bwd_reduce_split(gout, y, saved, gamma, beta, act, dsum, nullptr, stream);
+}
+
+extern "C" int myolo_bn_act_bwd_apply_split(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                            const float* gamma, const float* beta, int act, const float* dsum,
+                                            float* dgamma, float* dbeta, const myolo_tensor* dy, const myolo_tensor* gres,
+                                            int gres_accumulate, const myolo_bn_split* split, void* stream) {
   if (!gout || !y || !dy || !vec_ok(gout) || !vec_ok(y) || !vec_ok(dy) || !same_shape(gout, y) || !same_shape(dy, y))
     return MYOLO_EINVAL;
   if (gamma && (!saved || !beta || !dsum)) return MYOLO_EINVAL;
+  if (split && (!gamma || !split_ok(split, y->c, y->dtype == MYOLO_F16 ? 8 : 4, true))) return MYOLO_EINVAL;
+  const BnSplit bs = mk_split(split, y->c);
   myolo_tensor r{};
   if (gres && gres->ptr) { if (!vec_ok(gres) || !same_shape(gres, y)) return MYOLO_EINVAL; r = *gres; }
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
@@ -310,12 +363,20 @@ extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tens
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
-                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB);
+                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB, bs);
   else
     hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
-                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB);
+                       act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB, bs);
   MYOLO_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tensor* y, const float* saved,
+                                      const float* gamma, const float* beta, int act, const float* dsum,
+                                      float* dgamma, float* dbeta, const myolo_tensor* dy, const myolo_tensor* gres,
+                                      int gres_accumulate, void* stream) {
+  return myolo_bn_act_bwd_apply_split(gout, y, saved, gamma, beta, act, dsum, dgamma, dbeta, dy, gres, gres_accumulate, nullptr,
+                                      stream);
 }
 
 // fallback of myolo_conv_desc.bnb: one reduce launch per segment over the gradient the conv launch(es) just stored

@@ -373,6 +373,194 @@ inline bool strided_ok(const void* p, int dt) { return p && (dt == MYOLO_F16 || 
 
 }  // namespace
 
+namespace {
+
+// ---- K15: x`scale` bilinear upsample (align_corners=True) + mean cross entropy + its gradient + the transposed upsample in ONE pass over
+// the LOW-resolution class logits (yolo.py:163 nn.Upsample + loss.py:236-237).  Unfused, the full-resolution logits are read back
+// (38 B/pixel), softmax - onehot is written (38 B/pixel) and read again by the transposed upsample: ~1 GB per step at 16x512x1024.
+// Here a workgroup owns 256 consecutive full-resolution columns x TY rows of one image; every thread walks its column downwards:
+//   logits(y, x) = (1-ly)*top + ly*bot, top/bot = the two low rows around y interpolated in x ONCE per low row (registers),
+//   rounded to the storage type like the materialised tensor the reference's loss reads; softmax / loss / gradient in registers;
+//   the gradient is folded into the two low rows ((1-ly), ly) in registers; when the walk leaves a low row its per-column sums go
+//   through LDS, each (low x, class) pair folds its <= 2/sx columns and adds the result to the fp32 low-res gradient (one global
+//   atomic per pair, <= 4 workgroups touch an address).  HBM traffic: the int64 targets (8 B/pixel) + the low-res maps.
+__device__ __forceinline__ void up_out_range(int i, int in, int out, float s, int& lo, int& hi) {
+  if (out == 1 || in == 1 || s <= 0.f) { lo = 0; hi = out - 1; return; }
+  lo = (int)floorf(((float)i - 1.f) / s) - 1; hi = (int)ceilf(((float)i + 1.f) / s) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+template <typename T, int CC>
+__global__ __launch_bounds__(256) void seg_upce_kernel(myolo_tensor low, int H, int W, float sy, float sx, int TY, const int64_t* tgt,
+                                                       int ignore, double* acc, float* g32) {
+  constexpr int C = CC;
+  __shared__ float fb[256 * C];
+  __shared__ double shd[4];
+  const int strips = (W + 255) / 256, nyb = (H + TY - 1) / TY;
+  int b = blockIdx.x;
+  const int xs = b % strips; b /= strips;
+  const int yb = b % nyb; const int n = b / nyb;
+  const int xbase = xs * 256;
+  const int x = xbase + threadIdx.x;
+  const bool live = x < W;
+  const int xc = live ? x : W - 1;
+  const float fx = sx * (float)xc;
+  const int x0 = (int)fx, x1 = x0 + 1 < low.w ? x0 + 1 : low.w - 1;
+  const float lx = fx - (float)x0;
+  const int xend = xbase + 255 < W - 1 ? xbase + 255 : W - 1;
+  const int lxa = (int)(sx * (float)xbase);
+  int lxz = (int)(sx * (float)xend) + 1;
+  if (lxz > low.w - 1) lxz = low.w - 1;
+  const int nlx = lxz - lxa + 1;
+  const int ya = yb * TY, yz = (ya + TY < H ? ya + TY : H) - 1;
+  const T* lp = reinterpret_cast<const T*>(low.ptr) + (int64_t)n * low.sn;
+  float top[C], bot[C], at[C], ab[C];
+  auto row_interp = [&](int r, float* dst) {
+    const T* p0 = lp + (int64_t)r * low.sh + (int64_t)x0 * low.sw;
+    const T* p1 = lp + (int64_t)r * low.sh + (int64_t)x1 * low.sw;
+#pragma unroll
+    for (int c = 0; c < C; ++c) dst[c] = (1.f - lx) * (float)p0[c] + lx * (float)p1[c];
+  };
+  // per-column sums `a` of low row r -> fp32 low-res gradient
+  auto flush = [&](int r, const float* a) {
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C; ++c) fb[threadIdx.x * C + c] = live ? a[c] : 0.f;
+    __syncthreads();
+    for (int p = threadIdx.x; p < nlx * C; p += 256) {
+      const int li = p / C, c = p - li * C;
+      const int ix = lxa + li;
+      int pxlo, pxhi;
+      up_out_range(ix, low.w, W, sx, pxlo, pxhi);
+      if (pxlo < xbase) pxlo = xbase;
+      if (pxhi > xend) pxhi = xend;
+      float sacc = 0.f;
+      for (int ox = pxlo; ox <= pxhi; ++ox) {
+        const float gx = sx * (float)ox; const int q0 = (int)gx; const int q1 = q0 + 1 < low.w ? q0 + 1 : low.w - 1;
+        const float l = gx - (float)q0;
+        float wx = 0.f;
+        if (q0 == ix) wx += 1.f - l;
+        if (q1 == ix) wx += l;
+        sacc += wx * fb[(ox - xbase) * C + c];
+      }
+      if (sacc != 0.f) atomicAdd(g32 + (((int64_t)n * low.h + r) * low.w + ix) * C + c, sacc);
+    }
+  };
+  int j = (int)(sy * (float)ya);
+  row_interp(j, top);
+  row_interp(j + 1 < low.h ? j + 1 : low.h - 1, bot);
+#pragma unroll
+  for (int c = 0; c < C; ++c) { at[c] = 0.f; ab[c] = 0.f; }
+  double lsum = 0.0, lcnt = 0.0;
+  const int64_t* tp = tgt + ((int64_t)n * H + ya) * W + xc;
+  int64_t tnext = live ? tp[0] : (int64_t)ignore;
+  for (int y = ya; y <= yz; ++y) {
+    const int64_t t = tnext;
+    if (y < yz && live) tnext = tp[(int64_t)(y + 1 - ya) * W];          // next row's target in flight
+    const float fy = sy * (float)y;
+    const int y0 = (int)fy;
+    const float ly = fy - (float)y0;
+    while (j != y0) {                                   // uniform over the workgroup: the walk left low row j
+      flush(j, at);
+      ++j;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { at[c] = ab[c]; ab[c] = 0.f; top[c] = bot[c]; }
+      row_interp(j + 1 < low.h ? j + 1 : low.h - 1, bot);
+    }
+    if (t != ignore) {
+      float v[C];
+      float m = -INFINITY;
+#pragma unroll
+      for (int c = 0; c < C; ++c) { v[c] = (float)(T)((1.f - ly) * top[c] + ly * bot[c]); m = fmaxf(m, v[c]); }
+      const float mb = -m * LOG2E;
+      float sm = 0.f, xt = 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        if (c == (int)t) xt = v[c];
+        v[c] = __builtin_amdgcn_exp2f(fmaf(v[c], LOG2E, mb));
+        sm += v[c];
+      }
+      lsum += (double)((m + __builtin_amdgcn_logf(sm) * LN2) - xt);
+      lcnt += 1.0;
+      const float inv = __builtin_amdgcn_rcpf(sm);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float g = v[c] * inv - (c == (int)t ? 1.f : 0.f);
+        at[c] += (1.f - ly) * g;
+        ab[c] += ly * g;
+      }
+    }
+  }
+  flush(j, at);
+  flush(j + 1 < low.h ? j + 1 : low.h - 1, ab);
+  const double bs = block_sum256(lsum, shd);
+  const double bc = block_sum256(lcnt, shd);
+  if (threadIdx.x == 0) { atomicAdd(acc + 0, bs); atomicAdd(acc + 1, bc); }
+}
+
+// low-res gradient of the head's classifier: glow (+)= scale * g32   (scale = gout / n_valid, myolo_seg_ce_scale)
+template <typename T>
+__global__ __launch_bounds__(256) void seg_lowgrad_apply_kernel(const float* __restrict__ g32, myolo_tensor glow, int C, int acc,
+                                                                const float* scale) {
+  const float gs = scale ? scale[0] : 1.f;
+  const int64_t total = (int64_t)glow.n * glow.h * glow.w * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = i;
+    const int c = (int)(r % C); r /= C;
+    const int ix = (int)(r % glow.w); r /= glow.w;
+    const int iy = (int)(r % glow.h); const int n = (int)(r / glow.h);
+    T* o = reinterpret_cast<T*>(glow.ptr) + (int64_t)n * glow.sn + (int64_t)iy * glow.sh + (int64_t)ix * glow.sw + c;
+    float v = g32[i] * gs;
+    if (acc) v += (float)*o;
+    *o = (T)v;
+  }
+}
+
+}  // namespace
+
+extern "C" int myolo_seg_upce_fwd_grad(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, double* acc,
+                                       float* loss, float* glow32, void* stream) {
+  if (!low || !low->ptr || !target || !acc || !glow32 || H < 1 || W < 1) return MYOLO_EINVAL;
+  if (low->dtype != MYOLO_F16 && low->dtype != MYOLO_F32) return MYOLO_EINVAL;
+  if (low->c != 19) return MYOLO_EINVAL;                       // Cityscapes' 19 classes (the reference's only use): other counts take the unfused path
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(glow32, 0, (size_t)low->n * low->h * low->w * low->c * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
+  int TY = 32;
+  const int strips = (W + 255) / 256;
+  while (TY > 8 && (int64_t)low->n * ((H + TY - 1) / TY) * strips < 1024) TY >>= 1;     // >= 4 workgroups per CU when the map allows
+  const int64_t grid = (int64_t)low->n * ((H + TY - 1) / TY) * strips;
+  if (grid > 0x7fffffff) return MYOLO_EINVAL;
+  if (low->dtype == MYOLO_F16)
+    hipLaunchKernelGGL((seg_upce_kernel<half_t, 19>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index,
+                       acc, glow32);
+  else
+    hipLaunchKernelGGL((seg_upce_kernel<float, 19>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index,
+                       acc, glow32);
+  MYOLO_CHECK_LAUNCH();
+  if (loss) {
+    hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, st, acc, loss);
+    MYOLO_CHECK_LAUNCH();
+  }
+  return 0;
+}
+
+extern "C" int myolo_seg_lowgrad_apply(const float* glow32, const myolo_tensor* glow, int accumulate, const float* scale, void* stream) {
+  if (!glow32 || !glow || !glow->ptr || (glow->dtype != MYOLO_F16 && glow->dtype != MYOLO_F32)) return MYOLO_EINVAL;
+  const int64_t total = (int64_t)glow->n * glow->h * glow->w * glow->c;
+  const int grid = grid_for(total, 256, 4096);
+  if (glow->dtype == MYOLO_F16)
+    hipLaunchKernelGGL(seg_lowgrad_apply_kernel<half_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, glow32, *glow, glow->c, accumulate, scale);
+  else
+    hipLaunchKernelGGL(seg_lowgrad_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, glow32, *glow, glow->c, accumulate, scale);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
 static int seg_ce_fwd_impl(const void* logits, void* grad, int dtype, int n, int c, int h, int w, int64_t sn, int64_t sc, int64_t sh,
                            int64_t sw, const int64_t* target, int ignore_index, double* acc, float* pix, float* loss,
                            void* stream) {

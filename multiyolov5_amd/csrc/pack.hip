@@ -25,15 +25,18 @@ __global__ void pack_weight_kernel(const S* __restrict__ src, D* __restrict__ ds
 }
 
 // every weight of a training plan in ONE launch (the per-conv launches were ~160 x 5 us per step): job table (device int64
-// [njobs][10]) = {src, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose, src_dtype, dst_dtype}; chunk list (device int32
-// [nchunks][2]) = {job, first packed element}
+// [njobs][12]) = {src, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose, src_dtype, dst_dtype, src2, cout2}; chunk list (device
+// int32 [nchunks][2]) = {job, first packed element}.  src2 (or 0): a second OIHW tensor stacked behind src along cout (output
+// channels cout .. cout+cout2: two convolutions of one input run as one launch)
 __global__ __launch_bounds__(256) void pack_weights_mt_kernel(const int64_t* jobs, const int32_t* chunks, int chunk_elems) {
   const int j = chunks[blockIdx.x * 2], start = chunks[blockIdx.x * 2 + 1];
-  const int64_t* e = jobs + (int64_t)j * 10;
+  const int64_t* e = jobs + (int64_t)j * 12;
   const void* src = reinterpret_cast<const void*>(e[0]);
   void* dst = reinterpret_cast<void*>(e[1]);
   const int cout = (int)e[2], cin = (int)e[3], ntaps = (int)e[4], rows_pad = (int)e[5], cols_pad = (int)e[6];
   const int transpose = (int)e[7], sdt = (int)e[8], ddt = (int)e[9];
+  const void* src2 = reinterpret_cast<const void*>(e[10]);
+  const int cout2 = src2 ? (int)e[11] : 0;
   // (one packed weight tensor is far below 2^31 elements: 32-bit index arithmetic, one division chain per thread, then strides)
   const uint32_t total = (uint32_t)rows_pad * (uint32_t)ntaps * (uint32_t)cols_pad;
   uint32_t end = (uint32_t)start + (uint32_t)chunk_elems;
@@ -48,9 +51,11 @@ __global__ __launch_bounds__(256) void pack_weights_mt_kernel(const int64_t* job
     const int row = (int)row_u;
     const int co = transpose ? col : row, ci = transpose ? row : col;
     float v = 0.f;
-    if (co < cout && ci < cin) {
-      const uint32_t si = ((uint32_t)co * (uint32_t)cin + (uint32_t)ci) * utaps + (uint32_t)t;
-      v = f16s ? (float)((const half_t*)src)[si] : ((const float*)src)[si];
+    if (co < cout + cout2 && ci < cin) {
+      const bool second = co >= cout;
+      const uint32_t si = ((uint32_t)(second ? co - cout : co) * (uint32_t)cin + (uint32_t)ci) * utaps + (uint32_t)t;
+      const void* sp = second ? src2 : src;
+      v = f16s ? (float)((const half_t*)sp)[si] : ((const float*)sp)[si];
     }
     if (f16d) ((half_t*)dst)[i] = (half_t)v; else ((float*)dst)[i] = v;
   }

@@ -101,6 +101,19 @@ class Call:
             L.check(e, self.name)
 
 
+class SwitchCall:
+    """one of two launches, chosen when it is issued: `b` if state[key] (set by the consumer of the plan's output for this step) else
+    `a`.  A captured backward graph bakes in the choice made at capture time."""
+    __slots__ = ('a', 'b', 'state', 'key', 'name', 'side', 'args', 'keep')
+
+    def __init__(self, a, b, state, key):
+        self.a, self.b, self.state, self.key = a, b, state, key
+        self.name, self.side, self.args, self.keep = a.name, False, a.args, (a, b)
+
+    def __call__(self, st):
+        (self.b if self.state[self.key] else self.a)(st)
+
+
 class Op:
     def build(self, plan):      # create Calls (buffers are allocated)
         self.fwd_calls, self.bwd_calls, self.prep_calls = [], [], []
@@ -209,11 +222,19 @@ class ImportOp(Op):
 class ConvOp(Op):
     """Conv2d (+BN) (+act) (+residual) / Detect conv; see include/myolo.h myolo_conv."""
 
-    def __init__(self, plan, x, out, weight, bn=None, bias=None, k=1, s=1, d=1, act=L.ACT_NONE, res=None, det=None):
+    def __init__(self, plan, x, out, weight, bn=None, bias=None, k=1, s=1, d=1, act=L.ACT_NONE, res=None, det=None,
+                 weight2=None, bn2=None, bias2=None):
+        """weight2 / bn2 / bias2: a SECOND Conv(+BN) of the same geometry on the same input, run in the same launches; its output
+        channels follow the first one's (`out` holds c1out + c2out channels; C3.cv2 | C3.cv1, common.py:137)."""
         self.x, self.out, self.weight, self.bn, self.bias = x, out, weight, bn, bias
+        self.weight2, self.bn2, self.bias2 = weight2, bn2, bias2
         self.k, self.s, self.d, self.act, self.res, self.det = k, s, d, act, res, det
         self.pad = d * (k // 2)
-        self.cout, self.cin = weight.shape[0], weight.shape[1]
+        self.c1out = weight.shape[0]
+        self.cout, self.cin = weight.shape[0] + (weight2.shape[0] if weight2 is not None else 0), weight.shape[1]
+        if weight2 is not None:
+            assert tuple(weight2.shape[1:]) == tuple(weight.shape[1:]) and (bn is None) == (bn2 is None) and \
+                (bias is None) == (bias2 is None) and res is None and det is None and self.c1out % SEG[plan.dtype] == 0
         self.acc_x = 0
         self.zero_first = []
         self.res_acc = 0
@@ -240,11 +261,18 @@ class ConvOp(Op):
         cin_pad, cout_pad = rup(self.x.c, kc), rup(self.cout, 32)
         self.wpack = torch.zeros(cout_pad, ntaps, cin_pad, dtype=dt, device=dev)
         w = self.weight
+        w2 = self.weight2
         if training:      # repacked from the live fp32 master every forward (= autocast's cast): batched into one launch
-            plan.add_pack_job(w, self.wpack, self.cout, self.cin, ntaps, cout_pad, cin_pad, 0)
-        else:
+            plan.add_pack_job(w, self.wpack, self.c1out, self.cin, ntaps, cout_pad, cin_pad, 0, w2)
+        elif w2 is None:
             self.prep_calls.append(Call('myolo_pack_weight', (L.ptr(w), L.DT[w.dtype], self.cout, self.cin, self.k, self.k,
                                                               L.ptr(self.wpack), L.DT[dt], cout_pad, cin_pad, 0, None), keep=w))
+        else:             # rows [0, c1out) from the first weight, the rest (+ zero padding) from the second
+            self.prep_calls.append(Call('myolo_pack_weight', (L.ptr(w), L.DT[w.dtype], self.c1out, self.cin, self.k, self.k,
+                                                              L.ptr(self.wpack), L.DT[dt], self.c1out, cin_pad, 0, None), keep=w))
+            self.prep_calls.append(Call('myolo_pack_weight', (L.ptr(w2), L.DT[w2.dtype], self.cout - self.c1out, self.cin, self.k, self.k,
+                                                              L.ptr(self.wpack[self.c1out:]), L.DT[dt], cout_pad - self.c1out, cin_pad,
+                                                              0, None), keep=w2))
         d = L.ConvDesc()
         d.x = self.x.desc()
         d.w = self.wpack.data_ptr()
@@ -267,7 +295,18 @@ class ConvOp(Op):
             self.yd, self.od = yv.desc(), self.out.desc()
             self.rd = self.res.desc() if self.res is not None else null_tensor()
             bn = self.bn
-            if has_bn:
+            if has_bn and self.bn2 is not None:
+                b2 = self.bn2
+                assert (b2.eps, b2.momentum) == (bn.eps, bn.momentum)
+                sp = self.split = L.BnSplit()
+                sp.c_split = self.c1out
+                sp.gamma2, sp.beta2, sp.running_mean2 = b2.weight.data_ptr(), b2.bias.data_ptr(), b2.running_mean.data_ptr()
+                sp.running_var2, sp.nbt2 = b2.running_var.data_ptr(), b2.num_batches_tracked.data_ptr()
+                self.fwd_calls.append(Call('myolo_bn_act_fwd_split', (
+                    C.byref(self.yd), L.ptr(self.stats), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
+                    L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), L.ptr(self.saved), C.c_float(bn.eps),
+                    C.c_float(bn.momentum), self.act, C.byref(self.rd), C.byref(self.od), C.byref(sp)), keep=(bn, b2)))
+            elif has_bn:
                 self.fwd_calls.append(Call('myolo_bn_act_fwd', (
                     C.byref(self.yd), L.ptr(self.stats), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
                     L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), L.ptr(self.saved), C.c_float(bn.eps),
@@ -291,7 +330,7 @@ class ConvOp(Op):
                 self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
                 d.scale, d.shift = self.scale.data_ptr(), self.shift.data_ptr()
             elif self.bias is not None:
-                if self.bias.dtype == torch.float32:
+                if self.bias.dtype == torch.float32 and self.bias2 is None:
                     d.shift = self.bias.data_ptr()        # read the live parameter: no stale copy under training
                 else:
                     self.shift = torch.empty(self.cout, dtype=torch.float32, device=dev)
@@ -305,12 +344,19 @@ class ConvOp(Op):
         """(re)derive eval-mode epilogue constants from the parameters (host-side, once per weight version)."""
         with torch.no_grad():
             if hasattr(self, 'scale'):
-                bn = self.bn
-                sc = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
-                self.scale.copy_(sc)
-                self.shift.copy_(bn.bias.float() - bn.running_mean.float() * sc)
+                c0 = 0
+                for bn in (self.bn, self.bn2):
+                    if bn is None:
+                        continue
+                    sc = bn.weight.float() * torch.rsqrt(bn.running_var.float() + bn.eps)
+                    c1 = c0 + sc.numel()
+                    self.scale[c0:c1].copy_(sc)
+                    self.shift[c0:c1].copy_(bn.bias.float() - bn.running_mean.float() * sc)
+                    c0 = c1
             elif hasattr(self, 'shift'):
-                self.shift.copy_(self.bias.float())
+                self.shift[:self.c1out].copy_(self.bias.float())
+                if self.bias2 is not None:
+                    self.shift[self.c1out:].copy_(self.bias2.float())
 
     def _build_bwd(self, plan, two_pass, has_bn):
         dt, dev = plan.dtype, plan.device
@@ -333,13 +379,24 @@ class ConvOp(Op):
             if has_bn:
                 bn = self.bn
                 self.dsum = plan.f32_bwd_zero(L.STAT_COPIES * 2 * self.cout)
-                if self.reduce_by is None:       # (else the dgrad that wrote the last piece of `gout` already left the sums in dsum)
-                    calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
-                                                                  L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
-                calls.append(Call('myolo_bn_act_bwd_apply', (
-                    C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
-                    L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
-                    C.byref(grd), self.res_acc)))
+                if self.bn2 is not None:
+                    sp = self.split
+                    sp.dgamma2, sp.dbeta2 = plan.pgrad(self.bn2.weight).data_ptr(), plan.pgrad(self.bn2.bias).data_ptr()
+                    calls.append(Call('myolo_bn_act_bwd_reduce_split', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
+                                                                        L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum),
+                                                                        C.byref(sp))))
+                    calls.append(Call('myolo_bn_act_bwd_apply_split', (
+                        C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
+                        L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
+                        C.byref(grd), self.res_acc, C.byref(sp))))
+                else:
+                    if self.reduce_by is None:   # (else the dgrad that wrote the last piece of `gout` already left the sums in dsum)
+                        calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
+                                                                      L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
+                    calls.append(Call('myolo_bn_act_bwd_apply', (
+                        C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
+                        L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
+                        C.byref(grd), self.res_acc)))
             else:
                 calls.append(Call('myolo_bn_act_bwd_apply', (
                     C.byref(self.god), C.byref(self.yd), None, None, None, self.act, None, None, None,
@@ -361,7 +418,7 @@ class ConvOp(Op):
             ntaps = self.k * self.k
             self.wpack_t = torch.zeros(cout_pad_t, ntaps, cin_pad_t, dtype=dt, device=dev)
             w = self.weight
-            plan.add_pack_job(w, self.wpack_t, self.cout, self.cin, ntaps, cout_pad_t, cin_pad_t, 1)
+            plan.add_pack_job(w, self.wpack_t, self.c1out, self.cin, ntaps, cout_pad_t, cin_pad_t, 1, self.weight2)
             self.dg = []
             par = []                                     # stride 2: the parity sub-convolutions, fused into one launch when all four exist
             s = self.s
@@ -403,22 +460,34 @@ class ConvOp(Op):
             if par:
                 self.dg_arr = (C.POINTER(L.ConvDesc) * len(par))(*[C.pointer(g) for g in par])
                 calls.append(Call('myolo_conv_dgrad_s2', (self.dg_arr, len(par))))
-        # wgrad
-        wd = L.WgradDesc()
-        wd.x, wd.dy = self.x.desc(), dy_desc
-        wd.dw = plan.pgrad(self.weight).data_ptr()
-        wd.db = plan.pgrad(self.bias).data_ptr() if self.bias is not None else None
-        wd.ntaps, wd.stride, wd.up_shift, wd.ksplit, wd.cout, wd.cin = self.k * self.k, self.s, 0, 0, self.cout, self.cin
-        # weight gradients run beside the dgrad / BatchNorm chain: few long-lived workgroups (less CU / LDS stolen from the chain) while
-        # plenty of the backward is still to come, many for the first layers of the network (= the END of the backward: exposed tail)
-        pos = getattr(plan, '_building', 0) / max(len(plan.ops), 1)
-        wd.wg_hint = WGRAD_WG_TAIL if pos < WGRAD_TAIL_FRAC else WGRAD_WG
-        ws = plan.wgrad_workspace()
-        wd.ws, wd.ws_bytes = ws.data_ptr(), ws.numel() * 4
-        tdy, tdx, _ = taps_fwd(self.k, self.d, self.pad)
-        fill_taps(wd, tdy, tdx)
-        self.wd = wd
-        calls.append(Call('myolo_conv_wgrad', (C.byref(wd),), side=True))
+        # wgrad (one launch per weight tensor: the gradients live in separate slots of the flat gradient buffer)
+        es = 2 if dt == torch.float16 else 4
+        self.wds = []
+        c0 = 0
+        for w, b in ((self.weight, self.bias), (self.weight2, self.bias2)):
+            if w is None:
+                continue
+            co = w.shape[0]
+            wd = L.WgradDesc()
+            wd.x = self.x.desc()
+            wd.dy = dy_desc if self.weight2 is None else CT(dy_desc.ptr + c0 * es, dy_desc.n, dy_desc.h, dy_desc.w, co, dy_desc.sn,
+                                                            dy_desc.sh, dy_desc.sw, dy_desc.dtype, 0)
+            wd.dw = plan.pgrad(w).data_ptr()
+            wd.db = plan.pgrad(b).data_ptr() if b is not None else None
+            wd.ntaps, wd.stride, wd.up_shift, wd.ksplit, wd.cout, wd.cin = self.k * self.k, self.s, 0, 0, co, self.cin
+            # weight gradients run beside the dgrad / BatchNorm chain: few long-lived workgroups (less CU / LDS stolen from the chain)
+            # while plenty of the backward is still to come, many for the first layers of the network (= the END of the backward:
+            # exposed tail)
+            pos = getattr(plan, '_building', 0) / max(len(plan.ops), 1)
+            wd.wg_hint = WGRAD_WG_TAIL if pos < WGRAD_TAIL_FRAC else WGRAD_WG
+            ws = plan.wgrad_workspace()
+            wd.ws, wd.ws_bytes = ws.data_ptr(), ws.numel() * 4
+            tdy, tdx, _ = taps_fwd(self.k, self.d, self.pad)
+            fill_taps(wd, tdy, tdx)
+            self.wds.append(wd)
+            calls.append(Call('myolo_conv_wgrad', (C.byref(wd),), side=True))
+            c0 += co
+        self.wd = self.wds[0]
 
 
 class SimpleOp(Op):
@@ -638,8 +707,16 @@ class SegOutOp(Op):
             out._myolo_grad_scale = (self.gscale, self.gstate)
             plan.output_scales[self.slot] = (self.gscale, self.gstate)
             self.gld = lw.desc(grad=True)
-            self.bwd_calls.append(Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], H, W, *g.stride(), C.byref(self.gld),
-                                                                  self.acc, L.ptr(self.gscale)), keep=(g, self.gscale)))
+            full = Call('myolo_seg_upsample_bwd', (L.ptr(g), L.DT[g.dtype], H, W, *g.stride(), C.byref(self.gld),
+                                                   self.acc, L.ptr(self.gscale)), keep=(g, self.gscale))
+            # K15: utils.loss can run upsample + CE + both backwards in one pass over the low-res logits (myolo_seg_upce_fwd_grad); it
+            # leaves the classifier's unnormalised fp32 gradient in glow32 and sets gstate['low'] -- the backward then only rescales it
+            self.glow32 = torch.zeros(lw.n, lw.h, lw.w, lw.c, dtype=torch.float32, device=plan.device)
+            out._myolo_low_grad = self.glow32
+            self.gstate['low'] = False
+            low = Call('myolo_seg_lowgrad_apply', (L.ptr(self.glow32), C.byref(self.gld), self.acc, L.ptr(self.gscale)),
+                       keep=(self.glow32, self.gscale))
+            self.bwd_calls.append(SwitchCall(full, low, self.gstate, 'low'))
 
 
 class ExportOp(Op):
@@ -699,22 +776,25 @@ class Plan:
         self.ops.append(op)
         return op
 
-    def add_pack_job(self, w, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose):
-        self._pack_jobs.append((w, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose))
+    def add_pack_job(self, w, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose, w2=None):
+        """w2: a second weight tensor stacked behind `w` along cout (ConvOp weight2)"""
+        assert w2 is None or w2.dtype == w.dtype
+        self._pack_jobs.append((w, dst, cout, cin, ntaps, rows_pad, cols_pad, transpose, w2))
 
     def _build_pack_table(self):
         CH = 8192
         rows, chunks = [], []
-        for j, (w, dst, cout, cin, ntaps, rp, cp, tr) in enumerate(self._pack_jobs):
-            rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, ntaps, rp, cp, tr, L.DT[w.dtype], L.DT[dst.dtype]))
+        for j, (w, dst, cout, cin, ntaps, rp, cp, tr, w2) in enumerate(self._pack_jobs):
+            rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, ntaps, rp, cp, tr, L.DT[w.dtype], L.DT[dst.dtype],
+                         w2.data_ptr() if w2 is not None else 0, w2.shape[0] if w2 is not None else 0))
             for s0 in range(0, rp * ntaps * cp, CH):
                 chunks.append((j, s0))
-        self._pack_key = tuple(r[0] for r in rows)
+        self._pack_key = tuple((r[0], r[10]) for r in rows)
         if not rows:
             self._pack_call = None
             return
         dev = self.device
-        self._pack_tab = torch.tensor(rows, dtype=torch.int64).reshape(-1, 10).to(dev)
+        self._pack_tab = torch.tensor(rows, dtype=torch.int64).reshape(-1, 12).to(dev)
         self._pack_chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
         self._pack_call = Call('myolo_pack_weights_mt', (L.ptr(self._pack_tab), L.ptr(self._pack_chunks), len(chunks), CH))
 
@@ -824,7 +904,7 @@ class Plan:
             return                                                     # ~0.4 ms of reduce work INTO the conv launches (conv roofline 0.145 -> 0.130)
         max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
         for op in self.ops:
-            if not isinstance(op, ConvOp) or op.bn is None or op.det:
+            if not isinstance(op, ConvOp) or op.bn is None or op.det or op.bn2 is not None:
                 continue
             o = op.out
             if o.n * o.h * o.w * o.c > max_elems:      # big maps: the separate reduce pass streams at 3-4 TB/s, cheaper than 8-byte epilogue loads
@@ -864,7 +944,7 @@ class Plan:
             self._arena[0][:self._used[0]].zero_()
 
     def _check_pack_table(self):
-        if self._pack_call is not None and self._pack_key != tuple(j[0].data_ptr() for j in self._pack_jobs):
+        if self._pack_call is not None and self._pack_key != tuple((j[0].data_ptr(), j[8].data_ptr() if j[8] is not None else 0) for j in self._pack_jobs):
             self._build_pack_table()                          # a parameter was re-allocated (.to(), load): new table, new graphs
             self.__dict__.pop('_graphs', None)
 
@@ -1207,12 +1287,12 @@ def call_algorithmic_bytes(call):
         d = call.args[0]._obj
         return _tensor_bytes(d.x) + _tensor_bytes(d.dy) + d.ntaps * max(d.cout, 1) * max(d.cin, 1) * 4
     a = [x._obj if hasattr(x, '_obj') else x for x in call.args]
-    if n == 'myolo_bn_act_fwd':
+    if n in ('myolo_bn_act_fwd', 'myolo_bn_act_fwd_split'):
         y, res = a[0], a[11]
         return _tensor_bytes(y) * 2 + (_tensor_bytes(res) if res.ptr else 0)
-    if n == 'myolo_bn_act_bwd_reduce':
+    if n in ('myolo_bn_act_bwd_reduce', 'myolo_bn_act_bwd_reduce_split'):
         return _tensor_bytes(a[0]) * 2
-    if n == 'myolo_bn_act_bwd_apply':
+    if n in ('myolo_bn_act_bwd_apply', 'myolo_bn_act_bwd_apply_split'):
         g, gres = a[0], a[10]
         return _tensor_bytes(g) * 3 + (_tensor_bytes(gres) if gres.ptr else 0)
     return None
@@ -1222,7 +1302,8 @@ def plan_algorithmic_bytes(plan):
     """{family: bytes} over the forward + backward launch lists of a training plan"""
     out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
     fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
-           'myolo_bn_act_bwd_apply': 'batchnorm'}
+           'myolo_bn_act_bwd_apply': 'batchnorm', 'myolo_bn_act_fwd_split': 'batchnorm', 'myolo_bn_act_bwd_reduce_split': 'batchnorm',
+           'myolo_bn_act_bwd_apply_split': 'batchnorm'}
     for op in plan.ops:
         for c in list(op.fwd_calls) + list(op.bwd_calls):
             b = call_algorithmic_bytes(c)

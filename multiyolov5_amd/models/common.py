@@ -6,6 +6,8 @@ checkpoints resolve.  None of these modules calls ATen for compute: `forward()` 
 signature) and runs a static plan of libmyolo kernel launches (multiyolov5_amd/engine.py); the nn.Conv2d /
 nn.BatchNorm2d members are parameter containers only.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -46,6 +48,42 @@ def emit_conv(plan, x, conv, bn=None, act=L.ACT_NONE, res=None, out=None, det=No
         out = plan.new(x.n, ho, wo, conv.out_channels)
     op = plan.add(E.ConvOp(plan, x, out, conv.weight, bn=bn, bias=conv.bias, k=k, s=s, d=d, act=act, res=res, det=det))
     return out, op
+
+
+C3_MERGE = os.environ.get('MYOLO_C3_MERGE', '1') != '0'
+
+
+def emit_csp_entry(plan, x, cv1, cv2, c_inner):
+    """C3 / C3SPP entry (common.py:137,150): cv1(x) and cv2(x) are two 1x1 Conv+BN+SiLU of the SAME input -> ONE convolution with the
+    stacked weights [cv2; cv1], one BatchNorm pass per direction with two parameter sets, one dgrad (K = 2c_): ~5 launches fewer per
+    block on the backward's dependent chain.  One buffer [inner (c_inner) | cv2 (c_) | cv1 (c_)]: the stacked conv writes the last
+    2c_ channels, the inner branch reads the cv1 slice and its result is placed in front, so cv3 reads channels [0, c_inner + c_) in
+    the reference's concat order.  Returns (cv1 output slice, place(inner_result) -> cv3 input) or None when the pair cannot merge."""
+    a, b = cv1.conv, cv2.conv
+    bn1, bn2 = (cv1.bn if hasattr(cv1, 'bn') else None), (cv2.bn if hasattr(cv2, 'bn') else None)
+    seg = E.SEG[plan.dtype]
+    same = (a.kernel_size, a.stride, a.padding, a.dilation, a.groups, a.bias is None) == \
+           (b.kernel_size, b.stride, b.padding, b.dilation, b.groups, b.bias is None)
+    if not (C3_MERGE and same and a.kernel_size == (1, 1) and a.stride == (1, 1) and a.groups == 1 and (bn1 is None) == (bn2 is None)
+            and type(cv1.act) is type(cv2.act) and a.out_channels % seg == 0 and b.out_channels % seg == 0 and c_inner % seg == 0
+            and (bn1 is None or (bn1.eps, bn1.momentum) == (bn2.eps, bn2.momentum))):
+        return None
+    c1o, c2o = a.out_channels, b.out_channels
+    buf = plan.new_buf(x.n, x.h, x.w, c_inner + c2o + c1o)
+    both = plan.new(x.n, x.h, x.w, c2o + c1o)
+    both.place(buf, c_inner)
+    plan.add(E.ConvOp(plan, x, both, b.weight, bn=bn2, bias=b.bias, k=1, s=1, d=1, act=_act_code(cv1.act),
+                      weight2=a.weight, bn2=bn1, bias2=a.bias))
+    first = plan.new(x.n, x.h, x.w, c1o)
+    first.place(buf, c_inner + c2o)
+
+    def place(inner):
+        assert inner.buf is None and inner.c == c_inner and (inner.n, inner.h, inner.w) == (x.n, x.h, x.w)
+        inner.place(buf, 0)
+        cat = plan.new(x.n, x.h, x.w, c_inner + c2o)
+        cat.place(buf, 0)
+        return cat
+    return first, place
 
 
 class Conv(PlannedModule):
@@ -91,6 +129,12 @@ class C3(PlannedModule):
         self.m = nn.Sequential(*[Bottleneck(c_, c_, shortcut, g, e=1.0) for _ in range(n)])
 
     def emit(self, plan, x):
+        merged = emit_csp_entry(plan, x, self.cv1, self.cv2, self.cv1.conv.out_channels) if len(self.m) else None
+        if merged is not None:
+            a, place = merged
+            for b in self.m:
+                a = b.emit(plan, a)
+            return self.cv3.emit(plan, place(a))
         a = self.cv1.emit(plan, x)
         for b in self.m:
             a = b.emit(plan, a)
@@ -129,6 +173,10 @@ class C3SPP(PlannedModule):
         self.m = SPP(c_, int(c_ * 1.5), k=k)
 
     def emit(self, plan, x):
+        merged = emit_csp_entry(plan, x, self.cv1, self.cv2, self.m.cv2.conv.out_channels)
+        if merged is not None:
+            a, place = merged
+            return self.cv3.emit(plan, place(self.m.emit(plan, a)))
         a = self.m.emit(plan, self.cv1.emit(plan, x))
         return self.cv3.emit(plan, plan.cat([a, self.cv2.emit(plan, x)]))
 

@@ -92,11 +92,13 @@ class PlanFn(torch.autograd.Function):
         outs = []
         for o in holder.output_tensors():
             d = o.detach()
-            for attr in ('_myolo_low', '_myolo_grad_buf', '_myolo_grad_scale'):          # side channels of the fused loss / argmax kernels
+            for attr in ('_myolo_low', '_myolo_grad_buf', '_myolo_grad_scale', '_myolo_low_grad'):   # side channels of the fused loss / argmax kernels
                 if hasattr(o, attr):
                     setattr(d, attr, getattr(o, attr))
             outs.append(d)
         outs = tuple(outs)
+        for sc in plan.output_scales.values():        # (a fused low-resolution CE of an earlier forward that never ran its backward)
+            sc[1]['low'] = False
         holder.generation += 1                       # activations / BN statistics / dropout masks of this forward
         ctx.generation = holder.generation
         holder.pending_bwd = True
@@ -118,6 +120,8 @@ class PlanFn(torch.autograd.Function):
                                    'their gradients cannot be combined (set MYOLO_FUSED_CE=0 for that use)')
             if g is None:
                 dst.zero_()
+                if sc is not None:
+                    sc[1]['low'] = False                  # this output's loss is not part of the backward: no low-resolution gradient either
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
                 dst.copy_(g)                              # (the fused losses already wrote into dst: nothing to move)
             if sc is not None:                            # gradient factor published by the fused CE (utils.loss._SegCE)
@@ -128,6 +132,8 @@ class PlanFn(torch.autograd.Function):
                     scale.fill_(1.0)
                     state['dirty'] = False
         plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
+        for sc in plan.output_scales.values():
+            sc[1]['low'] = False
         holder.pending_bwd = False
         in_grads = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]
         flat = plan.flat_grad.clone()

@@ -18,6 +18,8 @@ from .torch_utils import is_parallel
 
 # MYOLO_FUSED_CE=0: keep the CE backward a separate pass (needed only if the logits feed another differentiable op as well)
 FUSED_CE = os.environ.get('MYOLO_FUSED_CE', '1') != '0'
+# MYOLO_FUSED_UPCE=0: keep the loss on the materialised full-resolution logits (myolo_seg_ce_fwd_grad + myolo_seg_upsample_bwd)
+FUSED_UPCE = os.environ.get('MYOLO_FUSED_UPCE', '1') != '0'
 
 
 def smooth_BCE(eps=0.1):  # loss.py:11-13
@@ -63,7 +65,22 @@ class _SegCE(torch.autograd.Function):
         # gradient buffer and the backward only publishes the scalar gout/n_valid to the buffer's consumer
         gs = getattr(logits, '_myolo_grad_scale', None)
         ctx.fused = None
-        if (FUSED_CE and pix is None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
+        # K15: the plan's low-resolution class logits are at hand -> upsample + CE + gradient + transposed upsample in one pass over
+        # them; the full-resolution logits are not read and their gradient is never formed
+        low, g32 = getattr(logits, '_myolo_low', None), getattr(logits, '_myolo_low_grad', None)
+        if (FUSED_UPCE and FUSED_CE and pix is None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
+                and low is not None and g32 is not None and low.shape[3] == 19 and low.stride(3) == 1 and low.dtype == logits.dtype
+                and not gs[1].get('low', True)):
+            ld = L.Tensor(low.data_ptr(), low.shape[0], low.shape[1], low.shape[2], low.shape[3], low.stride(0), low.stride(1),
+                          low.stride(2), L.DT[low.dtype], 0)
+            rc = lib.myolo_seg_upce_fwd_grad(C.byref(ld), h, w, L.ptr(target), int(ignore_index), L.ptr(acc), L.ptr(loss),
+                                             L.ptr(g32), st)
+            if rc == 0:
+                ctx.fused = gs
+                gs[1]['low'] = True
+            elif rc != L.EINVAL:
+                L.check(rc, 'myolo_seg_upce_fwd_grad')
+        if (ctx.fused is None and FUSED_CE and pix is None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
                 and logits.stride() == (h * w * c, 1, w * c, c) and ctx.grad_buf.stride() == logits.stride()
                 and ctx.grad_buf.dtype == logits.dtype and logits.data_ptr() % 16 == 0 and ctx.grad_buf.data_ptr() % 16 == 0):
             rc = lib.myolo_seg_ce_fwd_grad(L.ptr(logits), L.ptr(ctx.grad_buf), L.DT[logits.dtype], n, c, h, w, L.ptr(target),
