@@ -387,6 +387,8 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
     if (b * panel_pitch(K) + 4 * b * 4 + 256 <= 144 * 1024) { bn = b; break; }
   }
   if (!bn) return -1;
+  if (d->ntaps > 1 && d->cout_pad / bn > 2) return -1;  // multi-tap A tiles re-streamed per N tile (the 128 -> 256 3x3 dgrad of the PSP head: 8 N
+                                                       // tiles of 32, 270 us here against 122 us for the same shape tiled)
   if (d->cout_pad / bn > 8) return -1;                 // A would be re-streamed too often: the tiled kernel wins (6 N tiles of the
                                                        // 64 -> 384 dgrads still stream: 116 us tiled in the r2 step profile)
   ConvS k;

@@ -10,9 +10,9 @@ m = Model(os.path.join(CFG, TAGS['s_psp'])); m.train(True)
 h = R.PlanHolder(m, [torch.zeros(16, 3, 512, 1024)], ('t', 0), torch.float16, True)
 calls = []
 for o in h.plan.ops:
-    calls += [('f', c) for c in o.fwd_calls if c.name == 'myolo_conv']
+    calls += [('f', c) for c in o.fwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2')]
 for o in reversed(h.plan.ops):
-    calls += [('b', c) for c in o.bwd_calls if c.name == 'myolo_conv']
+    calls += [('b', c) for c in o.bwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2')]
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 sgd = [i for i, r in enumerate(rows) if 'mt_sgd' in r['Kernel_Name']]
@@ -20,8 +20,23 @@ step = rows[sgd[-2] + 1:sgd[-1] + 1]
 ks = [r for r in step if 'conv_igemm_kernel' in r['Kernel_Name'] or 'conv_stream_kernel' in r['Kernel_Name'] or 'conv_halo_kernel' in r['Kernel_Name']]
 print(len(calls), len(ks))
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, ''])
-for (ph, c), r in zip(calls, ks):
-    d = E._conv_desc_of(c)
+import re
+pairs, ki = [], 0
+for ph, c in calls:                     # a stride-2 dgrad is one parity-fused halo kernel (template arg S2 = 1) or four plain launches
+    if c.name == 'myolo_conv_dgrad_s2':
+        m_ = re.search(r'conv_halo_kernel<\d+, \d+, \d+, \d+, \d+, (\d)', ks[ki]['Kernel_Name'])
+        nk = 1 if (m_ and m_.group(1) == '1') else c.args[1]
+    else:
+        nk = 1
+    grp = ks[ki:ki + nk]
+    ki += nk
+    r = dict(grp[0])
+    r['Start_Timestamp'] = 0
+    r['End_Timestamp'] = sum(int(g['End_Timestamp']) - int(g['Start_Timestamp']) for g in grp)
+    pairs.append(((ph, c), r))
+print('kernels consumed', ki, 'of', len(ks))
+for (ph, c), r in pairs:
+    d = E._s2_descs(c)[0] if c.name == 'myolo_conv_dgrad_s2' else E._conv_desc_of(c)
     t = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
     kn = 'stream' if 'stream' in r['Kernel_Name'] else ('halo' if 'halo' in r['Kernel_Name'] else 'igemm')
     key = (ph, d.x.h, d.x.w, d.x.c, d.y.h, d.y.w, d.y.c, d.ntaps, kn)

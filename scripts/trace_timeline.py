@@ -69,3 +69,13 @@ g = [(y['s'] - x['e'], x, y) for x, y in zip(main, main[1:])]
 print('largest main-queue gaps:')
 for gap, x, y in sorted(g, key=lambda t: -t[0])[:12]:
     print(f'  {gap / 1e3:7.1f} us at +{(x["e"] - t0) / 1e3:8.1f}: {x["Kernel_Name"][:40]} -> {y["Kernel_Name"][:40]}')
+# duration histogram of the main queue (where does the dependent chain spend its time: many short launches or few long ones?)
+bins = [(0, 6), (6, 9), (9, 12), (12, 16), (16, 24), (24, 40), (40, 80), (80, 1e9)]
+print('main-queue duration histogram (us): count, total us')
+for lo, hi in bins:
+    rs = [r for r in main if lo * 1e3 <= r['e'] - r['s'] < hi * 1e3]
+    fam = defaultdict(int)
+    for r in rs:
+        fam[r['Kernel_Name'].split('<')[0].split('(')[0].replace('void ', '')[:28]] += 1
+    top = ', '.join(f'{k} x{v}' for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:5])
+    print(f'  [{lo:3.0f},{hi:5.0f}): {len(rs):4d}  {sum(r["e"] - r["s"] for r in rs) / 1e3:8.1f}   {top}')
