@@ -138,21 +138,28 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
   const PixDec pd(y);
   const bool dense = pix_dense(y) && pix_dense(gout);
   const int64_t stride = (int64_t)gridDim.x * PPB;
-  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += 2 * stride) {      // two pixels in flight per thread
-    const int64_t pix2 = pix + stride;
-    const bool has2 = pix2 < M;
-    float fy[SEG], fg[SEG], fy2[SEG], fg2[SEG];
-    const uint4 ry = ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), rg = ldg16(pptr<T>(gout, dense, pd, pix) + cg * SEG);
-    const int64_t q = has2 ? pix2 : pix;
-    const uint4 ry2 = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG), rg2 = ldg16(pptr<T>(gout, dense, pd, q) + cg * SEG);
-    Vec<T>::unpack(ry, fy); Vec<T>::unpack(rg, fg); Vec<T>::unpack(ry2, fy2); Vec<T>::unpack(rg2, fg2);
-    const float w2 = has2 ? 1.f : 0.f;
+  constexpr int NPF = 4;                 // pixels in flight per thread (8 x 16-byte loads): a thread of a small map makes 1-2 round trips
+  for (int64_t pix = (int64_t)blockIdx.x * PPB + pl; pix < M; pix += NPF * stride) {
+    uint4 ry[NPF], rg[NPF];
+    float wk[NPF];
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      const float dz = fg[i] * act_grad_f(fy[i] * sc[i] + sh[i], act);
-      const float dz2 = w2 * fg2[i] * act_grad_f(fy2[i] * sc[i] + sh[i], act);
-      s0[i] += dz + dz2;
-      s1[i] += (dz * (fy[i] - mean[i]) + dz2 * (fy2[i] - mean[i])) * istd[i];
+    for (int k = 0; k < NPF; ++k) {
+      const int64_t pk = pix + k * stride;
+      const int64_t q = pk < M ? pk : pix;                    // clamped: the loads stay unconditional, the weight masks
+      wk[k] = pk < M ? 1.f : 0.f;
+      ry[k] = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG);
+      rg[k] = ldg16(pptr<T>(gout, dense, pd, q) + cg * SEG);
+    }
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+      float fy[SEG], fg[SEG];
+      Vec<T>::unpack(ry[k], fy); Vec<T>::unpack(rg[k], fg);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        const float dz = wk[k] * fg[i] * act_grad_f(fy[i] * sc[i] + sh[i], act);
+        s0[i] += dz;
+        s1[i] += dz * (fy[i] - mean[i]) * istd[i];
+      }
     }
   }
   float* mine = red + (size_t)pl * (G * SEG * 2) + cg * SEG * 2;
@@ -322,8 +329,9 @@ extern "C" int myolo_bn_act_bwd_reduce_split(const myolo_tensor* gout, const myo
   if (G > 256) return MYOLO_EINVAL;
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  int grid = (int)((M + PPB * 8 - 1) / (PPB * 8));   // >= 8 pixels per thread
-  if (grid > 512) grid = 512;        // few, long-lived workgroups: the final per-channel atomics are same-address
+  int grid = (int)((M + PPB * 4 - 1) / (PPB * 4));   // >= 4 pixels per thread (one pass of the 4-deep load pipeline)
+  const int cap = y->c >= 512 ? 256 : 512;   // few, long-lived workgroups: the final per-channel atomics (2*C per workgroup) are same-address
+  if (grid > cap) grid = cap;
   if (grid < 1) grid = 1;
   const size_t smem = (size_t)PPB * G * seg * 2 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
