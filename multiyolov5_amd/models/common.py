@@ -53,12 +53,13 @@ def emit_conv(plan, x, conv, bn=None, act=L.ACT_NONE, res=None, out=None, det=No
 C3_MERGE = os.environ.get('MYOLO_C3_MERGE', '1') != '0'
 
 
-def emit_csp_entry(plan, x, cv1, cv2, c_inner):
+def emit_csp_entry(plan, x, cv1, cv2, c_inner, place_inner=True):
     """C3 / C3SPP entry (common.py:137,150): cv1(x) and cv2(x) are two 1x1 Conv+BN+SiLU of the SAME input -> ONE convolution with the
     stacked weights [cv2; cv1], one BatchNorm pass per direction with two parameter sets, one dgrad (K = 2c_): ~5 launches fewer per
     block on the backward's dependent chain.  One buffer [inner (c_inner) | cv2 (c_) | cv1 (c_)]: the stacked conv writes the last
     2c_ channels, the inner branch reads the cv1 slice and its result is placed in front, so cv3 reads channels [0, c_inner + c_) in
-    the reference's concat order.  Returns (cv1 output slice, place(inner_result) -> cv3 input) or None when the pair cannot merge."""
+    the reference's concat order.  Returns (cv1 output slice, place(inner_result) -> cv3 input) -- or (cv1 output slice, buffer) with
+    place_inner=False -- or None when the pair cannot merge."""
     a, b = cv1.conv, cv2.conv
     bn1, bn2 = (cv1.bn if hasattr(cv1, 'bn') else None), (cv2.bn if hasattr(cv2, 'bn') else None)
     seg = E.SEG[plan.dtype]
@@ -76,6 +77,8 @@ def emit_csp_entry(plan, x, cv1, cv2, c_inner):
                       weight2=a.weight, bn2=bn1, bias2=a.bias))
     first = plan.new(x.n, x.h, x.w, c1o)
     first.place(buf, c_inner + c2o)
+    if not place_inner:                 # (RFB2: the caller lays several tensors out in front itself)
+        return first, buf
 
     def place(inner):
         assert inner.buf is None and inner.c == c_inner and (inner.n, inner.h, inner.w) == (x.n, x.h, x.w)
@@ -312,6 +315,22 @@ class RFB2(PlannedModule):
         self.ConvLinear = Conv(int(5 * ip) if has_globel else int(4 * ip), out_planes, k=1, s=1)
 
     def emit(self, plan, x, res=None):
+        # branch3 and branch0[0] are two 1x1 Conv+BN+SiLU of the same input: one launch (see emit_csp_entry); the buffer is the block's
+        # concat [x0 | x1 | x2 | x3] with branch0's hidden map appended behind x3, the stacked conv writes [x3 | hidden]
+        b3, b00 = self.branch3[0], self.branch0[0]
+        merged = None if self.has_globel else emit_csp_entry(plan, x, b00, b3, 3 * b3.conv.out_channels, place_inner=False)
+        if merged is not None:
+            hidden, buf = merged
+            ip = b3.conv.out_channels
+            x0 = self.branch0[1].emit(plan, hidden)
+            x1 = _emit_bare(plan, self.branch1, x0)
+            x2 = _emit_bare(plan, self.branch2, x1)
+            for i, t in enumerate((x0, x1, x2)):
+                assert t.buf is None and t.c == ip
+                t.place(buf, i * ip)
+            cat = plan.new(x.n, x.h, x.w, 4 * ip)
+            cat.place(buf, 0)
+            return self.ConvLinear.emit(plan, cat)
         x3 = _emit_seq(plan, self.branch3, x)
         x0 = _emit_seq(plan, self.branch0, x)
         x1 = _emit_bare(plan, self.branch1, x0)
