@@ -378,6 +378,43 @@ int myolo_frame_resize_pack(const uint8_t* frame_hwc, int h0, int w0, int rh, in
 int myolo_seg_blend(const void* labels, int label_dtype, const uint8_t* im0_hwc, int h, int w, const uint8_t* colormap_rgb, int ncls,
                     int swap_rb, float alpha, float beta, float gamma, uint8_t* mask_hwc, uint8_t* dst_hwc, void* stream);
 
+/* ---- training-time augmentation on the device ------------------------------------------------------------ */
+/* SegmentationDataset.py:118-151 `_sync_transform` for one sample, fused (only the crop is computed): img.transpose(FLIP_LEFT_RIGHT)
+ * when flip; img.resize((ow, oh), BILINEAR) / mask.resize((ow, oh), NEAREST); ImageOps.expand to the crop size (fill 0 / 255);
+ * crop (x1, y1, x1+wc, y1+hc); `_mask_transform` (label id -> train id through lab_lut[256], int64).
+ * Pillow's 8-bit resampler: the caller supplies its per-output-pixel tables exactly as precompute_coeffs() / normalize_coeffs_8bpc()
+ * (Resample.c) build them -- hb/vb: int32 [ow|oh][2] = (first source index, tap count); hk/vk: int32 [ow|oh][ksh|ksv] coefficients in
+ * 2^-22 units (identity tables when a dimension is not resized) -- and ImagingScaleAffine's NEAREST index tables xin [ow], yin [oh].
+ * img: uint8 [H0][W0][3]; mask: uint8 [H0][W0]; out_img: uint8 [hc][wc][3] (or NULL); out_lab: int64 [hc][wc] (or NULL).
+ * All pointers are device memory. */
+typedef struct myolo_seg_sync_desc {
+  const uint8_t* img;
+  const uint8_t* mask;
+  int32_t H0, W0, flip, ow, oh;
+  int32_t ksh, ksv;
+  int32_t x1, y1, wc, hc;
+  int32_t reserved;
+  const int32_t* hb;
+  const int32_t* hk;
+  const int32_t* vb;
+  const int32_t* vk;
+  const int32_t* xin;
+  const int32_t* yin;
+  uint8_t* out_img;
+  int64_t* out_lab;
+  const int64_t* lab_lut;
+} myolo_seg_sync_desc;
+int myolo_seg_sync_transform(const myolo_seg_sync_desc* d, void* stream);
+/* torchvision.transforms.ColorJitter on a PIL RGB image + ToTensor (get_citys_loader, SegmentationDataset.py:462-466): the four
+ * adjustments in the order order4[0..3] (0 brightness, 1 contrast, 2 saturation, 3 hue, -1 = skip), Pillow's arithmetic restated
+ * (ImageEnhance / Blend.c float32 blend with (UINT8) truncation, 'L' = (19595R + 38470G + 7471B + 0x8000) >> 16, contrast grey level
+ * int(mean(L) + 0.5) of the image AT THAT STAGE, Convert.c rgb2hsv / hsv2rgb); hue_shift_u8 = the uint8 torchvision adds to the H plane.
+ * img_hwc uint8 [h][w][3]; scratch: device uint64[1] (needed when contrast is in the order); out_hwc: uint8 [h][w][3] or NULL;
+ * out_chw: [3][h][w] of out_dtype = lut256[value] (the caller's 256 values of v/255: ToTensor) or NULL. */
+int myolo_color_jitter(const uint8_t* img_hwc, int h, int w, const int32_t* order4, float brightness, float contrast, float saturation,
+                       int hue_shift_u8, uint64_t* scratch, uint8_t* out_hwc, void* out_chw, int out_dtype, const void* lut256,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -32,6 +32,13 @@ class BnSplit(C.Structure):
                 ('dbeta2', C.c_void_p)]
 
 
+class SegSyncDesc(C.Structure):
+    _fields_ = [('img', C.c_void_p), ('mask', C.c_void_p), ('H0', C.c_int32), ('W0', C.c_int32), ('flip', C.c_int32), ('ow', C.c_int32),
+                ('oh', C.c_int32), ('ksh', C.c_int32), ('ksv', C.c_int32), ('x1', C.c_int32), ('y1', C.c_int32), ('wc', C.c_int32),
+                ('hc', C.c_int32), ('reserved', C.c_int32), ('hb', C.c_void_p), ('hk', C.c_void_p), ('vb', C.c_void_p), ('vk', C.c_void_p),
+                ('xin', C.c_void_p), ('yin', C.c_void_p), ('out_img', C.c_void_p), ('out_lab', C.c_void_p), ('lab_lut', C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('x', Tensor), ('y', Tensor), ('w', C.c_void_p),
                 ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('wtaps', C.c_int32),
@@ -106,6 +113,8 @@ _PROTOS = {
     'myolo_dropout_bwd': (C.c_int, [TP, P, TP, C.c_float, C.c_int, P]),
     'myolo_seg_upsample_fwd': (C.c_int, [TP, P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, P]),
     'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P, P]),
+    'myolo_seg_sync_transform': (C.c_int, [C.POINTER(SegSyncDesc), P]),
+    'myolo_color_jitter': (C.c_int, [P, C.c_int, C.c_int, P, C.c_float, C.c_float, C.c_float, C.c_int, P, P, P, C.c_int, P, P]),
     'myolo_seg_upce_fwd_grad': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
     'myolo_seg_lowgrad_apply': (C.c_int, [P, TP, C.c_int, P, P]),
     'myolo_seg_ce_fwd_grad': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),

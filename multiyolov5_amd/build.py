@@ -23,6 +23,11 @@ def stale():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# augment.hip restates C code compiled for baseline x86-64 (Pillow / OpenCV float arithmetic): a fused multiply-add changes the
+# truncated uint8 results.  hipcc's default -ffp-contract=fast ignores source pragmas, so the whole file is built without contraction.
+PER_FILE_FLAGS = {'augment.hip': ['-ffp-contract=off']}
+
+
 def build(force=False, verbose=True):
     if not force and not stale():
         return LIB
@@ -38,7 +43,7 @@ def build(force=False, verbose=True):
         objs.append(obj)
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), hdr_t):
             continue                                     # object is newer than its source and every header
-        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-c', src, '-o', obj]
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC'] + PER_FILE_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for cmd, p in procs:
         out, _ = p.communicate()

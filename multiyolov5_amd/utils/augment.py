@@ -1,0 +1,199 @@
+"""Training-time augmentation on the device -- host side.
+
+Mirrors the reference's per-sample augmentation entry points (SegmentationDataset.py:118-151 `_sync_transform`, :25-45
+`range_and_prob` / `get_long_size`, :166-183 `_class_to_index`): the random numbers are drawn here with Python's `random` in the
+reference's call order (same seed -> same parameters), the pixels are moved by libmyolo (csrc/augment.hip).  Inputs are uint8
+tensors already on the GPU (a decoded image is uploaded once, 3 bytes per pixel); there is no CPU path.
+"""
+import ctypes as C
+import math
+import random as _random
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+PIL_BITS = 22                                            # Resample.c PRECISION_BITS
+
+
+# ---- Pillow's resampling tables (Resample.c precompute_coeffs / normalize_coeffs_8bpc, BILINEAR = triangle filter, support 1) ---------
+@lru_cache(64)
+def pil_bilinear_tables(in_size, out_size):
+    """(bounds int32 [out,2], coefficients int32 [out,ksize]) of Image.resize(..., BILINEAR) along one axis; identity when the
+    axis is not resized (ImagingResampleInner skips that pass)."""
+    if in_size == out_size:
+        b = np.stack([np.arange(out_size), np.ones(out_size, np.int64)], 1).astype(np.int32)
+        return b, np.full((out_size, 1), 1 << PIL_BITS, np.int32)
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size          # box coordinates are C floats
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / fscale
+    xx = np.arange(out_size, dtype=np.float64)
+    center = 0.0 + (xx + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)           # (int) truncation of non-negative values
+    neg = (center - support + 0.5) < 0
+    xmin = np.where(neg, 0, xmin)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    j = np.arange(ksize, dtype=np.float64)[None, :]
+    arg = np.abs((j + xmin[:, None] - center[:, None] + 0.5) * ss)
+    w = np.where(arg < 1.0, 1.0 - arg, 0.0)
+    w = np.where(j < xmax[:, None], w, 0.0)
+    ww = np.zeros(out_size)
+    for k in range(ksize):                                                     # sequential sum, as the C loop accumulates
+        ww = ww + w[:, k]
+    w = np.where(ww[:, None] != 0.0, w / np.where(ww[:, None] != 0.0, ww[:, None], 1.0), w)
+    kk = np.where(w < 0, (-0.5 + w * (1 << PIL_BITS)), (0.5 + w * (1 << PIL_BITS))).astype(np.int64).astype(np.int32)   # (int) truncates
+    return np.stack([xmin, xmax], 1).astype(np.int32), kk
+
+
+@lru_cache(64)
+def pil_nearest_table(in_size, out_size):
+    """source index of every output index for Image.resize(..., NEAREST) (Geometry.c ImagingScaleAffine: xo = a*0.5, then `xo += a`
+    per pixel -- the running double sum is reproduced, not the closed form)"""
+    a = float(np.float32(in_size) - np.float32(0.0)) / out_size
+    steps = np.full(out_size, a)
+    steps[0] = 0.0 + a * 0.5
+    xo = np.add.accumulate(steps)                                              # sequential double additions
+    return np.where(xo < 0.0, -1, xo.astype(np.int64)).astype(np.int32)
+
+
+# ---- random scale (SegmentationDataset.py:25-45) ----------------------------------------------------------------------------------
+@lru_cache(128)
+def range_and_prob(base_size, low=0.5, high=3.0, std=25):
+    from scipy import stats
+    lo = math.ceil((base_size * low) / 32)
+    hi = math.ceil((base_size * high) / 32)
+    mean = math.ceil(base_size / 32) - 4
+    x = np.array(list(range(lo, hi + 1)))
+    p = stats.norm.pdf(x, mean, std)
+    p = p / p.sum()
+    return x, np.cumsum(p)
+
+
+def get_long_size(base_size, low=0.5, high=3.0, std=40, rng=_random):
+    x, cum_p = range_and_prob(base_size, low, high, std)
+    return int(rng.choices(population=x, cum_weights=cum_p, k=1)[0] * 32)
+
+
+def city_label_lut():
+    """CitySegmentation._class_to_index (SegmentationDataset.py:166-183) as a 256-entry table: 255 (padding) -> id 0 -> -1, id v ->
+    _key[v + 1]; ids the reference asserts against (34..254) map to -1"""
+    key = np.array([-1, -1, -1, -1, -1, -1, -1, -1, 0, 1, -1, -1, 2, 3, 4, -1, -1, -1, 5, -1, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+                    -1, -1, 16, 17, 18], np.int64)
+    lut = np.full(256, -1, np.int64)
+    lut[:34] = key[1:35]
+    lut[255] = key[1]
+    return lut
+
+
+def draw_sync_params(w, h, base_size, crop_size, low=0.65, high=3.0, std=25, rng=_random):
+    """the random decisions of `_sync_transform` (SegmentationDataset.py:118-151) for a (w, h) image, in its call order:
+    random.random() (mirror) -> get_long_size (one random.choices) -> random.randint x 2 (crop origin)"""
+    flip = rng.random() < 0.5
+    wc, hc = crop_size
+    long_size = get_long_size(base_size, low, high, std, rng)
+    if h > w:
+        oh = long_size
+        ow = int(1.0 * w * long_size / h + 0.5)
+    else:
+        ow = long_size
+        oh = int(1.0 * h * long_size / w + 0.5)
+    pw, ph = max(ow, wc), max(oh, hc)                           # size after ImageOps.expand
+    x1 = rng.randint(0, pw - wc)
+    y1 = rng.randint(0, ph - hc)
+    return {'flip': bool(flip), 'ow': int(ow), 'oh': int(oh), 'x1': int(x1), 'y1': int(y1), 'wc': int(wc), 'hc': int(hc)}
+
+
+_DEV_TABLES = {}
+
+
+def _dev(arr, device, key):
+    k = (str(device), key)
+    t = _DEV_TABLES.get(k)
+    if t is None:
+        if len(_DEV_TABLES) > 256:
+            _DEV_TABLES.clear()
+        t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
+        _DEV_TABLES[k] = t
+    return t
+
+
+def seg_sync_transform(img, mask, params, lab_lut=None):
+    """img: uint8 [H0,W0,3] (RGB, as `Image.open(...).convert('RGB')`) and mask: uint8 [H0,W0] on the GPU; params from
+    draw_sync_params.  Returns (crop uint8 [hc,wc,3], label int64 [hc,wc]) = `_sync_transform` + `_mask_transform`."""
+    L.require_gpu(img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
+        raise L.MyoloError('image must be a contiguous uint8 [H,W,3] tensor')
+    H0, W0 = int(img.shape[0]), int(img.shape[1])
+    if mask is not None and (mask.dtype != torch.uint8 or tuple(mask.shape) != (H0, W0) or not mask.is_contiguous()):
+        raise L.MyoloError('label map must be a contiguous uint8 [H,W] tensor matching the image')
+    dev = img.device
+    ow, oh, wc, hc = params['ow'], params['oh'], params['wc'], params['hc']
+    hb, hk = pil_bilinear_tables(W0, ow)
+    vb, vk = pil_bilinear_tables(H0, oh)
+    d = L.SegSyncDesc()
+    keep = [_dev(hb, dev, ('hb', W0, ow)), _dev(hk, dev, ('hk', W0, ow)), _dev(vb, dev, ('vb', H0, oh)), _dev(vk, dev, ('vk', H0, oh))]
+    d.img, d.H0, d.W0, d.flip, d.ow, d.oh = img.data_ptr(), H0, W0, int(params['flip']), ow, oh
+    d.hb, d.hk, d.vb, d.vk, d.ksh, d.ksv = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), hk.shape[1], vk.shape[1]
+    d.x1, d.y1, d.wc, d.hc = params['x1'], params['y1'], wc, hc
+    out = torch.empty(hc, wc, 3, dtype=torch.uint8, device=dev)
+    d.out_img = out.data_ptr()
+    lab = None
+    if mask is not None:
+        lut = city_label_lut() if lab_lut is None else np.asarray(lab_lut, np.int64)
+        keep += [_dev(pil_nearest_table(W0, ow), dev, ('xin', W0, ow)), _dev(pil_nearest_table(H0, oh), dev, ('yin', H0, oh)),
+                 _dev(lut, dev, ('lut', lut.tobytes()))]
+        lab = torch.empty(hc, wc, dtype=torch.int64, device=dev)
+        d.mask, d.xin, d.yin, d.lab_lut, d.out_lab = mask.data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(), lab.data_ptr()
+    L.check(L.lib().myolo_seg_sync_transform(C.byref(d), L.stream_ptr()), 'myolo_seg_sync_transform')
+    return out, lab
+
+
+# ---- ColorJitter + ToTensor (get_citys_loader: ColorJitter(brightness=0.45, contrast=0.45, saturation=0.45, hue=0.15)) -----------------
+def draw_color_jitter_params(brightness=0.45, contrast=0.45, saturation=0.45, hue=0.15, generator=None):
+    """torchvision.transforms.ColorJitter.get_params (torch-RNG versions, >= 0.9): torch.randperm(4), then one uniform_ each for
+    brightness, contrast, saturation, hue.  (0.8.x shuffled with Python's `random`; torchvision is not installed here, the version
+    the reference ran with is not pinned by requirements.txt -- the order of the draws is "parity unpinned".)"""
+    order = torch.randperm(4, generator=generator).tolist()
+    u = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi, generator=generator))
+    b = u(max(0.0, 1 - brightness), 1 + brightness)
+    c = u(max(0.0, 1 - contrast), 1 + contrast)
+    s = u(max(0.0, 1 - saturation), 1 + saturation)
+    h = u(-hue, hue)
+    return {'order': order, 'brightness': b, 'contrast': c, 'saturation': s, 'hue': h}
+
+
+_LUTS = {}
+
+
+def _unit_lut(device, dtype):
+    """ToTensor's 256 values: uint8 -> float32 `.div(255)` (then cast).  Computed by torch ON THE CPU, where the reference's DataLoader
+    workers run ToTensor: the GPU division by a scalar multiplies by the reciprocal and differs in the last bit for some values."""
+    k = (str(device), dtype)
+    t = _LUTS.get(k)
+    if t is None:
+        t = (torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255)).to(dtype).to(device)
+        _LUTS[k] = t
+    return t
+
+
+def color_jitter(img, params, dtype=torch.float32, return_uint8=False):
+    """img: uint8 [h,w,3] RGB on the GPU.  Returns the jittered image as ToTensor would hand it to the model ([3,h,w] `dtype` in [0,1])
+    or, with return_uint8, the uint8 [h,w,3] PIL-equivalent image."""
+    L.require_gpu(img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
+        raise L.MyoloError('image must be a contiguous uint8 [H,W,3] tensor')
+    h, w = int(img.shape[0]), int(img.shape[1])
+    order = (C.c_int32 * 4)(*[int(o) for o in params['order']])
+    hue_u8 = int(params['hue'] * 255) % 256                 # functional_pil.adjust_hue: np.uint8(hue_factor * 255) added with wrap-around
+    scratch = torch.empty(1, dtype=torch.int64, device=img.device)
+    out_u8 = torch.empty(h, w, 3, dtype=torch.uint8, device=img.device) if return_uint8 else None
+    out_f = None if return_uint8 else torch.empty(3, h, w, dtype=dtype, device=img.device)
+    L.check(L.lib().myolo_color_jitter(L.ptr(img), h, w, order, C.c_float(params['brightness']), C.c_float(params['contrast']),
+                                       C.c_float(params['saturation']), hue_u8, L.ptr(scratch), L.ptr(out_u8) if return_uint8 else None,
+                                       None if return_uint8 else L.ptr(out_f), L.DT.get(dtype, 0) if not return_uint8 else 0,
+                                       None if return_uint8 else L.ptr(_unit_lut(img.device, dtype)), L.stream_ptr()), 'myolo_color_jitter')
+    return out_u8 if return_uint8 else out_f

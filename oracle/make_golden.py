@@ -341,11 +341,81 @@ def boxes_case(ref):
     print('wrote boxes')
 
 
+def augment_inputs(i):
+    """synthetic (RGB uint8 image, Cityscapes label-id map) of case i: smooth gradients + noise so that resampling errors show"""
+    shapes = [(96, 192), (150, 100), (64, 128), (200, 260)]
+    h, w = shapes[i % len(shapes)]
+    rs = np.random.RandomState(100 + i)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), ((xx + yy) * 7) % 256], 2).astype(np.int64)
+    img = np.clip(img + rs.randint(-40, 41, img.shape), 0, 255).astype(np.uint8)
+    ids = np.array([0, 7, 8, 11, 12, 13, 17, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 31, 32, 33, 1, 5], np.uint8)
+    mask = ids[rs.randint(0, len(ids), (h // 8 + 1, w // 8 + 1))].repeat(8, 0).repeat(8, 1)[:h, :w]
+    return img, np.ascontiguousarray(mask)
+
+
+AUG_CASES = [  # (input case, seed, base_size, crop_size (w, h))
+    (0, 1, 128, (64, 48)), (0, 2, 128, (160, 96)), (1, 3, 128, (64, 64)), (2, 4, 96, (96, 64)), (3, 5, 256, (128, 96)), (3, 6, 64, (200, 120)),
+]
+
+
+def augment_case(ref):
+    """SegmentationDataset.py:118-151 `_sync_transform` + :225-228 `_mask_transform`, run from the reference's own classes with PIL
+    (installed here) under a seeded `random`: pins the random call order, Pillow's BILINEAR / NEAREST resize, padding, crop and the
+    label-id table."""
+    import random
+    from PIL import Image
+    import SegmentationDataset as rsd            # the reference's module (repo root)
+    rsd.get_city_pairs = lambda *a, **k: (['x'], ['x'])
+    out = {}
+    for ci, (inp, seed, base, crop) in enumerate(AUG_CASES):
+        ds = rsd.CitySegmentation(root='.', split='train', mode='train', base_size=base, crop_size=crop, low=0.65, high=3, sample_std=25)
+        img, mask = augment_inputs(inp)
+        random.seed(seed)
+        a, b = ds._sync_transform(Image.fromarray(img), Image.fromarray(mask))
+        lab = ds._mask_transform(b)
+        out[f'c{ci}.img'] = np.array(a)
+        out[f'c{ci}.lab'] = lab.numpy().astype(np.int8)
+        out[f'c{ci}.after'] = np.float64(random.random())            # the generator state after the transform (same number of draws)
+    np.savez_compressed(os.path.join(GOLD, 'augment_seg.npz'), **out)
+    print('augment_seg', {k: v.shape for k, v in out.items() if k.endswith('img')})
+
+
+JITTER_CASES = [  # (input case, order, brightness, contrast, saturation, hue)
+    (0, (0, 1, 2, 3), 1.2, 0.8, 1.3, 0.05), (1, (3, 2, 1, 0), 0.6, 1.4, 0.7, -0.12), (2, (1, 3, 0, 2), 1.45, 0.55, 1.45, 0.15),
+    (3, (2, 0, 3, 1), 0.9, 1.0, 0.0, -0.15), (0, (3, 1, 2, 0), 1.0, 1.2, 1.0, 0.0),
+]
+
+
+def jitter_case(ref):
+    """ColorJitter's four adjustments through the REAL Pillow (ImageEnhance.Brightness/Contrast/Color, convert('HSV')), composed as
+    torchvision's functional_pil.py composes them (torchvision itself is not installed)"""
+    from PIL import Image, ImageEnhance
+    out = {}
+    for ci, (inp, order, b, c, sat, hue) in enumerate(JITTER_CASES):
+        img = Image.fromarray(augment_inputs(inp)[0])
+        for op in order:
+            if op == 0:
+                img = ImageEnhance.Brightness(img).enhance(b)
+            elif op == 1:
+                img = ImageEnhance.Contrast(img).enhance(c)
+            elif op == 2:
+                img = ImageEnhance.Color(img).enhance(sat)
+            else:                                             # functional_pil.adjust_hue
+                h, s_, v = img.convert('HSV').split()
+                np_h = np.array(h, dtype=np.uint8)
+                np_h = (np_h.astype(np.int64) + int(hue * 255)).astype(np.uint8)       # uint8 wrap-around add
+                img = Image.merge('HSV', (Image.fromarray(np_h, 'L'), s_, v)).convert('RGB')
+        out[f'c{ci}'] = np.array(img)
+    np.savez_compressed(os.path.join(GOLD, 'augment_jitter.npz'), **out)
+    print('augment_jitter', len(out))
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ['models', 'blocks', 'losses', 'nms', 'metrics', 'match', 'letterbox', 'boxes']
+    which = sys.argv[1:] or ['models', 'blocks', 'losses', 'nms', 'metrics', 'match', 'letterbox', 'boxes', 'augment']
     if 'models' in which:
         model_case(ref, 'yolov5s_city_seg.yaml', 's_psp', True)
         model_case(ref, 'yolov5s_city_seg_base.yaml', 's_base', True)
@@ -368,6 +438,9 @@ def main():
         letterbox_case(ref)
     if 'boxes' in which:
         boxes_case(ref)
+    if 'augment' in which:
+        augment_case(ref)
+        jitter_case(ref)
 
 
 if __name__ == '__main__':

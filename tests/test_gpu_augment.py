@@ -1,0 +1,109 @@
+"""-m gpu: training-time augmentation kernels (csrc/augment.hip) through the host mirror, bit-exact against the oracle and the golden
+the reference's own `_sync_transform` wrote (SegmentationDataset.py:118-151 on the real Pillow)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aug_ref
+from oracle.make_golden import AUG_CASES, augment_inputs
+from tests.util import golden
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+@pytest.mark.parametrize('ci', range(len(AUG_CASES)))
+def test_seg_sync_transform_matches_reference_golden(ci):
+    from multiyolov5_amd.utils import augment as A
+    g = golden('augment_seg')
+    inp, seed, base, crop = AUG_CASES[ci]
+    img, mask = augment_inputs(inp)
+    p = A.draw_sync_params(img.shape[1], img.shape[0], base, crop, rng=random.Random(seed))
+    a, lab = A.seg_sync_transform(torch.from_numpy(img).to(DEV), torch.from_numpy(mask).to(DEV), p)
+    assert a.dtype == torch.uint8 and lab.dtype == torch.int64
+    assert np.array_equal(a.cpu().numpy(), g[f'c{ci}.img'])
+    assert np.array_equal(lab.cpu().numpy(), g[f'c{ci}.lab'].astype(np.int64))
+
+
+@pytest.mark.parametrize('case', [
+    # H0, W0, flip, ow, oh, x1, y1, wc, hc
+    (64, 128, 1, 128, 64, 0, 0, 128, 64),            # no resampling at all (identity tables), mirrored
+    (64, 128, 0, 384, 192, 100, 50, 160, 96),        # x3 up-scale, interior crop
+    (96, 200, 1, 67, 32, 0, 0, 96, 64),              # x3 down-scale (7-tap filter), padded on both sides
+    (33, 47, 0, 47, 80, 3, 10, 40, 64),              # vertical pass only
+    (80, 33, 1, 70, 80, 0, 0, 70, 80),               # horizontal pass only
+    (256, 512, 0, 736, 368, 17, 5, 512, 256),        # a Cityscapes-like ratio
+])
+def test_seg_sync_transform_vs_oracle(case):
+    from multiyolov5_amd.utils import augment as A
+    H0, W0, flip, ow, oh, x1, y1, wc, hc = case
+    rs = np.random.RandomState(H0 + W0)
+    img = rs.randint(0, 256, (H0, W0, 3)).astype(np.uint8)
+    ids = np.array(list(range(34)) + [255], np.uint8)
+    mask = ids[rs.randint(0, len(ids), (H0, W0))]
+    p = dict(flip=bool(flip), ow=ow, oh=oh, x1=x1, y1=y1, wc=wc, hc=hc)
+    want_img, want_lab = aug_ref.sync_transform(img, mask, p)
+    a, lab = A.seg_sync_transform(torch.from_numpy(img).to(DEV), torch.from_numpy(mask).to(DEV), p)
+    assert np.array_equal(a.cpu().numpy(), want_img)
+    assert np.array_equal(lab.cpu().numpy(), want_lab)
+    # image only
+    a2, lab2 = A.seg_sync_transform(torch.from_numpy(img).to(DEV), None, p)
+    assert lab2 is None and torch.equal(a2, a)
+
+
+def test_seg_sync_transform_rejects_cpu_and_bad_layouts():
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd.utils import augment as A
+    p = dict(flip=False, ow=8, oh=8, x1=0, y1=0, wc=8, hc=8)
+    with pytest.raises(L.MyoloError):
+        A.seg_sync_transform(torch.zeros(8, 8, 3, dtype=torch.uint8), None, p)
+    with pytest.raises(L.MyoloError):
+        A.seg_sync_transform(torch.zeros(8, 8, 3, device=DEV), None, p)
+    with pytest.raises(L.MyoloError):
+        A.seg_sync_transform(torch.zeros(8, 8, 3, dtype=torch.uint8, device=DEV), torch.zeros(4, 4, dtype=torch.uint8, device=DEV), p)
+
+
+def test_color_jitter_matches_pillow_golden_and_oracle():
+    from multiyolov5_amd.utils import augment as A
+    from oracle.make_golden import JITTER_CASES
+    g = golden('augment_jitter')
+    for ci, (inp, order, b, c, s, h) in enumerate(JITTER_CASES):
+        img, _ = augment_inputs(inp)
+        p = dict(order=list(order), brightness=b, contrast=c, saturation=s, hue=h)
+        d = torch.from_numpy(img).to(DEV)
+        u8 = A.color_jitter(d, p, return_uint8=True)
+        assert np.array_equal(u8.cpu().numpy(), g[f'c{ci}']), ci
+        for dt in (torch.float32, torch.float16):                      # ToTensor: uint8 -> float32 / 255 (-> model dtype), CHW
+            t = A.color_jitter(d, p, dtype=dt)
+            want = (torch.from_numpy(g[f'c{ci}']).permute(2, 0, 1).float() / 255).to(dt)
+            assert t.shape == want.shape and torch.equal(t.cpu(), want)
+
+
+def test_color_jitter_partial_orders_and_every_hue_shift():
+    from multiyolov5_amd.utils import augment as A
+    rs = np.random.RandomState(3)
+    img = rs.randint(0, 256, (64, 96, 3)).astype(np.uint8)
+    img[0, :6] = [[0, 0, 0], [255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [9, 9, 9]]
+    d = torch.from_numpy(img).to(DEV)
+    for order, b, c, s, h in (((0, -1, -1, -1), 1.3, 1.0, 1.0, 0.0), ((-1, -1, 3, -1), 1.0, 1.0, 1.0, 0.37), ((2, -1, -1, 1), 1.0, 0.3, 1.8, 0.0),
+                              ((-1, -1, -1, -1), 1.0, 1.0, 1.0, 0.0)):
+        got = A.color_jitter(d, dict(order=list(order), brightness=b, contrast=c, saturation=s, hue=h), return_uint8=True).cpu().numpy()
+        assert np.array_equal(got, aug_ref.color_jitter(img, [o for o in order if o >= 0], b, c, s, h)), order
+    for shift in range(0, 256, 7):
+        h = shift / 255.0 + 1e-9 if shift < 128 else (shift - 256) / 255.0 - 1e-9
+        got = A.color_jitter(d, dict(order=[3, -1, -1, -1], brightness=1, contrast=1, saturation=1, hue=h), return_uint8=True).cpu().numpy()
+        assert np.array_equal(got, aug_ref.color_jitter(img, [3], 1, 1, 1, h)), shift
+
+
+def test_hue_round_trip_over_all_colours():
+    """2^24 colours through rgb -> hsv -> (+0) -> rgb on the device against the numpy restatement (itself pinned to Pillow)"""
+    from multiyolov5_amd.utils import augment as A
+    v = np.arange(256, dtype=np.uint8)
+    for r0 in range(0, 256, 64):
+        rr, gg, bb = np.meshgrid(v[r0:r0 + 64], v, v, indexing='ij')
+        a = np.ascontiguousarray(np.stack([rr, gg, bb], -1).reshape(64 * 256, 256, 3))
+        got = A.color_jitter(torch.from_numpy(a).to(DEV), dict(order=[3, -1, -1, -1], brightness=1, contrast=1, saturation=1, hue=0.1),
+                             return_uint8=True).cpu().numpy()
+        assert np.array_equal(got, aug_ref.color_jitter(a, [3], 1, 1, 1, 0.1)), r0
