@@ -415,6 +415,32 @@ int myolo_color_jitter(const uint8_t* img_hwc, int h, int w, const int32_t* orde
                        int hue_shift_u8, uint64_t* scratch, uint8_t* out_hwc, void* out_chw, int out_dtype, const void* lut256,
                        void* stream);
 
+/* cv2.resize(img, (rw, rh), interpolation=cv2.INTER_LINEAR) on a uint8 HWC image (load_image, utils/datasets.py:638-640), the
+ * arithmetic of myolo_frame_resize_pack with HWC uint8 output */
+int myolo_resize_u8(const uint8_t* img_hwc, int h0, int w0, int rh, int rw, uint8_t* out_hwc, void* stream);
+/* One detection training sample, fused (utils/datasets.py): load_mosaic's canvas (672-711: up to 4 source images pasted at
+ * [y1a:y2a, x1a:x2a] = img[y1a-padh : , x1a-padw : ] on a cw x ch canvas of `fill`) -> random_perspective's cv2.warpAffine(img, M[:2],
+ * dsize=(ow, oh), borderValue=fill) (851-895; M = the dst->src matrix, i.e. ALREADY inverted the way cv::warpAffine inverts its
+ * argument; warp = 0 copies the canvas) -> augment_hsv (646-658; hsv_lut = uint8 [3][256] hue/sat/val tables, NULL = skip) -> flipud /
+ * fliplr (574-584) -> out_chw uint8 [3][oh][ow] RGB (590: img[:, :, ::-1].transpose(2, 0, 1)) and/or out_hwc uint8 [oh][ow][3] BGR.
+ * A single source covering the canvas gives the non-mosaic path (letterboxed image -> random_perspective). */
+typedef struct myolo_mosaic_src {
+  const uint8_t* img;            /* uint8 [h][w][3] BGR, device */
+  int32_t h, w;
+  int32_t x1a, y1a, x2a, y2a;    /* window on the canvas */
+  int32_t padw, padh;            /* canvas = source + pad */
+} myolo_mosaic_src;
+typedef struct myolo_mosaic_desc {
+  myolo_mosaic_src src[4];
+  int32_t nsrc, cw, ch, warp;
+  double  M[6];
+  int32_t ow, oh, fliplr, flipud, fill, reserved;
+  const uint8_t* hsv_lut;
+  uint8_t* out_chw;
+  uint8_t* out_hwc;
+} myolo_mosaic_desc;
+int myolo_mosaic_warp(const myolo_mosaic_desc* d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

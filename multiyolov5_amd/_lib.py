@@ -39,6 +39,17 @@ class SegSyncDesc(C.Structure):
                 ('xin', C.c_void_p), ('yin', C.c_void_p), ('out_img', C.c_void_p), ('out_lab', C.c_void_p), ('lab_lut', C.c_void_p)]
 
 
+class MosaicSrc(C.Structure):
+    _fields_ = [('img', C.c_void_p), ('h', C.c_int32), ('w', C.c_int32), ('x1a', C.c_int32), ('y1a', C.c_int32), ('x2a', C.c_int32),
+                ('y2a', C.c_int32), ('padw', C.c_int32), ('padh', C.c_int32)]
+
+
+class MosaicDesc(C.Structure):
+    _fields_ = [('src', MosaicSrc * 4), ('nsrc', C.c_int32), ('cw', C.c_int32), ('ch', C.c_int32), ('warp', C.c_int32),
+                ('M', C.c_double * 6), ('ow', C.c_int32), ('oh', C.c_int32), ('fliplr', C.c_int32), ('flipud', C.c_int32),
+                ('fill', C.c_int32), ('reserved', C.c_int32), ('hsv_lut', C.c_void_p), ('out_chw', C.c_void_p), ('out_hwc', C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [('x', Tensor), ('y', Tensor), ('w', C.c_void_p),
                 ('cin_pad', C.c_int32), ('cout_pad', C.c_int32), ('wtaps', C.c_int32),
@@ -115,6 +126,8 @@ _PROTOS = {
     'myolo_seg_upsample_bwd': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, C.c_int64, TP, C.c_int, P, P]),
     'myolo_seg_sync_transform': (C.c_int, [C.POINTER(SegSyncDesc), P]),
     'myolo_color_jitter': (C.c_int, [P, C.c_int, C.c_int, P, C.c_float, C.c_float, C.c_float, C.c_int, P, P, P, C.c_int, P, P]),
+    'myolo_resize_u8': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
+    'myolo_mosaic_warp': (C.c_int, [C.POINTER(MosaicDesc), P]),
     'myolo_seg_upce_fwd_grad': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
     'myolo_seg_lowgrad_apply': (C.c_int, [P, TP, C.c_int, P, P]),
     'myolo_seg_ce_fwd_grad': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),

@@ -231,3 +231,179 @@ extern "C" int myolo_color_jitter(const uint8_t* img_hwc, int h, int w, const in
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------- detection: mosaic + warp + HSV
+// utils/datasets.py:672-724 load_mosaic (4 images on a 2s x 2s grey canvas) -> :851-895 random_perspective (cv2.warpAffine, INTER_LINEAR,
+// borderValue 114, output s x s) -> :646-658 augment_hsv -> :574-584 flips -> :590 BGR->RGB, HWC->CHW, fused: an output pixel is traced
+// back through the affine map to (at most) four canvas pixels, each of which is a pixel of one source image or the grey border; the
+// 2s x 2s canvas never exists.  OpenCV is not installed here: its 8-bit arithmetic is restated (imgwarp.cpp warpAffine + remapBilinear:
+// AB_BITS 10, INTER_BITS 5, weights (32-a)(32-b)*32 summing to 2^15; color_hsv RGB2HSV_b integer tables / HSV2RGB float) -- "parity
+// unpinned", as for letterbox's cv2.resize.
+namespace {
+
+struct MosaicSrc { const uint8_t* img; int h, w; int x1a, y1a, x2a, y2a; int padw, padh; };
+struct MosaicWarp {
+  MosaicSrc src[4]; int nsrc;
+  int cw, ch;                          // canvas size
+  double M[6];                         // dst -> src affine, inverted by the host the way cv::warpAffine inverts it
+  int warp;                            // 0: the canvas is copied (identity matrix and no border: random_perspective's `image changed` test)
+  int ow, oh;
+  const uint8_t* lut;                  // [3][256] hue / sat / val tables of augment_hsv, or NULL
+  int fliplr, flipud, fill;
+  uint8_t* out_chw; uint8_t* out_hwc;
+};
+
+__device__ __forceinline__ void canvas_px(const MosaicWarp& p, int X, int Y, int& b, int& g, int& r) {
+  b = g = r = p.fill;
+  if ((unsigned)X >= (unsigned)p.cw || (unsigned)Y >= (unsigned)p.ch) return;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (k >= p.nsrc) break;
+    const MosaicSrc& s = p.src[k];
+    if (X >= s.x1a && X < s.x2a && Y >= s.y1a && Y < s.y2a) {
+      const uint8_t* q = s.img + ((int64_t)(Y - s.padh) * s.w + (X - s.padw)) * 3;
+      b = q[0]; g = q[1]; r = q[2];
+      return;
+    }
+  }
+}
+
+__device__ __forceinline__ int cv_round(double v) { return (int)rint(v); }          // cvRound: round half to even
+
+__device__ void hsv_lut_bgr(int& b, int& g, int& r, const uint8_t* lut, const int* sdiv, const int* hdiv) {
+  // cv2.cvtColor(BGR2HSV) on uint8 (H in [0,180))
+  int v = max(b, max(g, r)), vmin = min(b, min(g, r));
+  const int diff = v - vmin;
+  const int vr = v == r ? -1 : 0, vg = v == g ? -1 : 0;
+  int s = (diff * sdiv[v] + (1 << 11)) >> 12;
+  int h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))));
+  h = (h * hdiv[diff] + (1 << 11)) >> 12;
+  h += h < 0 ? 180 : 0;
+  h = clip8(h);
+  // cv2.LUT per plane
+  h = lut[h]; s = lut[256 + (s & 255)]; v = lut[512 + v];
+  // cv2.cvtColor(HSV2BGR) on uint8: float path
+  const float fs = (float)s * (1.f / 255.f), fv = (float)v * (1.f / 255.f);
+  float fb, fg, fr;
+  if (s == 0) fb = fg = fr = fv;
+  else {
+    float fh = (float)h * (6.f / 180.f);
+    fh = fmodf(fh, 6.f);
+    int sector = (int)floorf(fh);
+    fh -= (float)sector;
+    if ((unsigned)sector >= 6u) { sector = 0; fh = 0.f; }
+    float tab[4];
+    tab[0] = fv; tab[1] = fv * (1.f - fs); tab[2] = fv * (1.f - fs * fh); tab[3] = fv * (1.f - fs * (1.f - fh));
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    fb = tab[sd[sector][0]]; fg = tab[sd[sector][1]]; fr = tab[sd[sector][2]];
+  }
+  b = clip8((int)rintf(fb * 255.f)); g = clip8((int)rintf(fg * 255.f)); r = clip8((int)rintf(fr * 255.f));
+}
+
+__global__ __launch_bounds__(256) void mosaic_warp_kernel(const MosaicWarp p) {
+  __shared__ int sdiv[256], hdiv[256];
+  {
+    const int i = threadIdx.x;
+    sdiv[i] = i ? cv_round((double)(255 << 12) / (1. * i)) : 0;
+    hdiv[i] = i ? cv_round((double)(180 << 12) / (6. * i)) : 0;
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)p.oh * p.ow;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int y = (int)(i / p.ow), x = (int)(i - (int64_t)y * p.ow);
+    int b, g, r;
+    if (!p.warp) canvas_px(p, x, y, b, g, r);
+    else {
+      const int adx = cv_round(p.M[0] * x * 1024.), bdx = cv_round(p.M[3] * x * 1024.);
+      const int X0 = cv_round((p.M[1] * y + p.M[2]) * 1024.) + 16, Y0 = cv_round((p.M[4] * y + p.M[5]) * 1024.) + 16;
+      const int X = (X0 + adx) >> 5, Y = (Y0 + bdx) >> 5;
+      int sx = X >> 5, sy = Y >> 5;
+      sx = sx < -32768 ? -32768 : (sx > 32767 ? 32767 : sx); sy = sy < -32768 ? -32768 : (sy > 32767 ? 32767 : sy);   // saturate_cast<short>
+      const int fa = Y & 31, fb_ = X & 31;
+      const int w00 = (32 - fa) * (32 - fb_) * 32, w01 = (32 - fa) * fb_ * 32, w10 = fa * (32 - fb_) * 32, w11 = fa * fb_ * 32;
+      int b0, g0, r0, b1, g1, r1, b2, g2, r2, b3, g3, r3;
+      canvas_px(p, sx, sy, b0, g0, r0); canvas_px(p, sx + 1, sy, b1, g1, r1);
+      canvas_px(p, sx, sy + 1, b2, g2, r2); canvas_px(p, sx + 1, sy + 1, b3, g3, r3);
+      b = clip8((b0 * w00 + b1 * w01 + b2 * w10 + b3 * w11 + (1 << 14)) >> 15);
+      g = clip8((g0 * w00 + g1 * w01 + g2 * w10 + g3 * w11 + (1 << 14)) >> 15);
+      r = clip8((r0 * w00 + r1 * w01 + r2 * w10 + r3 * w11 + (1 << 14)) >> 15);
+    }
+    if (p.lut) hsv_lut_bgr(b, g, r, p.lut, sdiv, hdiv);
+    const int oy = p.flipud ? p.oh - 1 - y : y, ox = p.fliplr ? p.ow - 1 - x : x;
+    const int64_t o = (int64_t)oy * p.ow + ox;
+    if (p.out_chw) { p.out_chw[o] = (uint8_t)r; p.out_chw[total + o] = (uint8_t)g; p.out_chw[2 * total + o] = (uint8_t)b; }
+    if (p.out_hwc) { p.out_hwc[o * 3] = (uint8_t)b; p.out_hwc[o * 3 + 1] = (uint8_t)g; p.out_hwc[o * 3 + 2] = (uint8_t)r; }
+  }
+}
+
+// cv2.resize(img, (rw, rh), interpolation=cv2.INTER_LINEAR) on uint8 HWC (load_image, datasets.py:638-640): the arithmetic of
+// frame.hip's letterbox resampler, HWC in -> HWC out
+__global__ __launch_bounds__(256) void resize_u8_kernel(const uint8_t* __restrict__ im, int h0, int w0, int rh, int rw, uint8_t* __restrict__ out,
+                                                        double scale_x, double scale_y, int area2) {
+  const int64_t total = (int64_t)rh * rw;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int dy = (int)(i / rw), dx = (int)(i - (int64_t)dy * rw);
+    int c3[3];
+    if (area2) {
+      const uint8_t* p0 = im + ((int64_t)(2 * dy) * w0 + 2 * dx) * 3;
+      const uint8_t* p1 = p0 + (int64_t)w0 * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) c3[c] = (p0[c] + p0[3 + c] + p1[c] + p1[3 + c] + 2) >> 2;
+    } else {
+      float fx = (float)(((double)dx + 0.5) * scale_x - 0.5);
+      int sx = (int)floorf(fx);
+      fx -= (float)sx;
+      if (sx < 0) { fx = 0.f; sx = 0; }
+      if (sx >= w0 - 1) { fx = 0.f; sx = w0 - 1; }
+      float fy = (float)(((double)dy + 0.5) * scale_y - 0.5);
+      const int sy = (int)floorf(fy);
+      fy -= (float)sy;
+      const int a0 = (int)rintf((1.f - fx) * 2048.f), a1 = (int)rintf(fx * 2048.f), b0 = (int)rintf((1.f - fy) * 2048.f), b1 = (int)rintf(fy * 2048.f);
+      const int x1 = sx + 1 < w0 ? sx + 1 : w0 - 1;
+      const int y0 = sy < 0 ? 0 : (sy > h0 - 1 ? h0 - 1 : sy), y1 = sy + 1 < 0 ? 0 : (sy + 1 > h0 - 1 ? h0 - 1 : sy + 1);
+      const uint8_t* r0 = im + (int64_t)y0 * w0 * 3;
+      const uint8_t* r1 = im + (int64_t)y1 * w0 * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int h0v = r0[sx * 3 + c] * a0 + r0[x1 * 3 + c] * a1;
+        const int h1v = r1[sx * 3 + c] * a0 + r1[x1 * 3 + c] * a1;
+        c3[c] = clip8((((b0 * (h0v >> 4)) >> 16) + ((b1 * (h1v >> 4)) >> 16) + 2) >> 2);
+      }
+    }
+    out[i * 3] = (uint8_t)c3[0]; out[i * 3 + 1] = (uint8_t)c3[1]; out[i * 3 + 2] = (uint8_t)c3[2];
+  }
+}
+
+}  // namespace
+
+extern "C" int myolo_resize_u8(const uint8_t* img_hwc, int h0, int w0, int rh, int rw, uint8_t* out_hwc, void* stream) {
+  if (!img_hwc || !out_hwc || h0 < 1 || w0 < 1 || rh < 1 || rw < 1) return MYOLO_EINVAL;
+  const int area2 = (w0 == 2 * rw && h0 == 2 * rh) ? 1 : 0;
+  hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for((int64_t)rh * rw, 256, 4096)), dim3(256), 0, (hipStream_t)stream, img_hwc, h0, w0, rh, rw,
+                     out_hwc, (double)w0 / rw, (double)h0 / rh, area2);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_mosaic_warp(const myolo_mosaic_desc* d, void* stream) {
+  if (!d || d->nsrc < 1 || d->nsrc > 4 || d->cw < 1 || d->ch < 1 || d->ow < 1 || d->oh < 1 || (!d->out_chw && !d->out_hwc)) return MYOLO_EINVAL;
+  MosaicWarp k;
+  k.nsrc = d->nsrc;
+  for (int i = 0; i < d->nsrc; ++i) {
+    const myolo_mosaic_src& s = d->src[i];
+    if (!s.img || s.h < 1 || s.w < 1) return MYOLO_EINVAL;
+    // the pasted window must lie inside both the canvas and the source image
+    if (s.x1a < 0 || s.y1a < 0 || s.x2a > d->cw || s.y2a > d->ch || s.x1a - s.padw < 0 || s.y1a - s.padh < 0 ||
+        s.x2a - s.padw > s.w || s.y2a - s.padh > s.h)
+      return MYOLO_EINVAL;
+    k.src[i] = MosaicSrc{s.img, s.h, s.w, s.x1a, s.y1a, s.x2a, s.y2a, s.padw, s.padh};
+  }
+  k.cw = d->cw; k.ch = d->ch; k.warp = d->warp; k.ow = d->ow; k.oh = d->oh;
+  for (int i = 0; i < 6; ++i) k.M[i] = d->M[i];
+  if (!d->warp && (d->ow != d->cw || d->oh != d->ch)) return MYOLO_EINVAL;
+  k.lut = d->hsv_lut; k.fliplr = d->fliplr; k.flipud = d->flipud; k.fill = d->fill & 255;
+  k.out_chw = d->out_chw; k.out_hwc = d->out_hwc;
+  hipLaunchKernelGGL(mosaic_warp_kernel, dim3(grid_for((int64_t)d->oh * d->ow, 256, 8192)), dim3(256), 0, (hipStream_t)stream, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}

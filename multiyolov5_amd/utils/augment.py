@@ -197,3 +197,195 @@ def color_jitter(img, params, dtype=torch.float32, return_uint8=False):
                                        None if return_uint8 else L.ptr(out_f), L.DT.get(dtype, 0) if not return_uint8 else 0,
                                        None if return_uint8 else L.ptr(_unit_lut(img.device, dtype)), L.stream_ptr()), 'myolo_color_jitter')
     return out_u8 if return_uint8 else out_f
+
+
+# ---- detection samples: mosaic + random_perspective + augment_hsv + flips (utils/datasets.py:518-593, 646-658, 672-724, 851-937) --------
+def resize_u8(img, rw, rh):
+    """cv2.resize(img, (rw, rh), interpolation=cv2.INTER_LINEAR) of load_image (datasets.py:638-640) on the device"""
+    L.require_gpu(img)
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
+        raise L.MyoloError('image must be a contiguous uint8 [H,W,3] tensor')
+    out = torch.empty(int(rh), int(rw), 3, dtype=torch.uint8, device=img.device)
+    L.check(L.lib().myolo_resize_u8(L.ptr(img), int(img.shape[0]), int(img.shape[1]), int(rh), int(rw), L.ptr(out), L.stream_ptr()),
+            'myolo_resize_u8')
+    return out
+
+
+def load_image_dev(img0, img_size):
+    """load_image (datasets.py:629-641) for a training (augment=True) dataset: long side -> img_size, always INTER_LINEAR"""
+    h0, w0 = int(img0.shape[0]), int(img0.shape[1])
+    r = img_size / max(h0, w0)
+    if r != 1:
+        img0 = resize_u8(img0, int(w0 * r), int(h0 * r))
+    return img0, (h0, w0), (int(img0.shape[0]), int(img0.shape[1]))
+
+
+def _boxes_norm_to_pixels(b, w, h, padw, padh):
+    """general.xywhn2xyxy: normalised centre boxes -> pixel corner boxes shifted by the paste offset (dtype of `b` is kept)"""
+    out = np.copy(b)
+    half_w, half_h = b[:, 2] / 2, b[:, 3] / 2
+    out[:, 0] = w * (b[:, 0] - half_w) + padw
+    out[:, 1] = h * (b[:, 1] - half_h) + padh
+    out[:, 2] = w * (b[:, 0] + half_w) + padw
+    out[:, 3] = h * (b[:, 1] + half_h) + padh
+    return out
+
+
+def mosaic_layout(s, yc, xc, hw4):
+    """the four paste windows of load_mosaic (datasets.py:684-699): per image (x1a, y1a, x2a, y2a) on the 2s x 2s canvas and the
+    offsets (padw, padh) = canvas - source coordinates"""
+    lay = []
+    for i, (h, w) in enumerate(hw4):
+        if i == 0:                                                   # top left: bottom-right corner of the image at the centre
+            x1a, y1a, x2a, y2a = max(xc - w, 0), max(yc - h, 0), xc, yc
+            x1b, y1b = w - (x2a - x1a), h - (y2a - y1a)
+        elif i == 1:                                                 # top right
+            x1a, y1a, x2a, y2a = xc, max(yc - h, 0), min(xc + w, s * 2), yc
+            x1b, y1b = 0, h - (y2a - y1a)
+        elif i == 2:                                                 # bottom left
+            x1a, y1a, x2a, y2a = max(xc - w, 0), yc, xc, min(s * 2, yc + h)
+            x1b, y1b = w - (x2a - x1a), 0
+        else:                                                        # bottom right
+            x1a, y1a, x2a, y2a = xc, yc, min(xc + w, s * 2), min(s * 2, yc + h)
+            x1b, y1b = 0, 0
+        lay.append((x1a, y1a, x2a, y2a, x1a - x1b, y1a - y1b))
+    return lay
+
+
+def draw_perspective_matrix(shape_hw, hyp, border, rng=_random):
+    """random_perspective's matrix (datasets.py:857-888) with its `random` calls in order; returns (M 3x3, scale s, (width, height))"""
+    height, width = shape_hw[0] + border[0] * 2, shape_hw[1] + border[1] * 2
+    Cm = np.eye(3)
+    Cm[0, 2], Cm[1, 2] = -shape_hw[1] / 2, -shape_hw[0] / 2
+    Pm = np.eye(3)
+    Pm[2, 0] = rng.uniform(-hyp['perspective'], hyp['perspective'])
+    Pm[2, 1] = rng.uniform(-hyp['perspective'], hyp['perspective'])
+    a = rng.uniform(-hyp['degrees'], hyp['degrees'])
+    sc = rng.uniform(1 - hyp['scale'], 1 + hyp['scale'])
+    Rm = np.eye(3)
+    ang = a * np.pi / 180.0                                           # cv2.getRotationMatrix2D(angle=a, center=(0, 0), scale=sc)
+    alpha, beta = math.cos(ang) * sc, math.sin(ang) * sc
+    Rm[0] = [alpha, beta, 0.0]
+    Rm[1] = [-beta, alpha, 0.0]
+    Sm = np.eye(3)
+    Sm[0, 1] = math.tan(rng.uniform(-hyp['shear'], hyp['shear']) * math.pi / 180)
+    Sm[1, 0] = math.tan(rng.uniform(-hyp['shear'], hyp['shear']) * math.pi / 180)
+    Tm = np.eye(3)
+    Tm[0, 2] = rng.uniform(0.5 - hyp['translate'], 0.5 + hyp['translate']) * width
+    Tm[1, 2] = rng.uniform(0.5 - hyp['translate'], 0.5 + hyp['translate']) * height
+    return Tm @ Sm @ Rm @ Pm @ Cm, sc, (width, height)
+
+
+def warp_boxes(targets, M, sc, width, height):
+    """random_perspective's label half for box labels (datasets.py:903-925): corners through M, new axis-aligned boxes clipped to the
+    output, box_candidates filter (wh > 2 px, area ratio > 0.1, aspect ratio < 20)"""
+    n = len(targets)
+    if not n:
+        return targets
+    corners = np.ones((n * 4, 3))
+    corners[:, :2] = targets[:, [1, 2, 3, 4, 1, 4, 3, 2]].reshape(n * 4, 2)
+    corners = (corners @ M.T)[:, :2].reshape(n, 8)
+    xs, ys = corners[:, [0, 2, 4, 6]], corners[:, [1, 3, 5, 7]]
+    new = np.stack([xs.min(1), ys.min(1), xs.max(1), ys.max(1)], 1)
+    new[:, [0, 2]] = new[:, [0, 2]].clip(0, width)
+    new[:, [1, 3]] = new[:, [1, 3]].clip(0, height)
+    old = targets[:, 1:5].T * sc
+    w1, h1 = old[2] - old[0], old[3] - old[1]
+    w2, h2 = new[:, 2] - new[:, 0], new[:, 3] - new[:, 1]
+    eps = 1e-16
+    ar = np.maximum(w2 / (h2 + eps), h2 / (w2 + eps))
+    keep = (w2 > 2) & (h2 > 2) & (w2 * h2 / (w1 * h1 + eps) > 0.10) & (ar < 20)
+    targets = targets[keep]
+    targets[:, 1:5] = new[keep]
+    return targets
+
+
+def hsv_luts(hyp, nprng=np.random):
+    """augment_hsv's three tables (datasets.py:647-654): one np.random.uniform(-1, 1, 3) draw"""
+    r = nprng.uniform(-1, 1, 3) * [hyp['hsv_h'], hyp['hsv_s'], hyp['hsv_v']] + 1
+    x = np.arange(0, 256, dtype=np.int16)
+    return np.stack([((x * r[0]) % 180).astype(np.uint8), np.clip(x * r[1], 0, 255).astype(np.uint8), np.clip(x * r[2], 0, 255).astype(np.uint8)])
+
+
+def _invert_for_warp(M):
+    """the inversion cv::warpAffine applies to its 2x3 argument, in its operation order (double)"""
+    m = np.array(M[:2], np.float64).copy()
+    D = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[1, 1] * D, m[0, 0] * D
+    m[0, 0] = A11
+    m[0, 1] *= -D
+    m[1, 0] *= -D
+    m[1, 1] = A22
+    b1 = -m[0, 0] * m[0, 2] - m[0, 1] * m[1, 2]
+    b2 = -m[1, 0] * m[0, 2] - m[1, 1] * m[1, 2]
+    m[0, 2], m[1, 2] = b1, b2
+    return m
+
+
+def mosaic_train_sample(index, images, labels, indices, img_size, hyp, rng=_random, nprng=np.random):
+    """LoadImagesAndLabels.__getitem__ for a training dataset with mosaic (datasets.py:518-593).
+    images: index -> uint8 [h,w,3] BGR tensor on the GPU, already `load_image`d (long side = img_size; see load_image_dev);
+    labels: index -> float32 [n,5] (cls, normalised xywh).  Returns (uint8 [3,s,s] RGB tensor on the GPU, labels_out float32 [nL,6])."""
+    s = img_size
+    if not (rng.random() < hyp['mosaic']):
+        raise NotImplementedError('the non-mosaic branch (letterbox + random_perspective) is not on the device path')
+    border = [-s // 2, -s // 2]
+    yc, xc = [int(rng.uniform(-x, 2 * s + x)) for x in border]
+    idx4 = [index] + rng.choices(indices, k=3)
+    imgs = [images(i) for i in idx4]
+    hw4 = [(int(im.shape[0]), int(im.shape[1])) for im in imgs]
+    lay = mosaic_layout(s, yc, xc, hw4)
+    parts = []
+    for i, (h, w) in zip(idx4, hw4):
+        x1a, y1a, x2a, y2a, padw, padh = lay[len(parts)]
+        lb = labels(i).copy()
+        if lb.size:
+            lb[:, 1:] = _boxes_norm_to_pixels(lb[:, 1:], w, h, padw, padh)
+        parts.append(lb)
+    lab4 = np.concatenate(parts, 0)
+    np.clip(lab4[:, 1:], 0, 2 * s, out=lab4[:, 1:])
+    M, sc, (width, height) = draw_perspective_matrix((2 * s, 2 * s), hyp, border, rng)
+    if hyp['perspective']:
+        raise NotImplementedError('perspective != 0 (cv2.warpPerspective) is not on the device path; hyp.scratch.yaml uses 0')
+    lab4 = warp_boxes(lab4, M, sc, width, height)
+    if rng.random() < hyp['mixup']:
+        raise NotImplementedError('mixup (hyp.scratch.yaml: 0.0) is not on the device path')
+    lut = hsv_luts(hyp, nprng)
+    nL = len(lab4)
+    if nL:                                                            # pixel xyxy -> normalised xywh (general.xyxy2xywh)
+        x1, y1, x2, y2 = lab4[:, 1].copy(), lab4[:, 2].copy(), lab4[:, 3].copy(), lab4[:, 4].copy()
+        lab4[:, 1], lab4[:, 2], lab4[:, 3], lab4[:, 4] = (x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1
+        lab4[:, [2, 4]] /= height
+        lab4[:, [1, 3]] /= width
+    flipud = rng.random() < hyp['flipud']
+    if flipud and nL:
+        lab4[:, 2] = 1 - lab4[:, 2]
+    fliplr = rng.random() < hyp['fliplr']
+    if fliplr and nL:
+        lab4[:, 1] = 1 - lab4[:, 1]
+    out_lab = torch.zeros((nL, 6))
+    if nL:
+        out_lab[:, 1:] = torch.from_numpy(lab4)
+    # pixels: one fused launch
+    dev = imgs[0].device
+    d = L.MosaicDesc()
+    d.nsrc, d.cw, d.ch, d.warp, d.ow, d.oh = 4, 2 * s, 2 * s, 1, width, height
+    for k, (im, (h, w)) in enumerate(zip(imgs, hw4)):
+        L.require_gpu(im)
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or not im.is_contiguous():
+            raise L.MyoloError('images must be contiguous uint8 [h,w,3] tensors')
+        x1a, y1a, x2a, y2a, padw, padh = lay[k]
+        if x2a <= x1a or y2a <= y1a:                                  # empty window (the centre lies outside the canvas on that side)
+            x1a = y1a = x2a = y2a = 0
+            padw = padh = 0
+        sk = d.src[k]
+        sk.img, sk.h, sk.w, sk.x1a, sk.y1a, sk.x2a, sk.y2a, sk.padw, sk.padh = im.data_ptr(), h, w, x1a, y1a, x2a, y2a, padw, padh
+    Mi = _invert_for_warp(M)
+    for k in range(6):
+        d.M[k] = float(Mi.reshape(-1)[k])
+    lut_d = torch.from_numpy(np.ascontiguousarray(lut)).to(dev)
+    out = torch.empty(3, height, width, dtype=torch.uint8, device=dev)
+    d.hsv_lut, d.fliplr, d.flipud, d.fill, d.out_chw = lut_d.data_ptr(), int(fliplr), int(flipud), 114, out.data_ptr()
+    L.check(L.lib().myolo_mosaic_warp(C.byref(d), L.stream_ptr()), 'myolo_mosaic_warp')
+    return out, out_lab

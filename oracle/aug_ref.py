@@ -214,3 +214,128 @@ def color_jitter(img, order, brightness, contrast, saturation, hue):
             hsv[..., 0] = (hsv[..., 0].astype(np.int64) + int(hue * 255)) % 256
             img = hsv2rgb(hsv)
     return img
+
+
+# ---- detection augmentation: the OpenCV pieces utils/datasets.py calls, restated (cv2 is NOT installed here -> "parity unpinned";
+# ---- make_golden.py serves them to the REAL reference code as its `cv2`, so everything around them -- random call order, mosaic
+# ---- geometry, label arithmetic, flips -- is the reference's own) -------------------------------------------------------------------
+def cv_get_rotation_matrix_2d(center, angle, scale):
+    """cv2.getRotationMatrix2D (imgwarp.cpp): angle in degrees, counter-clockwise"""
+    a = angle * np.pi / 180.0
+    alpha, beta = math.cos(a) * scale, math.sin(a) * scale
+    cx, cy = center
+    return np.array([[alpha, beta, (1 - alpha) * cx - beta * cy], [-beta, alpha, beta * cx + (1 - alpha) * cy]], np.float64)
+
+
+def cv_invert_affine_for_warp(M):
+    """the inversion cv::warpAffine applies to its 2x3 argument (no WARP_INVERSE_MAP)"""
+    M = np.array(M, np.float64).reshape(2, 3).copy()
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    M[0, 0] = A11
+    M[0, 1] *= -D
+    M[1, 0] *= -D
+    M[1, 1] = A22
+    b1 = -M[0, 0] * M[0, 2] - M[0, 1] * M[1, 2]
+    b2 = -M[1, 0] * M[0, 2] - M[1, 1] * M[1, 2]
+    M[0, 2], M[1, 2] = b1, b2
+    return M
+
+
+def cv_warp_affine_u8(img, M, dsize, border=114):
+    """cv2.warpAffine(img, M, dsize, flags=INTER_LINEAR, borderMode=BORDER_CONSTANT, borderValue=(border,)*3) for uint8 HxWx3: fixed-point
+    source coordinates (AB_BITS 10, 1/32 pixel), bilinear weights (32-a)(32-b)*32 (sum 2^15), result (sum + 2^14) >> 15"""
+    w, h = dsize
+    Mi = cv_invert_affine_for_warp(M)
+    xs, ys = np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64)
+    adx = np.rint(Mi[0, 0] * xs * 1024.0).astype(np.int64)
+    bdx = np.rint(Mi[1, 0] * xs * 1024.0).astype(np.int64)
+    X0 = np.rint((Mi[0, 1] * ys + Mi[0, 2]) * 1024.0).astype(np.int64) + 16
+    Y0 = np.rint((Mi[1, 1] * ys + Mi[1, 2]) * 1024.0).astype(np.int64) + 16
+    X = (X0[:, None] + adx[None, :]) >> 5
+    Y = (Y0[:, None] + bdx[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fa, fb = Y & 31, X & 31
+    H, W = img.shape[:2]
+    src = img.astype(np.int64)
+
+    def px(yy, xx):
+        ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+        v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+        return np.where(ok[..., None], v, border)
+    w00, w01, w10, w11 = (32 - fa) * (32 - fb) * 32, (32 - fa) * fb * 32, fa * (32 - fb) * 32, fa * fb * 32
+    acc = px(sy, sx) * w00[..., None] + px(sy, sx + 1) * w01[..., None] + px(sy + 1, sx) * w10[..., None] + px(sy + 1, sx + 1) * w11[..., None]
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+_SDIV = np.array([0] + [int(np.rint((255 << 12) / (1.0 * i))) for i in range(1, 256)], np.int64)
+_HDIV = np.array([0] + [int(np.rint((180 << 12) / (6.0 * i))) for i in range(1, 256)], np.int64)
+
+
+def cv_bgr2hsv_u8(img):
+    """cv2.cvtColor(img, cv2.COLOR_BGR2HSV) for uint8 (color_hsv RGB2HSV_b, hrange 180, integer tables)"""
+    b, g, r = (img[..., k].astype(np.int64) for k in range(3))
+    v = np.maximum(b, np.maximum(g, r))
+    vmin = np.minimum(b, np.minimum(g, r))
+    diff = v - vmin
+    vr = np.where(v == r, -1, 0)
+    vg = np.where(v == g, -1, 0)
+    s = (diff * _SDIV[v] + (1 << 11)) >> 12
+    h = (vr & (g - b)) + (~vr & ((vg & (b - r + 2 * diff)) + ((~vg) & (r - g + 4 * diff))))
+    h = (h * _HDIV[diff] + (1 << 11)) >> 12
+    h = h + np.where(h < 0, 180, 0)
+    return np.stack([np.clip(h, 0, 255), s & 255, v], -1).astype(np.uint8)
+
+
+def cv_hsv2bgr_u8(hsv):
+    """cv2.cvtColor(hsv, cv2.COLOR_HSV2BGR) for uint8 (HSV2RGB_b: float32 sector formula, saturate_cast<uchar>(x * 255))"""
+    f = np.float32
+    h = hsv[..., 0].astype(f)
+    s = (hsv[..., 1].astype(f) * f(1.0 / 255.0)).astype(f)
+    v = (hsv[..., 2].astype(f) * f(1.0 / 255.0)).astype(f)
+    hh = (h * f(6.0 / 180.0)).astype(f)
+    hh = np.fmod(hh, f(6.0)).astype(f)
+    sector = np.floor(hh).astype(np.int64)
+    hh = (hh - sector.astype(f)).astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector = np.where(bad, 0, sector)
+    hh = np.where(bad, f(0), hh).astype(f)
+    one = f(1.0)
+    t0 = v
+    t1 = (v * (one - s)).astype(f)
+    t2 = (v * (one - (s * hh).astype(f)).astype(f)).astype(f)
+    t3 = (v * (one - (s * (one - hh).astype(f)).astype(f)).astype(f)).astype(f)
+    tab = np.stack([t0, t1, t2, t3], -1)
+    sd = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+    idx = sd[sector]
+    out = np.take_along_axis(tab, idx, -1)
+    out = np.where((hsv[..., 1] == 0)[..., None], v[..., None], out)
+    return np.clip(np.rint((out * f(255.0)).astype(f)), 0, 255).astype(np.uint8)
+
+
+def install_cv2_stub(cv2):
+    """give the stub `cv2` module of oracle/ref_shim the functions utils/datasets.py's augmentation path calls"""
+    from . import frame_ref
+    cv2.INTER_LINEAR, cv2.INTER_AREA = 1, 3
+    cv2.COLOR_BGR2HSV, cv2.COLOR_HSV2BGR = 40, 54
+
+    def resize(img, dsize, interpolation=1):
+        assert interpolation == 1
+        return frame_ref.cv_resize_linear_u8(img, dsize)
+
+    def warp_affine(img, M, dsize, borderValue=(0, 0, 0)):
+        return cv_warp_affine_u8(img, M, dsize, int(borderValue[0]))
+
+    def cvt(img, code, dst=None):
+        out = cv_bgr2hsv_u8(img) if code == cv2.COLOR_BGR2HSV else cv_hsv2bgr_u8(img)
+        if dst is not None:
+            dst[...] = out
+            return dst
+        return out
+    cv2.resize, cv2.warpAffine, cv2.cvtColor = resize, warp_affine, cvt
+    cv2.getRotationMatrix2D = lambda angle, center, scale: cv_get_rotation_matrix_2d(center, angle, scale)
+    cv2.split = lambda m: [np.ascontiguousarray(m[..., k]) for k in range(m.shape[2])]
+    cv2.merge = lambda planes: np.stack(planes, -1)
+    cv2.LUT = lambda src, lut: lut[src]
+    return cv2

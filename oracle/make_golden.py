@@ -411,6 +411,58 @@ def jitter_case(ref):
     print('augment_jitter', len(out))
 
 
+DET_S = 96                                                        # img_size of the detection augmentation cases
+DET_HYPS = {
+    'scratch': dict(degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0, flipud=0.0, fliplr=0.5, mosaic=1.0, mixup=0.0,
+                    hsv_h=0.015, hsv_s=0.7, hsv_v=0.4),          # data/hyp.scratch.yaml
+    'rot': dict(degrees=10.0, translate=0.1, scale=0.5, shear=5.0, perspective=0.0, flipud=0.5, fliplr=0.5, mosaic=1.0, mixup=0.0,
+                hsv_h=0.015, hsv_s=0.7, hsv_v=0.4),
+}
+DET_CASES = [('scratch', 0, 1), ('scratch', 3, 2), ('rot', 1, 3), ('rot', 5, 4), ('scratch', 2, 7), ('rot', 4, 11)]   # (hyp, index, seed)
+
+
+def det_dataset():
+    """6 synthetic BGR images as load_image would cache them (long side = DET_S) + normalised xywh labels"""
+    shapes = [(96, 64), (72, 96), (96, 96), (50, 96), (96, 80), (64, 96)]
+    imgs, labels = [], []
+    for i, (h, w) in enumerate(shapes):
+        rs = np.random.RandomState(200 + i)
+        yy, xx = np.mgrid[0:h, 0:w]
+        im = np.stack([(xx * 255 // (w - 1)), (yy * 255 // (h - 1)), ((xx * 3 + yy * 5) % 256)], 2).astype(np.int64)
+        imgs.append(np.clip(im + rs.randint(-30, 31, im.shape), 0, 255).astype(np.uint8))
+        n = 3 + i % 4
+        xy = rs.uniform(0.2, 0.8, (n, 2))
+        wh = rs.uniform(0.1, 0.5, (n, 2))
+        labels.append(np.concatenate([rs.randint(0, 10, (n, 1)).astype(np.float64), xy, wh], 1).astype(np.float32))
+    return imgs, labels
+
+
+def det_augment_case(ref):
+    """utils/datasets.py LoadImagesAndLabels.__getitem__ (518-593, mosaic branch: load_mosaic 672-724 -> random_perspective 851-925 ->
+    augment_hsv 646-658 -> flips -> transpose), the reference's OWN code on a stand-in dataset object; its cv2 calls are served by
+    the restatements of oracle/aug_ref.py (cv2 is not installed): pins the random call order, mosaic geometry, label arithmetic"""
+    import random
+    from types import SimpleNamespace
+    from . import aug_ref
+    aug_ref.install_cv2_stub(sys.modules['cv2'])
+    import utils.datasets as rds
+    imgs, labels = det_dataset()
+    out = {}
+    for ci, (hyp, index, seed) in enumerate(DET_CASES):
+        ds = SimpleNamespace(indices=range(len(imgs)), hyp=DET_HYPS[hyp], mosaic=True, augment=True, rect=False, n=len(imgs), img_size=DET_S,
+                             mosaic_border=[-DET_S // 2, -DET_S // 2], labels=[l.copy() for l in labels], segments=[[] for _ in imgs],
+                             imgs=imgs, img_hw0=[im.shape[:2] for im in imgs], img_hw=[im.shape[:2] for im in imgs],
+                             img_files=[f'{i}.jpg' for i in range(len(imgs))])
+        random.seed(seed)
+        np.random.seed(seed)
+        img, lab, _, _ = rds.LoadImagesAndLabels.__getitem__(ds, index)
+        out[f'c{ci}.img'] = img.numpy()
+        out[f'c{ci}.lab'] = lab.numpy()
+        out[f'c{ci}.after'] = np.array([random.random(), np.random.rand()])
+    np.savez_compressed(os.path.join(GOLD, 'augment_det.npz'), **out)
+    print('augment_det', {k: v.shape for k, v in out.items() if not k.endswith('after')})
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = ref_shim.install()
@@ -441,6 +493,7 @@ def main():
     if 'augment' in which:
         augment_case(ref)
         jitter_case(ref)
+        det_augment_case(ref)
 
 
 if __name__ == '__main__':

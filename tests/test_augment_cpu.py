@@ -83,3 +83,33 @@ def test_oracle_hsv_round_trip_matches_pillow_on_a_colour_lattice():
     a = np.stack([rr, gg, bb], -1).reshape(len(lv), -1, 3)
     assert np.array_equal(aug_ref.rgb2hsv(a), np.array(Image.fromarray(a).convert('HSV')))
     assert np.array_equal(aug_ref.hsv2rgb(a), np.array(Image.fromarray(a, 'HSV').convert('RGB')))
+
+
+def test_mosaic_sample_host_half_matches_reference_golden(monkeypatch):
+    """labels, geometry and random call order of utils/augment.mosaic_train_sample against the golden the reference's own
+    LoadImagesAndLabels.__getitem__ produced (the pixel launch is replaced by a recorder: no GPU here)"""
+    import random
+    import torch
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd.utils import augment as A
+    from oracle.make_golden import DET_CASES, DET_HYPS, DET_S, det_dataset
+    imgs, labels = det_dataset()
+    g = golden('augment_det')
+    calls = []
+
+    class FakeLib:
+        def myolo_mosaic_warp(self, d, st):
+            calls.append(d)
+            return 0
+    monkeypatch.setattr(L, 'lib', lambda: FakeLib())
+    monkeypatch.setattr(L, 'require_gpu', lambda t: None)
+    monkeypatch.setattr(L, 'stream_ptr', lambda: None)
+    for ci, (hyp, index, seed) in enumerate(DET_CASES):
+        rng = random.Random(seed)
+        nprng = np.random.RandomState(seed)
+        t = [torch.from_numpy(im) for im in imgs]
+        out, lab = A.mosaic_train_sample(index, lambda i: t[i], lambda i: labels[i], range(len(imgs)), DET_S, DET_HYPS[hyp], rng, nprng)
+        assert tuple(out.shape) == (3, DET_S, DET_S)
+        np.testing.assert_array_equal(lab.numpy(), g[f'c{ci}.lab'])
+        assert [rng.random(), nprng.rand()] == list(g[f'c{ci}.after'])
+    assert len(calls) == len(DET_CASES)

@@ -107,3 +107,71 @@ def test_hue_round_trip_over_all_colours():
         got = A.color_jitter(torch.from_numpy(a).to(DEV), dict(order=[3, -1, -1, -1], brightness=1, contrast=1, saturation=1, hue=0.1),
                              return_uint8=True).cpu().numpy()
         assert np.array_equal(got, aug_ref.color_jitter(a, [3], 1, 1, 1, 0.1)), r0
+
+
+def test_mosaic_train_sample_matches_reference_golden():
+    """the whole detection sample (utils/datasets.py:518-593) on the device against the golden the reference's own __getitem__ wrote
+    with oracle/aug_ref.py's restated cv2 underneath (cv2 is not installed: pixels are pinned to the restatement, everything else to
+    the reference)"""
+    from multiyolov5_amd.utils import augment as A
+    from oracle.make_golden import DET_CASES, DET_HYPS, DET_S, det_dataset
+    imgs, labels = det_dataset()
+    g = golden('augment_det')
+    t = [torch.from_numpy(im).to(DEV) for im in imgs]
+    for ci, (hyp, index, seed) in enumerate(DET_CASES):
+        out, lab = A.mosaic_train_sample(index, lambda i: t[i], lambda i: labels[i], range(len(imgs)), DET_S, DET_HYPS[hyp],
+                                         random.Random(seed), np.random.RandomState(seed))
+        assert out.dtype == torch.uint8 and np.array_equal(out.cpu().numpy(), g[f'c{ci}.img']), ci
+        np.testing.assert_array_equal(lab.numpy(), g[f'c{ci}.lab'])
+
+
+@pytest.mark.parametrize('shape', [((480, 640), (96, 72)), ((100, 37), (96, 35)), ((64, 128), (32, 64)), ((50, 50), (96, 96))])
+def test_resize_u8_matches_cv_restatement(shape):
+    from multiyolov5_amd.utils import augment as A
+    from oracle import frame_ref
+    (h0, w0), (rw, rh) = shape
+    img = np.random.RandomState(h0).randint(0, 256, (h0, w0, 3)).astype(np.uint8)
+    got = A.resize_u8(torch.from_numpy(img).to(DEV), rw, rh).cpu().numpy()
+    assert np.array_equal(got, frame_ref.cv_resize_linear_u8(img, (rw, rh)))
+
+
+def test_mosaic_warp_kernel_vs_oracle_pieces():
+    """C ABI directly: single-source canvas + warp (rotation / shear / scale), HSV tables, flips, against the numpy restatements"""
+    import ctypes as C
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd.utils import augment as A
+    rs = np.random.RandomState(5)
+    img = rs.randint(0, 256, (70, 90, 3)).astype(np.uint8)
+    d_img = torch.from_numpy(img).to(DEV)
+    for case, (M, lut_on, fl, fu) in enumerate([
+            (np.array([[1.2, 0.15, -8.0], [-0.1, 0.85, 6.0], [0, 0, 1.0]]), True, 0, 0),
+            (np.array([[0.7, -0.3, 20.5], [0.25, 0.9, -3.25], [0, 0, 1.0]]), False, 1, 1),
+            (np.eye(3), True, 1, 0)]):
+        ow, oh = (64, 48) if case < 2 else (90, 70)
+        warp = int(case < 2)
+        lut = A.hsv_luts(dict(hsv_h=0.015, hsv_s=0.7, hsv_v=0.4), np.random.RandomState(case)) if lut_on else None
+        want = aug_ref.cv_warp_affine_u8(img, M[:2], (ow, oh)) if warp else img.copy()
+        if lut is not None:
+            hsv = aug_ref.cv_bgr2hsv_u8(want)
+            want = aug_ref.cv_hsv2bgr_u8(np.stack([lut[0][hsv[..., 0]], lut[1][hsv[..., 1]], lut[2][hsv[..., 2]]], -1))
+        if fu:
+            want = want[::-1]
+        if fl:
+            want = want[:, ::-1]
+        d = L.MosaicDesc()
+        d.nsrc, d.cw, d.ch, d.warp, d.ow, d.oh, d.fill, d.fliplr, d.flipud = 1, 90, 70, warp, ow, oh, 114, fl, fu
+        s0 = d.src[0]
+        s0.img, s0.h, s0.w, s0.x1a, s0.y1a, s0.x2a, s0.y2a, s0.padw, s0.padh = d_img.data_ptr(), 70, 90, 0, 0, 90, 70, 0, 0
+        Mi = A._invert_for_warp(M)
+        for k in range(6):
+            d.M[k] = float(Mi.reshape(-1)[k])
+        lut_d = torch.from_numpy(np.ascontiguousarray(lut)).to(DEV) if lut is not None else None
+        hwc = torch.empty(oh, ow, 3, dtype=torch.uint8, device=DEV)
+        chw = torch.empty(3, oh, ow, dtype=torch.uint8, device=DEV)
+        d.hsv_lut, d.out_chw, d.out_hwc = (lut_d.data_ptr() if lut_d is not None else None), chw.data_ptr(), hwc.data_ptr()
+        L.check(L.lib().myolo_mosaic_warp(C.byref(d), L.stream_ptr()), 'myolo_mosaic_warp')
+        assert np.array_equal(hwc.cpu().numpy(), np.ascontiguousarray(want)), case
+        assert np.array_equal(chw.cpu().numpy(), np.ascontiguousarray(want[:, :, ::-1].transpose(2, 0, 1))), case
+    # rejected descriptors
+    d.src[0].x2a = 200
+    assert L.lib().myolo_mosaic_warp(C.byref(d), L.stream_ptr()) == L.EINVAL
