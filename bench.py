@@ -301,6 +301,81 @@ def second_config_rate(args, world, rank, dev, cfg='yolov5m_city_seg_lab.yaml', 
     return r
 
 
+def augment_rates(dev, n=24):
+    """device augmentation throughput at the training scripts' real sizes, next to the reference's own CPU path
+    where its library is installed (Pillow: SegmentationDataset.py:118-151 + ColorJitter on one core; cv2 is absent, so the
+    detection side has no CPU number here).  Host-side parameter draws and table construction are inside the timed region."""
+    import random
+    import numpy as np
+    from multiyolov5_amd.utils import augment as A
+    rs = np.random.RandomState(0)
+    out = {}
+    # segmentation: a 2048x1024 Cityscapes frame -> random scale [0.65, 3] x 1024 -> 1024x512 crop -> ColorJitter -> fp16 CHW
+    img = torch.from_numpy(rs.randint(0, 256, (1024, 2048, 3)).astype(np.uint8)).to(dev)
+    mask = torch.from_numpy(rs.randint(0, 34, (1024, 2048)).astype(np.uint8)).to(dev)
+    rng = random.Random(0)
+    g = torch.Generator().manual_seed(0)
+
+    def seg_one():
+        p = A.draw_sync_params(2048, 1024, 1024, (1024, 512), rng=rng)
+        a, lab = A.seg_sync_transform(img, mask, p)
+        return A.color_jitter(a, A.draw_color_jitter_params(generator=g), dtype=torch.float16), lab
+    for _ in range(3):
+        seg_one()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        seg_one()
+    torch.cuda.synchronize(dev)
+    out['seg_samples_per_s'] = n / (time.perf_counter() - t0)
+    # detection: 4-image mosaic at img_size 1024 from 1024x512 frames, hyp.scratch.yaml
+    hyp = dict(degrees=0.0, translate=0.1, scale=0.5, shear=0.0, perspective=0.0, flipud=0.0, fliplr=0.5, mosaic=1.0, mixup=0.0,
+               hsv_h=0.015, hsv_s=0.7, hsv_v=0.4)
+    frames = [torch.from_numpy(rs.randint(0, 256, (512, 1024, 3)).astype(np.uint8)).to(dev) for _ in range(8)]
+    labels = [np.concatenate([rs.randint(0, 10, (8, 1)), rs.uniform(0.2, 0.8, (8, 2)), rs.uniform(0.05, 0.3, (8, 2))], 1).astype(np.float32)
+              for _ in range(8)]
+    nprng = np.random.RandomState(0)
+
+    def det_one(i):
+        return A.mosaic_train_sample(i % 8, lambda k: frames[k], lambda k: labels[k], range(8), 1024, hyp, rng, nprng)
+    for i in range(3):
+        det_one(i)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(n):
+        det_one(i)
+    torch.cuda.synchronize(dev)
+    out['det_mosaic_samples_per_s'] = n / (time.perf_counter() - t0)
+    out['what'] = ('seg: _sync_transform (2048x1024 -> random scale -> 1024x512 crop) + ColorJitter + ToTensor fp16; det: 4-image mosaic at '
+                   'img_size 1024 + warpAffine + augment_hsv + flip; one sample at a time, host parameter draws included')
+    try:                                                  # the reference's CPU path for the segmentation sample, through the real Pillow
+        from PIL import Image, ImageEnhance, ImageOps
+        im0, m0 = Image.fromarray(img.cpu().numpy()), Image.fromarray(mask.cpu().numpy())
+        rng2 = random.Random(0)
+        t0 = time.perf_counter()
+        k = 4
+        for _ in range(k):
+            p = A.draw_sync_params(2048, 1024, 1024, (1024, 512), rng=rng2)
+            a, b = (im0.transpose(Image.FLIP_LEFT_RIGHT), m0.transpose(Image.FLIP_LEFT_RIGHT)) if p['flip'] else (im0, m0)
+            a, b = a.resize((p['ow'], p['oh']), Image.BILINEAR), b.resize((p['ow'], p['oh']), Image.NEAREST)
+            if p['ow'] < 1024 or p['oh'] < 512:
+                a = ImageOps.expand(a, border=(0, 0, max(1024 - p['ow'], 0), max(512 - p['oh'], 0)), fill=0)
+                b = ImageOps.expand(b, border=(0, 0, max(1024 - p['ow'], 0), max(512 - p['oh'], 0)), fill=255)
+            a = a.crop((p['x1'], p['y1'], p['x1'] + 1024, p['y1'] + 512))
+            b = b.crop((p['x1'], p['y1'], p['x1'] + 1024, p['y1'] + 512))
+            a = ImageEnhance.Color(ImageEnhance.Contrast(ImageEnhance.Brightness(a).enhance(1.2)).enhance(0.9)).enhance(1.1)
+            hh, ss, vv = a.convert('HSV').split()
+            a = Image.merge('HSV', (hh.point(lambda v: (v + 12) % 256), ss, vv)).convert('RGB')
+            torch.from_numpy(np.array(a)).permute(2, 0, 1).float().div(255)
+            torch.from_numpy(np.array(b)).long()
+        out['seg_cpu_pillow_samples_per_s'] = k / (time.perf_counter() - t0)
+        out['seg_cpu_cores'] = 1
+    except Exception as e:
+        out['seg_cpu_pillow_samples_per_s'] = None
+        out['seg_cpu_error'] = repr(e)
+    return out
+
+
 def main():
     args = parse()
     world, rank, local = setup_dist(args)
@@ -379,6 +454,11 @@ def main():
                 out['train_py_step'] = train_py_rate(tr)
             except Exception as e:
                 out['train_py_step'] = {'pairs_per_s': None, 'error': repr(e)}
+        if args.stage == 'train' and not args.no_infer:
+            try:
+                out['augment'] = augment_rates(dev)
+            except Exception as e:
+                out['augment'] = {'error': repr(e)}
         if args.stage == 'train' and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
     if rank == 0:
