@@ -218,6 +218,9 @@ int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int acc
  * with it, big bins are summed by many workgroups in parallel. */
 int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, float* scratch, void* stream);
 int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
+/* the backward of up to four adaptive average pools of ONE input (PyramidPooling, common.py:521-524): gouts = array of `count`
+ * pooled-gradient views; gx (+)= sum over them -- the input gradient is read-modified-written once instead of once per pool */
+int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int count, const myolo_tensor* gx, int accumulate, void* stream);
 /* FFM gate: out = feat*att + feat, att [n,1,1,c] (common.py:228-229) */
 int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream);
 int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,

@@ -703,6 +703,51 @@ __global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_t
   }
 }
 
+// the same for up to four pooled maps of ONE input (PyramidPooling's bins 1, 2, 3, 6 -- common.py:521-524): the input gradient is
+// read-modified-written once instead of once per bin (4 x 66 MB at 16x64x128x128)
+struct AapMulti { myolo_tensor g[4]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void aap_bwd_multi_kernel(AapMulti m, myolo_tensor gx, int acc) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = gx.c / SEG;
+  const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (t >= m.n) break;
+      const myolo_tensor& gout = m.g[t];
+      const int kb = gout.h, kw = gout.w;
+      const int byc = (int)(((uint32_t)y * (uint32_t)kb) / (uint32_t)gx.h), bxc = (int)(((uint32_t)xx * (uint32_t)kw) / (uint32_t)gx.w);
+      for (int by = byc > 0 ? byc - 1 : 0; by <= byc + 1 && by < kb; ++by) {
+        const int y0 = (by * gx.h) / kb, y1 = ((by + 1) * gx.h + kb - 1) / kb;
+        if (y < y0 || y >= y1) continue;
+        for (int bx = bxc > 0 ? bxc - 1 : 0; bx <= bxc + 1 && bx < kw; ++bx) {
+          const int x0 = (bx * gx.w) / kw, x1 = ((bx + 1) * gx.w + kw - 1) / kw;
+          if (xx < x0 || xx >= x1) continue;
+          float f[SEG];
+          Vec<T>::unpack(ldg16(vptr<T>(gout, n, by, bx) + cg * SEG), f);
+          const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) a[i] += f[i] * inv;
+        }
+      }
+    }
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
 // ---------------------------------------------------------------- FFM gate
 template <typename T>
 __global__ __launch_bounds__(256) void gate_fwd_kernel(myolo_tensor feat, myolo_tensor att, myolo_tensor out, float one) {
@@ -963,6 +1008,18 @@ extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_
                                           void* stream) {
   if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
   DISPATCH(gx->dtype, aap_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx, accumulate);
+  return 0;
+}
+extern "C" int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int count, const myolo_tensor* gx, int accumulate,
+                                                void* stream) {
+  if (!gouts || count < 1 || count > 4 || !vec_ok(gx)) return MYOLO_EINVAL;
+  AapMulti m;
+  m.n = count;
+  for (int i = 0; i < count; ++i) {
+    if (!vec_ok(&gouts[i]) || !same_nc(gx, &gouts[i])) return MYOLO_EINVAL;
+    m.g[i] = gouts[i];
+  }
+  DISPATCH(gx->dtype, aap_bwd_multi_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, m, *gx, accumulate);
   return 0;
 }
 static int gate_fwd_impl(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, float one, void* stream) {

@@ -547,13 +547,39 @@ class BilinearOp(SimpleOp):
 
 
 class AvgPoolOp(SimpleOp):
+    """nn.AdaptiveAvgPool2d.  `group` (a list shared by the pools of one input, in forward order -- PyramidPooling): their backward
+    passes run as ONE launch at the position of the group's first member (= the last of them in the backward), the input gradient is
+    read-modified-written once."""
+
+    def __init__(self, plan, src, dst, group=None):
+        super().__init__(plan, src, dst)
+        self.group = group
+        if group is not None:
+            group.append(self)
+
+    def plan_bwd(self, plan):
+        if self.group is None or len(self.group) < 2:
+            return super().plan_bwd(plan)
+        if self is self.group[-1] and self.src.requires_grad:        # first claimer in the backward: its flags stand for the group
+            self.acc, z = claim(self.src)
+            self.zero_first = [(self.src, a, b) for a, b in z]
+
     def emit_fwd(self, plan):
         d = self.dst
         self.scratch = plan.f32_fwd_zero(d.n * d.h * d.w * d.buf.c)
         self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd', (C.byref(self.sd), C.byref(self.dd), L.ptr(self.scratch))))
 
     def emit_bwd(self, plan):
-        self.bwd_calls.append(Call('myolo_adaptive_avgpool_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc)))
+        g = self.group
+        if g is None or len(g) < 2:
+            self.bwd_calls.append(Call('myolo_adaptive_avgpool_bwd', (C.byref(self.gdd), C.byref(self.gsd), self.acc)))
+        elif self is g[0]:                                            # runs last in the backward: every pooled gradient is complete
+            self.bwd_calls = [c for c in self.bwd_calls if c.name != 'myolo_fill_zero']
+            self.bwd_calls += g[-1]._zero_calls(plan)
+            self.garr = (CT * len(g))(*[o.dst.desc(grad=True) for o in g])
+            self.bwd_calls.append(Call('myolo_adaptive_avgpool_bwd_multi', (self.garr, len(g), C.byref(self.gsd), g[-1].acc)))
+        elif self is g[-1]:
+            self.bwd_calls = []                                       # (its zero fills are issued by the group's launch)
 
 
 class DropoutOp(SimpleOp):

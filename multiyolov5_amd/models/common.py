@@ -251,9 +251,9 @@ def emit_bilinear(plan, x, h, w):
     return out
 
 
-def emit_avgpool(plan, x, k):
+def emit_avgpool(plan, x, k, group=None):
     out = plan.new(x.n, k, k, x.c)
-    plan.add(E.AvgPoolOp(plan, x, out))
+    plan.add(E.AvgPoolOp(plan, x, out, group))
     return out
 
 
@@ -433,8 +433,9 @@ class PyramidPooling(PlannedModule):
 
     def emit(self, plan, x):
         feats = [x]
+        group = []                                            # the four pools share one backward launch (engine.AvgPoolOp)
         for k, conv in zip(self.k, (self.conv1, self.conv2, self.conv3, self.conv4)):
-            feats.append(emit_bilinear(plan, conv.emit(plan, emit_avgpool(plan, x, k)), x.h, x.w))
+            feats.append(emit_bilinear(plan, conv.emit(plan, emit_avgpool(plan, x, k, group)), x.h, x.w))
         return plan.cat(feats)
 
 
