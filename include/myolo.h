@@ -220,6 +220,11 @@ int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, f
 int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
 /* the backward of up to four adaptive average pools of ONE input (PyramidPooling, common.py:521-524): gouts = array of `count`
  * pooled-gradient views; gx (+)= sum over them -- the input gradient is read-modified-written once instead of once per pool */
+/* PyramidPooling (common.py:534-537): the backward of `count` (<= 4) bilinear align_corners upsamples of k x k maps (k <= 6) whose
+ * outputs are ADJACENT equal-width channel slices of one tensor (`gout`: the view over all of them, <= 128 channels in fp16): one
+ * pass over gout, gxs[t] (+)= result.  scratch: fp32 [sum of the gxs element counts], ZERO on entry, left dirty. */
+int myolo_pyramid_upsample_bwd(const myolo_tensor* gout, const myolo_tensor* gxs, int count, const int32_t* accumulate, float* scratch,
+                               void* stream);
 int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int count, const myolo_tensor* gx, int accumulate, void* stream);
 /* FFM gate: out = feat*att + feat, att [n,1,1,c] (common.py:228-229) */
 int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream);

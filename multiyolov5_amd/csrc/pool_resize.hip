@@ -556,6 +556,119 @@ __global__ __launch_bounds__(256) void bilinear_bwd_finish_kernel(myolo_tensor g
   }
 }
 
+// ---------------------------------------------------------------- PyramidPooling: the four upsample backwards in one pass
+// common.py:534-537 upsamples four k x k maps (k = 1, 2, 3, 6) to the feature map and concatenates them: in the backward their
+// output gradients are four ADJACENT channel slices of one buffer.  One pass over those channels instead of four kernels that each
+// reduce an 8 MB map to k x k values (0.2 TB/s: the outputs are too few to spread the work): a workgroup owns a strip of rows of one
+// image, thread = (channel group -> branch, lane of 16 pixels); per row the x-fold into the <= 6 column cells runs in registers, rows
+// are folded into the two row cells around them ((1-ly), ly), and when the walk leaves a row cell (or the strip ends) the 16 lanes of a
+// channel group butterfly-reduce and add to the fp32 scratch (one atomic per (cell, channel) and workgroup).
+struct PyrUp { myolo_tensor gout; int k[4]; int cgs_per_branch, nbranch, rows; float sy[4], sx[4]; int off[4]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void pyr_up_bwd_kernel(PyrUp p, float* __restrict__ scratch) {
+  constexpr int SEG = ET<T>::SEG;
+  constexpr int KMAX = 6;
+  const int lane16 = threadIdx.x & 15, cg = threadIdx.x >> 4;
+  const int t = cg / p.cgs_per_branch;
+  const int strips = (p.gout.h + p.rows - 1) / p.rows;
+  const int n = blockIdx.x / strips, ys = (blockIdx.x - n * strips) * p.rows;
+  if (t >= p.nbranch) return;
+  const int k = p.k[t];
+  const float sy = p.sy[t], sx = p.sx[t];
+  const int cb = (cg - t * p.cgs_per_branch) * SEG;              // first channel of this thread inside its branch
+  const int cbr = p.cgs_per_branch * SEG;                        // channels per branch
+  float top[KMAX][SEG], bot[KMAX][SEG];
+#pragma unroll
+  for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { top[j][i] = 0.f; bot[j][i] = 0.f; }
+  // scratch layout: [branch offset][n][k][k][channels of the branch]
+  auto flush = [&](int row, float (&a)[KMAX][SEG]) {
+    float* base = scratch + p.off[t] + (((size_t)n * k + row) * k) * cbr + cb;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+      if (j >= k) break;
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) {
+        float v = a[j][i];
+        v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
+        if (((j * SEG + i) & 15) == lane16 && v != 0.f) atomicAdd(base + (size_t)j * cbr + i, v);
+        a[j][i] = 0.f;
+      }
+    }
+  };
+  const int yend = ys + p.rows < p.gout.h ? ys + p.rows : p.gout.h;
+  int icur = (int)(sy * (float)ys);
+  const T* gb = reinterpret_cast<const T*>(p.gout.ptr) + (int64_t)n * p.gout.sn + (int64_t)cg * SEG;
+  for (int y = ys; y < yend; ++y) {
+    const float fy = sy * (float)y;
+    const int i0 = (int)fy;
+    const float ly = fy - (float)i0;
+    while (icur != i0) {                       // (uniform over the 16 lanes of a channel group)
+      flush(icur, top);
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) { top[j][i] = bot[j][i]; bot[j][i] = 0.f; }
+      ++icur;
+    }
+    float row[KMAX][SEG];
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) row[j][i] = 0.f;
+    const T* rp = gb + (int64_t)y * p.gout.sh;
+    for (int x = lane16; x < p.gout.w; x += 16) {
+      float f[SEG];
+      Vec<T>::unpack(ldg16(rp + (int64_t)x * p.gout.sw), f);
+      const float fx = sx * (float)x;
+      const int j0 = (int)fx;
+      const float lx = fx - (float)j0;
+      const int j1 = j0 + 1 < k ? j0 + 1 : k - 1;
+#pragma unroll
+      for (int j = 0; j < KMAX; ++j) {
+        const float w = (j == j0 ? 1.f - lx : 0.f) + (j == j1 ? lx : 0.f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) row[j][i] += w * f[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j)
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) { top[j][i] += (1.f - ly) * row[j][i]; bot[j][i] += ly * row[j][i]; }
+  }
+  flush(icur, top);
+  flush(icur + 1 < k ? icur + 1 : k - 1, bot);
+}
+
+struct PyrFin { myolo_tensor gx[4]; int acc[4]; int off[4]; int n; };
+template <typename T>
+__global__ __launch_bounds__(256) void pyr_up_bwd_finish_kernel(PyrFin p, const float* __restrict__ scratch) {
+  constexpr int SEG = ET<T>::SEG;
+  for (int t = 0; t < p.n; ++t) {
+    const myolo_tensor& gx = p.gx[t];
+    const int G = gx.c / SEG;
+    const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
+    GRID_STRIDE(v, total) {
+      int n, y, xx, cg;
+      dec(v, G, gx.w, gx.h, n, y, xx, cg);
+      const float* sp = scratch + p.off[t] + (((size_t)n * gx.h + y) * gx.w + xx) * gx.c + cg * SEG;
+      float a[SEG];
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] = sp[i];
+      T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+      if (p.acc[t]) {
+        float o[SEG];
+        Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += o[i];
+      }
+      stg16(gp, Vec<T>::pack(a));
+    }
+  }
+}
+
 // ---------------------------------------------------------------- adaptive average pool
 // bin i of k over H: [floor(i*H/k), ceil((i+1)*H/k))
 template <typename T>
@@ -1008,6 +1121,38 @@ extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_
                                           void* stream) {
   if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
   DISPATCH(gx->dtype, aap_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx, accumulate);
+  return 0;
+}
+extern "C" int myolo_pyramid_upsample_bwd(const myolo_tensor* gout, const myolo_tensor* gxs, int count, const int32_t* accumulate,
+                                          float* scratch, void* stream) {
+  if (!gout || !gxs || !scratch || count < 1 || count > 4 || !vec_ok(gout) || gout->c % count) return MYOLO_EINVAL;
+  const int seg = gout->dtype == MYOLO_F16 ? 8 : 4;
+  const int cbr = gout->c / count;
+  if (cbr % seg || gout->c / seg > 16) return MYOLO_EINVAL;
+  PyrUp k;
+  PyrFin f;
+  k.gout = *gout; k.cgs_per_branch = cbr / seg; k.nbranch = count; k.rows = 4;
+  f.n = count;
+  int off = 0;
+  for (int t = 0; t < count; ++t) {
+    const myolo_tensor& g = gxs[t];
+    if (!vec_ok(&g) || g.n != gout->n || g.c != cbr || g.dtype != gout->dtype || g.h != g.w || g.h < 1 || g.h > 6) return MYOLO_EINVAL;
+    k.k[t] = g.h; k.sy[t] = ac_scale(g.h, gout->h); k.sx[t] = ac_scale(g.w, gout->w); k.off[t] = off;
+    f.gx[t] = g; f.acc[t] = accumulate ? accumulate[t] : 0; f.off[t] = off;
+    off += g.n * g.h * g.w * cbr;
+  }
+  for (int t = count; t < 4; ++t) { k.k[t] = 1; k.sy[t] = k.sx[t] = 0.f; k.off[t] = 0; }
+  hipStream_t st = (hipStream_t)stream;
+  const int strips = (gout->h + k.rows - 1) / k.rows;
+  const int threads = (gout->c / seg) * 16;
+  if (gout->dtype == MYOLO_F16) {
+    hipLaunchKernelGGL(pyr_up_bwd_kernel<half_t>, dim3(gout->n * strips), dim3(threads), 0, st, k, scratch);
+    hipLaunchKernelGGL(pyr_up_bwd_finish_kernel<half_t>, dim3(grid_for(off / seg, 256)), dim3(256), 0, st, f, scratch);
+  } else {
+    hipLaunchKernelGGL(pyr_up_bwd_kernel<float>, dim3(gout->n * strips), dim3(threads), 0, st, k, scratch);
+    hipLaunchKernelGGL(pyr_up_bwd_finish_kernel<float>, dim3(grid_for(off / seg, 256)), dim3(256), 0, st, f, scratch);
+  }
+  MYOLO_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int count, const myolo_tensor* gx, int accumulate,

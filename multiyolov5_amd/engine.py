@@ -534,10 +534,53 @@ class CopyUpOp(SimpleOp):
 
 
 class BilinearOp(SimpleOp):
+    """bilinear align_corners resize.  `group` (PyramidPooling's four upsamples, forward order): when their outputs are adjacent
+    equal-width channel slices of one buffer, the four backward passes run as one pass over that buffer (myolo_pyramid_upsample_bwd)
+    at the position of the group's LAST member (= the first of them in the backward; every consumer of the concat ran before)."""
+
+    def __init__(self, plan, src, dst, group=None):
+        super().__init__(plan, src, dst)
+        self.group = group
+        if group is not None:
+            group.append(self)
+
+    def _group_fused(self, plan):
+        g = self.group
+        if g is None or len(g) < 2 or len(g) > 4 or os.environ.get('MYOLO_NO_PYR_FUSE', '0') == '1':
+            return False
+        d0 = g[0].dst
+        seg = SEG[plan.dtype]
+        for i, o in enumerate(g):
+            d, s_ = o.dst, o.src
+            if d.buf is not d0.buf or d.c != d0.c or d.coff != d0.coff + i * d0.c or (d.h, d.w) != (d0.h, d0.w) or d.c % seg:
+                return False
+            if s_.h != s_.w or s_.h > 6 or s_.c != d.c or not s_.requires_grad:
+                return False
+        return len(g) * d0.c // seg <= 16
+
     def emit_fwd(self, plan):
         self.fwd_calls.append(Call('myolo_bilinear_fwd', (C.byref(self.sd), C.byref(self.dd))))
 
     def emit_bwd(self, plan):
+        if self._group_fused(plan):
+            g = self.group
+            if self is g[-1]:
+                zero = []
+                for o in g:
+                    zero += o._zero_calls(plan)
+                self.bwd_calls = zero
+                d0 = g[0].dst
+                allv = TV(plan, d0.n, d0.h, d0.w, d0.c * len(g))
+                allv.place(d0.buf, d0.coff)
+                self.gall = allv.desc(grad=True)
+                self.gxs = (CT * len(g))(*[o.src.desc(grad=True) for o in g])
+                self.gacc = (C.c_int32 * len(g))(*[int(o.acc) for o in g])
+                scratch = plan.f32_bwd_zero(sum(o.src.n * o.src.h * o.src.w * o.src.c for o in g))
+                self.bwd_calls.append(Call('myolo_pyramid_upsample_bwd', (C.byref(self.gall), self.gxs, len(g), self.gacc, L.ptr(scratch)),
+                                           keep=scratch))
+            else:
+                self.bwd_calls = []
+            return
         s_, d_ = self.src, self.dst
         scratch = None
         if s_.h <= 6 and s_.w <= 6 and (d_.h // max(s_.h, 1)) * (d_.w // max(s_.w, 1)) >= 64:      # PyramidPooling footprints

@@ -245,9 +245,9 @@ class Upsample(PlannedModule):
         return out
 
 
-def emit_bilinear(plan, x, h, w):
+def emit_bilinear(plan, x, h, w, group=None):
     out = plan.new(x.n, h, w, x.c)
-    plan.add(E.BilinearOp(plan, x, out))
+    plan.add(E.BilinearOp(plan, x, out, group))
     return out
 
 
@@ -433,9 +433,9 @@ class PyramidPooling(PlannedModule):
 
     def emit(self, plan, x):
         feats = [x]
-        group = []                                            # the four pools share one backward launch (engine.AvgPoolOp)
+        group, ups = [], []                                   # the four pools / the four upsamples share one backward pass each (engine)
         for k, conv in zip(self.k, (self.conv1, self.conv2, self.conv3, self.conv4)):
-            feats.append(emit_bilinear(plan, conv.emit(plan, emit_avgpool(plan, x, k, group)), x.h, x.w))
+            feats.append(emit_bilinear(plan, conv.emit(plan, emit_avgpool(plan, x, k, group)), x.h, x.w, ups))
         return plan.cat(feats)
 
 
