@@ -18,6 +18,7 @@ from ._lib import Tensor as CT
 # MYOLO_GRAPH_TRAIN=1: training launch lists are replayed as hipGraphs instead of enqueued call by call (see Plan.run_fwd / run_bwd).
 # Opt-in: the step is bound by the main stream'''s kernel time, not by the host (measured r2: eager 10.48 ms, graphs 10.59 ms per step)
 GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '0') != '0'
+LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
@@ -763,8 +764,15 @@ class SegOutOp(Op):
         out._myolo_low = lw.torch_view()                # low-res class logits: utils.general.seg_argmax fuses resize+argmax on them
         self.ld = lw.desc()
         sn, sc, sh, sw = out.stride()
-        self.fwd_calls.append(Call('myolo_seg_upsample_fwd', (C.byref(self.ld), L.ptr(out), L.DT[out.dtype], H, W, sn, sc, sh, sw),
-                                   keep=out))
+        up = Call('myolo_seg_upsample_fwd', (C.byref(self.ld), L.ptr(out), L.DT[out.dtype], H, W, sn, sc, sh, sw), keep=out)
+        # training: the full-resolution logits (318 MB at 16x19x512x1024) are consumed by the fused loss from the LOW-resolution map
+        # (K15) and nothing reads them -- the upsample is deferred until something other than that loss touches the tensor
+        # (runtime.LazySegLogits).  Captured training graphs keep the eager launch.
+        self.lazy_call = up if (plan.training and LAZY_SEG and not GRAPH_TRAIN) else None
+        if self.lazy_call is None:
+            self.fwd_calls.append(up)
+        else:
+            out._myolo_lazy = self
         if plan.training:
             g = torch.zeros_like(store).permute(0, 3, 1, 2)
             plan.output_grads[self.slot] = g

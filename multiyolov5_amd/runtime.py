@@ -80,6 +80,54 @@ class _OutSpec:
         return [_OutSpec.rebuild(s, vals) for s in v]
 
 
+class LazySegLogits(torch.Tensor):
+    """The training-mode segmentation output `pred[1]` (models/yolo.py:163: the x8 bilinear upsample of the class logits).  The fused
+    loss reads the LOW-resolution logits (utils/loss._SegCE) and never needs these 38 bytes per pixel; everything else --
+    any torch function or method other than pure metadata -- first runs the deferred upsample launch into the tensor's storage
+    (`materialize`), so the values any other consumer sees are the reference's.  A tensor of an OLDER forward cannot be materialised
+    once the plan's activations were overwritten: that raises instead of returning stale data."""
+    _META = None
+
+    @staticmethod
+    def _meta_funcs():
+        T = torch.Tensor
+        names = ('shape', 'dtype', 'device', 'requires_grad', 'grad_fn', 'is_cuda', 'ndim', 'is_leaf', 'layout', 'grad', 'names',
+                 'is_sparse', 'is_quantized', 'is_meta', 'output_nr', '_version', 'is_mkldnn', 'is_xpu', 'is_cpu')
+        fs = {getattr(T, n).__get__ for n in names if hasattr(T, n)}
+        fs |= {T.stride, T.size, T.dim, T.numel, T.is_contiguous, T.element_size, T.is_floating_point, T.is_complex, T.storage_offset,
+               T.nelement, T.ndimension, T.get_device, T.__len__, T.register_hook, T.retain_grad, T.backward, T.requires_grad_,
+               T.__hash__}
+        fs.add(getattr(T, 'grad').__set__)
+        return fs
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        if cls._META is None:
+            cls._META = cls._meta_funcs()
+        if func not in cls._META:
+            for a in tuple(args) + tuple((kwargs or {}).values()):
+                for t in (a if isinstance(a, (list, tuple)) else (a,)):
+                    if isinstance(t, LazySegLogits):
+                        materialize(t)
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*args, **(kwargs or {}))
+
+
+def materialize(t):
+    """run the deferred upsample of a LazySegLogits (no-op for anything else / when already done)"""
+    st = t.__dict__.get('_myolo_lazy_state')
+    if st is None or st['done']:
+        return t
+    holder, op = st['holder'], st['op']
+    if holder.generation != st['generation']:
+        raise L.MyoloError('segmentation logits of an earlier forward were read after a newer forward of the same module overwrote '
+                           "the plan's activations (they are materialised on first use; read them before the next forward, or set "
+                           'MYOLO_LAZY_SEG=0)')
+    op.lazy_call(L.stream_ptr())
+    st['done'] = True
+    return t
+
+
 class PlanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, holder, *tensors):
@@ -89,9 +137,14 @@ class PlanFn(torch.autograd.Function):
         holder.bind_inputs(tensors[:holder.n_in])
         plan.run_fwd()
         plan.capture_bwd(holder.module.__dict__.get('_grad_reducer'))      # no-op until the forward graph exists / once captured
+        holder.generation += 1                       # activations / BN statistics / dropout masks of this forward
         outs = []
         for o in holder.output_tensors():
             d = o.detach()
+            lazy = o.__dict__.get('_myolo_lazy')
+            if lazy is not None:
+                d = d.as_subclass(LazySegLogits)
+                d._myolo_lazy_state = {'holder': holder, 'op': lazy, 'generation': holder.generation, 'done': False}
             for attr in ('_myolo_low', '_myolo_grad_buf', '_myolo_grad_scale', '_myolo_low_grad'):   # side channels of the fused loss / argmax kernels
                 if hasattr(o, attr):
                     setattr(d, attr, getattr(o, attr))
@@ -99,7 +152,6 @@ class PlanFn(torch.autograd.Function):
         outs = tuple(outs)
         for sc in plan.output_scales.values():        # (a fused low-resolution CE of an earlier forward that never ran its backward)
             sc[1]['low'] = False
-        holder.generation += 1                       # activations / BN statistics / dropout masks of this forward
         ctx.generation = holder.generation
         holder.pending_bwd = True
         return outs

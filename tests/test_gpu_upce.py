@@ -143,3 +143,53 @@ def test_unused_segmentation_loss_contributes_no_gradient():
     assert aux and all(float(p.grad.abs().max()) == 0 for p in aux)
     main = [p for n, p in mod.named_parameters() if n.startswith('out')]
     assert main and any(float(p.grad.abs().max()) > 0 for p in main)
+
+
+def _psp_head():
+    from multiyolov5_amd.models import yolo as Y
+    from multiyolov5_amd.utils.torch_utils import initialize_weights
+    from tests.test_gpu_ops import _randomize
+    torch.manual_seed(4)
+    mod = Y.SegMaskPSP(19, 1, 64, False, [64, 128, 256])
+    initialize_weights(mod)
+    _randomize(mod)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(s, generator=g) for s in [(2, 64, 16, 32), (2, 128, 8, 16), (2, 256, 4, 8)]]
+    tgt = torch.randint(-1, 19, (2, 128, 256), generator=g).to(DEV)
+    return mod.to(DEV).train(), xs, tgt
+
+
+def test_training_logits_are_materialised_only_on_demand(monkeypatch):
+    """models/yolo.py:163's x8-upsampled logits in training mode: the fused loss never needs them (no upsample launch), any other use
+    runs the deferred launch first and sees exactly the values of the eager path; a tensor of an older forward raises"""
+    from multiyolov5_amd import _lib as L, engine as E, runtime as R
+    from multiyolov5_amd.utils import loss as loss_mod
+    mod, xs_cpu, tgt = _psp_head()
+    xs = [x.to(DEV).requires_grad_() for x in xs_cpu]
+    out = mod(xs)
+    assert isinstance(out, R.LazySegLogits) and tuple(out.shape) == (2, 19, 128, 256) and out.dtype == torch.float32
+    st = out._myolo_lazy_state
+    assert st['done'] is False
+    loss = loss_mod.seg_cross_entropy(out, tgt)
+    loss.backward()
+    assert st['done'] is False                                    # the whole step ran without the full-resolution tensor
+    g_fused = [x.grad.clone() for x in xs]
+    # second forward: now read the logits like any tensor
+    xs2 = [x.to(DEV).requires_grad_() for x in xs_cpu]
+    out2 = mod(xs2)
+    with pytest.raises(L.MyoloError):
+        out.sum()                                                 # first forward's logits: the plan has moved on
+    vals = out2.detach().float().cpu()
+    assert out2._myolo_lazy_state['done'] is True and type(vals) is torch.Tensor
+    loss2 = torch.nn.functional.cross_entropy(out2, tgt, ignore_index=-1)     # a consumer that is NOT the fused loss
+    loss2.backward()
+    assert abs(float(loss2) - float(loss)) <= 1e-5 * abs(float(loss))
+    for a, b in zip(g_fused, [x.grad for x in xs2]):
+        assert float((a - b).abs().max()) <= 2e-4 * float(b.abs().max())
+    # eager reference: a fresh module instance with the deferral switched off
+    monkeypatch.setattr(E, 'LAZY_SEG', False)
+    mod3, _, _ = _psp_head()
+    out3 = mod3([x.to(DEV) for x in xs_cpu])
+    assert not isinstance(out3, R.LazySegLogits)
+    ref = out3.detach().float().cpu()                             # (two forwards differ in the last bits: the BatchNorm sums are fp32 atomics)
+    assert float((ref - vals).abs().max()) <= 2e-5 * float(ref.abs().max())
