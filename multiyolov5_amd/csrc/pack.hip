@@ -61,6 +61,56 @@ __global__ __launch_bounds__(256) void pack_weights_mt_kernel(const int64_t* job
   }
 }
 
+// the same through LDS tiles (chunk_elems == 0: chunks = {job, tile}): the element-per-thread kernel above reads the OIHW source
+// with the destination's index order -- a transposed (dgrad) pack touches a different 64-byte line per lane, a 3x3 forward pack
+// re-reads every line once per tap: 414 MB of fetches for 31 MB of weights, 84 us at the head of every training forward.  Here a
+// workgroup owns a [co tile] x [ci tile] x all taps block: the source rows are read as contiguous runs (ci*taps is contiguous in
+// OIHW), transposed in LDS, and written as 64-byte runs of the destination's fastest index.  Padding rows / columns are NOT written:
+// the packed tensors are allocated zeroed and nothing else writes them.
+constexpr int PACK_TILE = 512;             // (co x ci) pairs per tile: 16 x 32 (forward operand) or 32 x 16 (transposed); 64 x 64 for 1x1 weights
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const int64_t* jobs, const int32_t* chunks) {
+  extern __shared__ float tile[];          // [tco][tci * taps]
+  const int j = chunks[blockIdx.x * 2], tid_tile = chunks[blockIdx.x * 2 + 1];
+  const int64_t* e = jobs + (int64_t)j * 12;
+  const void* src = reinterpret_cast<const void*>(e[0]);
+  void* dst = reinterpret_cast<void*>(e[1]);
+  const int cout = (int)e[2], cin = (int)e[3], ntaps = (int)e[4], cols_pad = (int)e[6];
+  const int transpose = (int)e[7], sdt = (int)e[8], ddt = (int)e[9];
+  const void* src2 = reinterpret_cast<const void*>(e[10]);
+  const int cout_all = cout + (src2 ? (int)e[11] : 0);
+  const int tco = ntaps == 1 ? 64 : (transpose ? 32 : 16), tci = ntaps == 1 ? 64 : (transpose ? 16 : 32);   // ~4-13 K elements per workgroup
+  const int tiles_ci = (cin + tci - 1) / tci;
+  const int co0 = (tid_tile / tiles_ci) * tco, ci0 = (tid_tile % tiles_ci) * tci;
+  const bool f16s = sdt == MYOLO_F16, f16d = ddt == MYOLO_F16;
+  const int run = tci * ntaps;                                   // contiguous source elements per output channel of the tile
+  const int nci = cin - ci0 < tci ? cin - ci0 : tci;
+  for (int i = threadIdx.x; i < tco * run; i += 256) {
+    const int col = i / run, r = i - col * run;
+    const int co = co0 + col;
+    float v = 0.f;
+    if (co < cout_all && r < nci * ntaps) {
+      const bool second = co >= cout;
+      const void* sp = second ? src2 : src;
+      const int64_t si = ((int64_t)(second ? co - cout : co) * cin + ci0) * ntaps + r;
+      v = f16s ? (float)((const half_t*)sp)[si] : ((const float*)sp)[si];
+    }
+    tile[i] = v;
+  }
+  __syncthreads();
+  // destination element (row, t, col): forward operand row = co, col = ci; transposed row = ci, col = co
+  const int fast = transpose ? tco : tci, slow = transpose ? tci : tco;
+  for (int i = threadIdx.x; i < slow * ntaps * fast; i += 256) {
+    const int f = i % fast, q = i / fast;
+    const int t = q % ntaps, sl = q / ntaps;
+    const int col = transpose ? f : sl, cil = transpose ? sl : f;       // tile-local co / ci
+    const int co = co0 + col, ci = ci0 + cil;
+    if (co >= cout_all || ci >= cin) continue;
+    const float v = tile[col * run + cil * ntaps + t];
+    const int64_t di = transpose ? ((int64_t)ci * ntaps + t) * cols_pad + co : ((int64_t)co * ntaps + t) * cols_pad + ci;
+    if (f16d) ((half_t*)dst)[di] = (half_t)v; else ((float*)dst)[di] = v;
+  }
+}
+
 template <typename S, typename D>
 __global__ void focus_pack_kernel(const S* __restrict__ img, int n, int h, int w, float mul, myolo_tensor out) {
   const int ho = h >> 1, wo = w >> 1;
@@ -135,8 +185,14 @@ extern "C" int myolo_focus_pack(const void* img, int src_dtype, int n, int h, in
 }
 
 extern "C" int myolo_pack_weights_mt(const int64_t* jobs, const int32_t* chunks, int nchunks, int chunk_elems, void* stream) {
-  if (!jobs || !chunks || nchunks < 0 || chunk_elems < 1) return MYOLO_EINVAL;
+  if (!jobs || !chunks || nchunks < 0 || chunk_elems < 0) return MYOLO_EINVAL;
   if (nchunks == 0) return 0;
+  if (chunk_elems == 0) {                   // tiled mode: chunks = {job, tile of PACK_TILE (co, ci) pairs}; ntaps <= MYOLO_MAX_TAPS
+    const size_t smem = (size_t)PACK_TILE * MYOLO_MAX_TAPS * sizeof(float);      // (>= the 64 x 64 floats of a 1x1 tile)
+    hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3(nchunks), dim3(256), smem, (hipStream_t)stream, jobs, chunks);
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
   hipLaunchKernelGGL(pack_weights_mt_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, jobs, chunks, chunk_elems);
   MYOLO_CHECK_LAUNCH();
   return 0;

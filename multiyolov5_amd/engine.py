@@ -18,6 +18,7 @@ from ._lib import Tensor as CT
 # MYOLO_GRAPH_TRAIN=1: training launch lists are replayed as hipGraphs instead of enqueued call by call (see Plan.run_fwd / run_bwd).
 # Opt-in: the step is bound by the main stream'''s kernel time, not by the host (measured r2: eager 10.48 ms, graphs 10.59 ms per step)
 GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '0') != '0'
+PACK_TILED = os.environ.get('MYOLO_PACK_TILED', '1') != '0'        # per-forward weight repack through LDS tiles (coalesced OIHW reads)
 LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
@@ -864,8 +865,14 @@ class Plan:
         for j, (w, dst, cout, cin, ntaps, rp, cp, tr, w2) in enumerate(self._pack_jobs):
             rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, ntaps, rp, cp, tr, L.DT[w.dtype], L.DT[dst.dtype],
                          w2.data_ptr() if w2 is not None else 0, w2.shape[0] if w2 is not None else 0))
-            for s0 in range(0, rp * ntaps * cp, CH):
-                chunks.append((j, s0))
+            if PACK_TILED:                # LDS-tiled pack: coalesced source reads (the packed tensors are zero-initialised: padding stays)
+                ca = cout + (w2.shape[0] if w2 is not None else 0)
+                tco, tci = (64, 64) if ntaps == 1 else ((32, 16) if tr else (16, 32))
+                for t_ in range(((ca + tco - 1) // tco) * ((cin + tci - 1) // tci)):
+                    chunks.append((j, t_))
+            else:
+                for s0 in range(0, rp * ntaps * cp, CH):
+                    chunks.append((j, s0))
         self._pack_key = tuple((r[0], r[10]) for r in rows)
         if not rows:
             self._pack_call = None
@@ -873,7 +880,7 @@ class Plan:
         dev = self.device
         self._pack_tab = torch.tensor(rows, dtype=torch.int64).reshape(-1, 12).to(dev)
         self._pack_chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
-        self._pack_call = Call('myolo_pack_weights_mt', (L.ptr(self._pack_tab), L.ptr(self._pack_chunks), len(chunks), CH))
+        self._pack_call = Call('myolo_pack_weights_mt', (L.ptr(self._pack_tab), L.ptr(self._pack_chunks), len(chunks), 0 if PACK_TILED else CH))
 
     def add_input(self, t):
         """declare an input tensor slot (shape/stride/dtype are part of the plan; the pointer is rebound per run)."""
