@@ -323,13 +323,82 @@ def _invert_for_warp(M):
     return m
 
 
+def _finish_sample(lab, width, height, hyp, rng, nprng):
+    """the tail of __getitem__ shared by both branches (datasets.py:558-584): augment_hsv draw, pixel xyxy -> normalised xywh, flips"""
+    lut = hsv_luts(hyp, nprng)
+    nL = len(lab)
+    if nL:                                                            # general.xyxy2xywh, then normalise by the image size
+        x1, y1, x2, y2 = lab[:, 1].copy(), lab[:, 2].copy(), lab[:, 3].copy(), lab[:, 4].copy()
+        lab[:, 1], lab[:, 2], lab[:, 3], lab[:, 4] = (x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1
+        lab[:, [2, 4]] /= height
+        lab[:, [1, 3]] /= width
+    flipud = rng.random() < hyp['flipud']
+    if flipud and nL:
+        lab[:, 2] = 1 - lab[:, 2]
+    fliplr = rng.random() < hyp['fliplr']
+    if fliplr and nL:
+        lab[:, 1] = 1 - lab[:, 1]
+    out_lab = torch.zeros((nL, 6))
+    if nL:
+        out_lab[:, 1:] = torch.from_numpy(lab)
+    return lut, flipud, fliplr, out_lab
+
+
+def _launch_warp(srcs, canvas_wh, M, warp, out_wh, lut, fliplr, flipud):
+    """srcs: [(uint8 [h,w,3] tensor, x1a, y1a, x2a, y2a, padw, padh)] -> uint8 [3,oh,ow] RGB"""
+    dev = srcs[0][0].device
+    d = L.MosaicDesc()
+    d.nsrc, d.cw, d.ch, d.warp, d.ow, d.oh = len(srcs), canvas_wh[0], canvas_wh[1], int(warp), out_wh[0], out_wh[1]
+    for k, (im, x1a, y1a, x2a, y2a, padw, padh) in enumerate(srcs):
+        L.require_gpu(im)
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or not im.is_contiguous():
+            raise L.MyoloError('images must be contiguous uint8 [h,w,3] tensors')
+        if x2a <= x1a or y2a <= y1a:                                  # empty window (the centre lies outside the canvas on that side)
+            x1a = y1a = x2a = y2a = 0
+            padw = padh = 0
+        sk = d.src[k]
+        sk.img, sk.h, sk.w = im.data_ptr(), int(im.shape[0]), int(im.shape[1])
+        sk.x1a, sk.y1a, sk.x2a, sk.y2a, sk.padw, sk.padh = x1a, y1a, x2a, y2a, padw, padh
+    Mi = _invert_for_warp(M) if warp else np.array([[1.0, 0, 0], [0, 1.0, 0]])
+    for k in range(6):
+        d.M[k] = float(Mi.reshape(-1)[k])
+    lut_d = torch.from_numpy(np.ascontiguousarray(lut)).to(dev)
+    out = torch.empty(3, out_wh[1], out_wh[0], dtype=torch.uint8, device=dev)
+    d.hsv_lut, d.fliplr, d.flipud, d.fill, d.out_chw = lut_d.data_ptr(), int(fliplr), int(flipud), 114, out.data_ptr()
+    L.check(L.lib().myolo_mosaic_warp(C.byref(d), L.stream_ptr()), 'myolo_mosaic_warp')
+    return out
+
+
+def _single_train_sample(index, images, labels, img_size, hyp, rng, nprng):
+    """the non-mosaic training branch of __getitem__ (datasets.py:536-556): letterbox(img, img_size, auto=False, scaleup=True) of the
+    (already long-side-resized) image -> random_perspective with border (0, 0) -> augment_hsv -> flips"""
+    from .datasets import letterbox_params
+    im = images(index)
+    h, w = int(im.shape[0]), int(im.shape[1])
+    new_unpad, ratio, (dw, dh), (top, bottom, left, right) = letterbox_params((h, w), img_size, auto=False, scaleFill=False, scaleup=True)
+    if tuple(new_unpad) != (w, h):
+        im = resize_u8(im, new_unpad[0], new_unpad[1])                # (only when the cached image is not at the target long side)
+    H, W = new_unpad[1] + top + bottom, new_unpad[0] + left + right
+    lab = labels(index).copy()
+    if lab.size:
+        lab[:, 1:] = _boxes_norm_to_pixels(lab[:, 1:], ratio[0] * w, ratio[1] * h, dw, dh)
+    M, sc, (width, height) = draw_perspective_matrix((H, W), hyp, (0, 0), rng)
+    if hyp['perspective']:
+        raise NotImplementedError('perspective != 0 (cv2.warpPerspective) is not on the device path; hyp.scratch.yaml uses 0')
+    warp = bool((M != np.eye(3)).any())
+    lab = warp_boxes(lab, M, sc, width, height)
+    lut, flipud, fliplr, out_lab = _finish_sample(lab, W, H, hyp, rng, nprng)
+    out = _launch_warp([(im, left, top, left + new_unpad[0], top + new_unpad[1], left, top)], (W, H), M, warp, (width, height), lut, fliplr, flipud)
+    return out, out_lab
+
+
 def mosaic_train_sample(index, images, labels, indices, img_size, hyp, rng=_random, nprng=np.random):
     """LoadImagesAndLabels.__getitem__ for a training dataset with mosaic (datasets.py:518-593).
     images: index -> uint8 [h,w,3] BGR tensor on the GPU, already `load_image`d (long side = img_size; see load_image_dev);
     labels: index -> float32 [n,5] (cls, normalised xywh).  Returns (uint8 [3,s,s] RGB tensor on the GPU, labels_out float32 [nL,6])."""
     s = img_size
     if not (rng.random() < hyp['mosaic']):
-        raise NotImplementedError('the non-mosaic branch (letterbox + random_perspective) is not on the device path')
+        return _single_train_sample(index, images, labels, img_size, hyp, rng, nprng)
     border = [-s // 2, -s // 2]
     yc, xc = [int(rng.uniform(-x, 2 * s + x)) for x in border]
     idx4 = [index] + rng.choices(indices, k=3)
@@ -351,41 +420,7 @@ def mosaic_train_sample(index, images, labels, indices, img_size, hyp, rng=_rand
     lab4 = warp_boxes(lab4, M, sc, width, height)
     if rng.random() < hyp['mixup']:
         raise NotImplementedError('mixup (hyp.scratch.yaml: 0.0) is not on the device path')
-    lut = hsv_luts(hyp, nprng)
-    nL = len(lab4)
-    if nL:                                                            # pixel xyxy -> normalised xywh (general.xyxy2xywh)
-        x1, y1, x2, y2 = lab4[:, 1].copy(), lab4[:, 2].copy(), lab4[:, 3].copy(), lab4[:, 4].copy()
-        lab4[:, 1], lab4[:, 2], lab4[:, 3], lab4[:, 4] = (x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1
-        lab4[:, [2, 4]] /= height
-        lab4[:, [1, 3]] /= width
-    flipud = rng.random() < hyp['flipud']
-    if flipud and nL:
-        lab4[:, 2] = 1 - lab4[:, 2]
-    fliplr = rng.random() < hyp['fliplr']
-    if fliplr and nL:
-        lab4[:, 1] = 1 - lab4[:, 1]
-    out_lab = torch.zeros((nL, 6))
-    if nL:
-        out_lab[:, 1:] = torch.from_numpy(lab4)
-    # pixels: one fused launch
-    dev = imgs[0].device
-    d = L.MosaicDesc()
-    d.nsrc, d.cw, d.ch, d.warp, d.ow, d.oh = 4, 2 * s, 2 * s, 1, width, height
-    for k, (im, (h, w)) in enumerate(zip(imgs, hw4)):
-        L.require_gpu(im)
-        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3 or not im.is_contiguous():
-            raise L.MyoloError('images must be contiguous uint8 [h,w,3] tensors')
-        x1a, y1a, x2a, y2a, padw, padh = lay[k]
-        if x2a <= x1a or y2a <= y1a:                                  # empty window (the centre lies outside the canvas on that side)
-            x1a = y1a = x2a = y2a = 0
-            padw = padh = 0
-        sk = d.src[k]
-        sk.img, sk.h, sk.w, sk.x1a, sk.y1a, sk.x2a, sk.y2a, sk.padw, sk.padh = im.data_ptr(), h, w, x1a, y1a, x2a, y2a, padw, padh
-    Mi = _invert_for_warp(M)
-    for k in range(6):
-        d.M[k] = float(Mi.reshape(-1)[k])
-    lut_d = torch.from_numpy(np.ascontiguousarray(lut)).to(dev)
-    out = torch.empty(3, height, width, dtype=torch.uint8, device=dev)
-    d.hsv_lut, d.fliplr, d.flipud, d.fill, d.out_chw = lut_d.data_ptr(), int(fliplr), int(flipud), 114, out.data_ptr()
-    L.check(L.lib().myolo_mosaic_warp(C.byref(d), L.stream_ptr()), 'myolo_mosaic_warp')
+    lut, flipud, fliplr, out_lab = _finish_sample(lab4, width, height, hyp, rng, nprng)
+    srcs = [(im, *lay[k]) for k, im in enumerate(imgs)]
+    out = _launch_warp(srcs, (2 * s, 2 * s), M, True, (width, height), lut, fliplr, flipud)
     return out, out_lab

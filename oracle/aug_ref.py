@@ -334,6 +334,14 @@ def install_cv2_stub(cv2):
             return dst
         return out
     cv2.resize, cv2.warpAffine, cv2.cvtColor = resize, warp_affine, cvt
+    cv2.BORDER_CONSTANT = 0
+
+    def copy_make_border(img, top, bottom, left, right, border_type, value=(0, 0, 0)):
+        out = np.empty((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), img.dtype)
+        out[...] = np.array(value, img.dtype)
+        out[top:top + img.shape[0], left:left + img.shape[1]] = img
+        return out
+    cv2.copyMakeBorder = copy_make_border
     cv2.getRotationMatrix2D = lambda angle, center, scale: cv_get_rotation_matrix_2d(center, angle, scale)
     cv2.split = lambda m: [np.ascontiguousarray(m[..., k]) for k in range(m.shape[2])]
     cv2.merge = lambda planes: np.stack(planes, -1)

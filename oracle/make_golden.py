@@ -418,7 +418,10 @@ DET_HYPS = {
     'rot': dict(degrees=10.0, translate=0.1, scale=0.5, shear=5.0, perspective=0.0, flipud=0.5, fliplr=0.5, mosaic=1.0, mixup=0.0,
                 hsv_h=0.015, hsv_s=0.7, hsv_v=0.4),
 }
-DET_CASES = [('scratch', 0, 1), ('scratch', 3, 2), ('rot', 1, 3), ('rot', 5, 4), ('scratch', 2, 7), ('rot', 4, 11)]   # (hyp, index, seed)
+DET_HYPS['single'] = dict(DET_HYPS['scratch'], mosaic=0.0)       # the letterbox + random_perspective branch (datasets.py:536-556)
+DET_HYPS['single_rot'] = dict(DET_HYPS['rot'], mosaic=0.0)
+DET_CASES = [('scratch', 0, 1), ('scratch', 3, 2), ('rot', 1, 3), ('rot', 5, 4), ('scratch', 2, 7), ('rot', 4, 11),
+             ('single', 0, 5), ('single', 3, 6), ('single_rot', 1, 8), ('single_rot', 4, 9)]   # (hyp, index, seed)
 
 
 def det_dataset():
