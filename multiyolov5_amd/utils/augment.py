@@ -107,6 +107,20 @@ def draw_sync_params(w, h, base_size, crop_size, low=0.65, high=3.0, std=25, rng
     return {'flip': bool(flip), 'ow': int(ow), 'oh': int(oh), 'x1': int(x1), 'y1': int(y1), 'wc': int(wc), 'hc': int(hc)}
 
 
+def testval_size(w, h, base_size):
+    """_testval_img_transform's target size (SegmentationDataset.py:80-94): long side -> base_size rounded up to a multiple of 32,
+    the other side scaled (truncated) and rounded up to a multiple of 32"""
+    div = lambda v: int(math.ceil(v / 32) * 32)                 # general.make_divisible(x, 32)
+    outlong = div(base_size)
+    if w > h:
+        ow = outlong
+        oh = div(int(1.0 * h * ow / w))
+    else:
+        oh = outlong
+        ow = div(int(1.0 * w * oh / h))
+    return ow, oh
+
+
 _DEV_TABLES = {}
 
 
@@ -124,6 +138,10 @@ def _dev(arr, device, key):
 def seg_sync_transform(img, mask, params, lab_lut=None):
     """img: uint8 [H0,W0,3] (RGB, as `Image.open(...).convert('RGB')`) and mask: uint8 [H0,W0] on the GPU; params from
     draw_sync_params.  Returns (crop uint8 [hc,wc,3], label int64 [hc,wc]) = `_sync_transform` + `_mask_transform`."""
+    return _seg_sync(img, mask, params, lab_lut, want_img=True)
+
+
+def _seg_sync(img, mask, params, lab_lut, want_img):
     L.require_gpu(img)
     if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3 or not img.is_contiguous():
         raise L.MyoloError('image must be a contiguous uint8 [H,W,3] tensor')
@@ -139,8 +157,8 @@ def seg_sync_transform(img, mask, params, lab_lut=None):
     d.img, d.H0, d.W0, d.flip, d.ow, d.oh = img.data_ptr(), H0, W0, int(params['flip']), ow, oh
     d.hb, d.hk, d.vb, d.vk, d.ksh, d.ksv = keep[0].data_ptr(), keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), hk.shape[1], vk.shape[1]
     d.x1, d.y1, d.wc, d.hc = params['x1'], params['y1'], wc, hc
-    out = torch.empty(hc, wc, 3, dtype=torch.uint8, device=dev)
-    d.out_img = out.data_ptr()
+    out = torch.empty(hc, wc, 3, dtype=torch.uint8, device=dev) if want_img else None
+    d.out_img = out.data_ptr() if want_img else None
     lab = None
     if mask is not None:
         lut = city_label_lut() if lab_lut is None else np.asarray(lab_lut, np.int64)
@@ -150,6 +168,25 @@ def seg_sync_transform(img, mask, params, lab_lut=None):
         d.mask, d.xin, d.yin, d.lab_lut, d.out_lab = mask.data_ptr(), keep[4].data_ptr(), keep[5].data_ptr(), keep[6].data_ptr(), lab.data_ptr()
     L.check(L.lib().myolo_seg_sync_transform(C.byref(d), L.stream_ptr()), 'myolo_seg_sync_transform')
     return out, lab
+
+
+def seg_testval_transform(img, mask, base_size, lab_lut=None):
+    """the validation sample of train.py:228-229 / test.py:71 (mode='testval', SegmentationDataset.py:201-204): the image resized
+    (BILINEAR) to testval_size, the label map only through `_mask_transform`.  Returns (uint8 [oh,ow,3], int64 [H0,W0])."""
+    H0, W0 = int(img.shape[0]), int(img.shape[1])
+    ow, oh = testval_size(W0, H0, base_size)
+    a, _ = seg_sync_transform(img, None, {'flip': False, 'ow': ow, 'oh': oh, 'x1': 0, 'y1': 0, 'wc': ow, 'hc': oh})
+    lab = None
+    if mask is not None:
+        lab = seg_label_map(img, mask, lab_lut)
+    return a, lab
+
+
+def seg_label_map(img, mask, lab_lut=None):
+    """CitySegmentation._mask_transform (SegmentationDataset.py:225-228) of an un-resized label map: id -> train id, int64"""
+    H0, W0 = int(mask.shape[0]), int(mask.shape[1])
+    p = {'flip': False, 'ow': W0, 'oh': H0, 'x1': 0, 'y1': 0, 'wc': W0, 'hc': H0}
+    return _seg_sync(img, mask, p, lab_lut, want_img=False)[1]
 
 
 # ---- ColorJitter + ToTensor (get_citys_loader: ColorJitter(brightness=0.45, contrast=0.45, saturation=0.45, hue=0.15)) -----------------

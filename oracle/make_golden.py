@@ -377,6 +377,12 @@ def augment_case(ref):
         out[f'c{ci}.img'] = np.array(a)
         out[f'c{ci}.lab'] = lab.numpy().astype(np.int8)
         out[f'c{ci}.after'] = np.float64(random.random())            # the generator state after the transform (same number of draws)
+    # validation samples (mode='testval', train.py:228-229): image through _testval_img_transform, label map through _mask_transform only
+    for inp, base in ((0, 128), (1, 96), (3, 160)):
+        ds = rsd.CitySegmentation(root='.', split='val', mode='testval', base_size=base, crop_size=(64, 64))
+        img, mask = augment_inputs(inp)
+        out[f'tv{inp}.img'] = np.array(ds._testval_img_transform(Image.fromarray(img)))
+        out[f'tv{inp}.lab'] = ds._mask_transform(Image.fromarray(mask)).numpy().astype(np.int8)
     np.savez_compressed(os.path.join(GOLD, 'augment_seg.npz'), **out)
     print('augment_seg', {k: v.shape for k, v in out.items() if k.endswith('img')})
 

@@ -113,3 +113,13 @@ def test_mosaic_sample_host_half_matches_reference_golden(monkeypatch):
         np.testing.assert_array_equal(lab.numpy(), g[f'c{ci}.lab'])
         assert [rng.random(), nprng.rand()] == list(g[f'c{ci}.after'])
     assert len(calls) == len(DET_CASES)
+
+
+def test_testval_size_matches_reference_golden_shapes():
+    from multiyolov5_amd.utils import augment as A
+    g = golden('augment_seg')
+    for inp, base in ((0, 128), (1, 96), (3, 160)):
+        img, _ = augment_inputs(inp)
+        ow, oh = A.testval_size(img.shape[1], img.shape[0], base)
+        assert g[f'tv{inp}.img'].shape[:2] == (oh, ow)
+        assert np.array_equal(aug_ref.pil_resize_bilinear(img, ow, oh), g[f'tv{inp}.img'])

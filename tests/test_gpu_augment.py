@@ -175,3 +175,15 @@ def test_mosaic_warp_kernel_vs_oracle_pieces():
     # rejected descriptors
     d.src[0].x2a = 200
     assert L.lib().myolo_mosaic_warp(C.byref(d), L.stream_ptr()) == L.EINVAL
+
+
+@pytest.mark.parametrize('case', [(0, 128), (1, 96), (3, 160)])
+def test_seg_testval_transform_matches_reference_golden(case):
+    """validation samples (train.py:228-229, mode='testval'): golden from the reference's `_testval_img_transform` / `_mask_transform`"""
+    from multiyolov5_amd.utils import augment as A
+    inp, base = case
+    g = golden('augment_seg')
+    img, mask = augment_inputs(inp)
+    a, lab = A.seg_testval_transform(torch.from_numpy(img).to(DEV), torch.from_numpy(mask).to(DEV), base)
+    assert np.array_equal(a.cpu().numpy(), g[f'tv{inp}.img'])
+    assert np.array_equal(lab.cpu().numpy(), g[f'tv{inp}.lab'].astype(np.int64))
