@@ -226,6 +226,8 @@ int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx,
 /* PyramidPooling (common.py:534-537): the backward of `count` (<= 4) bilinear align_corners upsamples of k x k maps (k <= 6) whose
  * outputs are ADJACENT equal-width channel slices of one tensor (`gout`: the view over all of them, <= 128 channels in fp16): one
  * pass over gout, gxs[t] (+)= result.  scratch: fp32 [sum of the gxs element counts], ZERO on entry, left dirty. */
+/* forward of the same: `count` bilinear align_corners upsamples of xs[t] into the adjacent equal-width channel slices of `out` */
+int myolo_pyramid_upsample_fwd(const myolo_tensor* xs, int count, const myolo_tensor* out, void* stream);
 int myolo_pyramid_upsample_bwd(const myolo_tensor* gout, const myolo_tensor* gxs, int count, const int32_t* accumulate, float* scratch,
                                void* stream);
 int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int count, const myolo_tensor* gx, int accumulate, void* stream);

@@ -129,6 +129,7 @@ _PROTOS = {
     'myolo_resize_u8': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, P, P]),
     'myolo_mosaic_warp': (C.c_int, [C.POINTER(MosaicDesc), P]),
     'myolo_adaptive_avgpool_bwd_multi': (C.c_int, [P, C.c_int, TP, C.c_int, P]),
+    'myolo_pyramid_upsample_fwd': (C.c_int, [P, C.c_int, TP, P]),
     'myolo_pyramid_upsample_bwd': (C.c_int, [TP, P, C.c_int, P, P, P]),
     'myolo_seg_upce_fwd_grad': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
     'myolo_seg_lowgrad_apply': (C.c_int, [P, TP, C.c_int, P, P]),

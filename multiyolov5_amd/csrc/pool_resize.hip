@@ -642,6 +642,34 @@ __global__ __launch_bounds__(256) void pyr_up_bwd_kernel(PyrUp p, float* __restr
   flush(icur + 1 < k ? icur + 1 : k - 1, bot);
 }
 
+// forward of the same four upsamples: one launch writes the four adjacent channel slices (bilinear_fwd_kernel's arithmetic per branch)
+struct PyrUpF { myolo_tensor x[4]; myolo_tensor out; int cgs_per_branch, n; float sy[4], sx[4]; };
+template <typename T>
+__global__ __launch_bounds__(256) void pyr_up_fwd_kernel(PyrUpF p) {
+  constexpr int SEG = ET<T>::SEG;
+  const int G = p.out.c / SEG;
+  const int64_t total = (int64_t)p.out.n * p.out.h * p.out.w * G;
+  GRID_STRIDE(v, total) {
+    int n, y, xx, cg;
+    dec(v, G, p.out.w, p.out.h, n, y, xx, cg);
+    const int t = cg / p.cgs_per_branch, cl = (cg - t * p.cgs_per_branch) * SEG;
+    const myolo_tensor& x = p.x[t];
+    const float fy = p.sy[t] * (float)y, fx = p.sx[t] * (float)xx;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + 1 < x.h ? y0 + 1 : x.h - 1, x1 = x0 + 1 < x.w ? x0 + 1 : x.w - 1;
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    float a[SEG], b[SEG], c[SEG], d[SEG], o[SEG];
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y0, x0) + cl), a);
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y0, x1) + cl), b);
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y1, x0) + cl), c);
+    Vec<T>::unpack(ldg16(vptr<T>(x, n, y1, x1) + cl), d);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i)
+      o[i] = (1.f - ly) * ((1.f - lx) * a[i] + lx * b[i]) + ly * ((1.f - lx) * c[i] + lx * d[i]);
+    stg16(vptr<T>(p.out, n, y, xx) + cg * SEG, Vec<T>::pack(o));
+  }
+}
+
 struct PyrFin { myolo_tensor gx[4]; int acc[4]; int off[4]; int n; };
 template <typename T>
 __global__ __launch_bounds__(256) void pyr_up_bwd_finish_kernel(PyrFin p, const float* __restrict__ scratch) {
@@ -1121,6 +1149,21 @@ extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_
                                           void* stream) {
   if (!vec_ok(gx) || !vec_ok(gout) || !same_nc(gx, gout)) return MYOLO_EINVAL;
   DISPATCH(gx->dtype, aap_bwd_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, *gout, *gx, accumulate);
+  return 0;
+}
+extern "C" int myolo_pyramid_upsample_fwd(const myolo_tensor* xs, int count, const myolo_tensor* out, void* stream) {
+  if (!xs || !out || count < 1 || count > 4 || !vec_ok(out) || out->c % count) return MYOLO_EINVAL;
+  const int seg = out->dtype == MYOLO_F16 ? 8 : 4;
+  const int cbr = out->c / count;
+  if (cbr % seg) return MYOLO_EINVAL;
+  PyrUpF k;
+  k.out = *out; k.cgs_per_branch = cbr / seg; k.n = count;
+  for (int t = 0; t < 4; ++t) {
+    const myolo_tensor& x = xs[t < count ? t : 0];
+    if (t < count && (!vec_ok(&x) || x.n != out->n || x.c != cbr || x.dtype != out->dtype)) return MYOLO_EINVAL;
+    k.x[t] = x; k.sy[t] = ac_scale(x.h, out->h); k.sx[t] = ac_scale(x.w, out->w);
+  }
+  DISPATCH(out->dtype, pyr_up_fwd_kernel, grid_for(nvec(out), 256), 256, 0, (hipStream_t)stream, k);
   return 0;
 }
 extern "C" int myolo_pyramid_upsample_bwd(const myolo_tensor* gout, const myolo_tensor* gxs, int count, const int32_t* accumulate,

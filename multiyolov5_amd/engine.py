@@ -546,7 +546,7 @@ class BilinearOp(SimpleOp):
         if group is not None:
             group.append(self)
 
-    def _group_fused(self, plan):
+    def _group_fused(self, plan, training=True):
         g = self.group
         if g is None or len(g) < 2 or len(g) > 4 or os.environ.get('MYOLO_NO_PYR_FUSE', '0') == '1':
             return False
@@ -556,11 +556,21 @@ class BilinearOp(SimpleOp):
             d, s_ = o.dst, o.src
             if d.buf is not d0.buf or d.c != d0.c or d.coff != d0.coff + i * d0.c or (d.h, d.w) != (d0.h, d0.w) or d.c % seg:
                 return False
-            if s_.h != s_.w or s_.h > 6 or s_.c != d.c or not s_.requires_grad:
+            if s_.h != s_.w or s_.h > 6 or s_.c != d.c or (training and not s_.requires_grad):
                 return False
         return len(g) * d0.c // seg <= 16
 
     def emit_fwd(self, plan):
+        if self._group_fused(plan, training=False):
+            g = self.group
+            if self is g[-1]:                     # the last source is ready: one launch writes the four adjacent slices
+                d0 = g[0].dst
+                allv = TV(plan, d0.n, d0.h, d0.w, d0.c * len(g))
+                allv.place(d0.buf, d0.coff)
+                self.fall = allv.desc()
+                self.fxs = (CT * len(g))(*[o.src.desc() for o in g])
+                self.fwd_calls.append(Call('myolo_pyramid_upsample_fwd', (self.fxs, len(g), C.byref(self.fall))))
+            return
         self.fwd_calls.append(Call('myolo_bilinear_fwd', (C.byref(self.sd), C.byref(self.dd))))
 
     def emit_bwd(self, plan):
