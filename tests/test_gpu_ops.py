@@ -1,5 +1,7 @@
 """-m gpu: every block of the hot path through the module API (-> plan -> libmyolo C ABI), forward and backward,
 against the CPU oracle restatement on the same seeded inputs.  fp32 parity mode and fp16."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -332,3 +334,101 @@ def test_bn_backward_sums_in_dgrad_epilogue_match_the_reduce_pass(case, dt):
         want = ref.view(L.STAT_COPIES, 2, c1 - c0).sum(0)
         assert float(want.abs().max()) > 1e-3
         check(f'bnb/{case}/{dt}/seg{i}', got, want, 2e-4)
+
+
+def _nhwc_desc(t, c0=0, c=None):
+    """myolo_tensor of channels [c0, c0+c) of a dense NHWC tensor"""
+    from multiyolov5_amd import _lib as L
+    n, h, w, ctot = t.shape
+    c = ctot - c0 if c is None else c
+    return L.Tensor(t.data_ptr() + c0 * t.element_size(), n, h, w, c, h * w * ctot, w * ctot, ctot, L.DT[t.dtype], 0)
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.float32], ids=['f16', 'f32'])
+@pytest.mark.parametrize('shape', [(2, 64, 128, 32), (3, 21, 37, 16), (1, 6, 6, 8), (2, 33, 16, 24)], ids=lambda s: 'x'.join(map(str, s)))
+def test_pyramid_grouped_kernels_match_the_single_op_entry_points(shape, dt):
+    """myolo_pyramid_upsample_fwd / _bwd and myolo_adaptive_avgpool_bwd_multi (PyramidPooling's four branches in one launch each,
+    common.py:521-537) against four calls of myolo_bilinear_fwd / myolo_bilinear_bwd / myolo_adaptive_avgpool_bwd on the same buffers"""
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    n, H, W, cb = shape
+    ks = (1, 2, 3, 6)
+    g = torch.Generator().manual_seed(H * W)
+    st = L.stream_ptr()
+    # forward
+    xs = [(torch.randn(n, k, k, cb, generator=g)).to(DEV, dt) for k in ks]
+    out_a = torch.zeros(n, H, W, 4 * cb + 8, dtype=dt, device=DEV)          # slices of a wider buffer
+    out_b = torch.zeros_like(out_a)
+    xd = (L.Tensor * 4)(*[_nhwc_desc(x) for x in xs])
+    L.check(lib.myolo_pyramid_upsample_fwd(xd, 4, C.byref(_nhwc_desc(out_a, 8, 4 * cb)), st), 'pyr fwd')
+    for t in range(4):
+        L.check(lib.myolo_bilinear_fwd(C.byref(_nhwc_desc(xs[t])), C.byref(_nhwc_desc(out_b, 8 + t * cb, cb)), st), 'bil fwd')
+    assert torch.equal(out_a, out_b)
+    # backward of the upsamples
+    gout = torch.zeros(n, H, W, 4 * cb + 8, dtype=dt, device=DEV)
+    gout[..., 8:] = (torch.randn(n, H, W, 4 * cb, generator=g) * 0.1).to(DEV, dt)
+    ga = [torch.full((n, k, k, cb), 0.25, dtype=dt, device=DEV) for k in ks]
+    gb = [x.clone() for x in ga]
+    acc = (C.c_int32 * 4)(0, 1, 0, 1)
+    scratch = torch.zeros(sum(x.numel() for x in ga), dtype=torch.float32, device=DEV)
+    gad = (L.Tensor * 4)(*[_nhwc_desc(x) for x in ga])
+    rc = lib.myolo_pyramid_upsample_bwd(C.byref(_nhwc_desc(gout, 8, 4 * cb)), gad, 4, acc, L.ptr(scratch), st)
+    if 4 * cb // (8 if dt == torch.float16 else 4) > 16:            # more than 16 channel groups: rejected, the engine keeps four launches
+        assert rc == L.EINVAL
+    else:
+        L.check(rc, 'pyr bwd')
+        for t in range(4):
+            L.check(lib.myolo_bilinear_bwd(C.byref(_nhwc_desc(gout, 8 + t * cb, cb)), C.byref(_nhwc_desc(gb[t])), acc[t], None, st), 'bil bwd')
+        tol = 2e-3 if dt == torch.float16 else 2e-5
+        for a, b in zip(ga, gb):
+            assert float((a.float() - b.float()).abs().max()) <= tol * (float(b.float().abs().max()) + 1e-6)
+    # backward of the pools
+    pg = [(torch.randn(n, k, k, cb, generator=g)).to(DEV, dt) for k in ks]
+    for accum in (0, 1):
+        gx_a = torch.full((n, H, W, cb), 0.5, dtype=dt, device=DEV)
+        gx_b = gx_a.clone()
+        pgd = (L.Tensor * 4)(*[_nhwc_desc(x) for x in pg])
+        L.check(lib.myolo_adaptive_avgpool_bwd_multi(pgd, 4, C.byref(_nhwc_desc(gx_a)), accum, st), 'aap multi')
+        for t in range(4):
+            L.check(lib.myolo_adaptive_avgpool_bwd(C.byref(_nhwc_desc(pg[t])), C.byref(_nhwc_desc(gx_b)), 1 if (t or accum) else 0, st), 'aap')
+        assert float((gx_a.float() - gx_b.float()).abs().max()) <= (4e-3 if dt == torch.float16 else 1e-5) * float(gx_b.float().abs().max())
+
+
+def test_weight_pack_tiled_mode_equals_element_mode():
+    """myolo_pack_weights_mt: the LDS-tiled mode (chunk_elems = 0) writes exactly what the element-per-thread mode writes into the
+    valid region, for forward / transposed operands, 1x1 / 3x3 / 5x5 taps, ragged channel counts and a stacked second source"""
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    g = torch.Generator().manual_seed(0)
+    jobs = []
+    keep = []
+    for (co, ci, k, co2) in [(64, 64, 1, 0), (48, 24, 3, 0), (33, 17, 3, 0), (16, 8, 5, 0), (32, 40, 1, 24), (19, 128, 1, 0), (64, 12, 3, 32)]:
+        w = torch.randn(co, ci, k, k, generator=g).to(DEV)
+        w2 = torch.randn(co2, ci, k, k, generator=g).to(DEV) if co2 else None
+        for tr in (0, 1):
+            rows, cols = (((co + co2 + 31) // 32) * 32, ((ci + 31) // 32) * 32) if not tr else (((ci + 31) // 32) * 32, ((co + co2 + 31) // 32) * 32)
+            for mode in (0, 1):
+                dst = torch.zeros(rows, k * k, cols, dtype=torch.float16, device=DEV)
+                jobs.append((mode, w, w2, dst, co, ci, k * k, rows, cols, tr))
+            keep += [w, w2]
+    for mode in (0, 1):
+        rows_, chunks = [], []
+        sel = [j for j in jobs if j[0] == mode]
+        for ji, (_, w, w2, dst, co, ci, nt, rp, cp, tr) in enumerate(sel):
+            rows_.append((w.data_ptr(), dst.data_ptr(), co, ci, nt, rp, cp, tr, L.F32, L.F16, w2.data_ptr() if w2 is not None else 0,
+                          w2.shape[0] if w2 is not None else 0))
+            if mode == 0:
+                chunks += [(ji, s0) for s0 in range(0, rp * nt * cp, 8192)]
+            else:
+                ca = co + (w2.shape[0] if w2 is not None else 0)
+                tco, tci = (64, 64) if nt == 1 else ((32, 16) if tr else (16, 32))
+                chunks += [(ji, t) for t in range(((ca + tco - 1) // tco) * ((ci + tci - 1) // tci))]
+        tab = torch.tensor(rows_, dtype=torch.int64).to(DEV)
+        ch = torch.tensor(chunks, dtype=torch.int32).to(DEV)
+        L.check(lib.myolo_pack_weights_mt(L.ptr(tab), L.ptr(ch), len(chunks), 8192 if mode == 0 else 0, L.stream_ptr()), 'pack')
+    torch.cuda.synchronize()
+    a = [j[3] for j in jobs if j[0] == 0]
+    b = [j[3] for j in jobs if j[0] == 1]
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+        assert float(x.abs().max()) > 0
