@@ -847,9 +847,45 @@ __global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_t
 // the same for up to four pooled maps of ONE input (PyramidPooling's bins 1, 2, 3, 6 -- common.py:521-524): the input gradient is
 // read-modified-written once instead of once per bin (4 x 66 MB at 16x64x128x128)
 struct AapMulti { myolo_tensor g[4]; int n; };
+// the bins [floor(b*H/k), ceil((b+1)*H/k)) a row / column belongs to (one or two per pool) are tabulated in LDS once per workgroup:
+// the per-pixel integer divisions of aap_bwd_kernel (four pools x up to nine candidate bins) were 2/3 of this kernel's time
 template <typename T>
 __global__ __launch_bounds__(256) void aap_bwd_multi_kernel(AapMulti m, myolo_tensor gx, int acc) {
   constexpr int SEG = ET<T>::SEG;
+  extern __shared__ unsigned char tabs[];                 // [4][H] row: first bin | count << 4 ; [4][W] column ; then extents
+  unsigned char* rowt = tabs;
+  unsigned char* colt = tabs + 4 * gx.h;
+  unsigned short* exth = reinterpret_cast<unsigned short*>(colt + 4 * gx.w);   // [4][8] bin heights, [4][8] bin widths (k <= 8)
+  unsigned short* extw = exth + 32;
+  for (int i = threadIdx.x; i < 4 * (gx.h + gx.w); i += blockDim.x) {
+    const bool isrow = i < 4 * gx.h;
+    const int j = isrow ? i : i - 4 * gx.h;
+    const int L = isrow ? gx.h : gx.w;
+    const int t = j / L, p = j - t * L;
+    unsigned char v = 0;
+    if (t < m.n) {
+      const int k = isrow ? m.g[t].h : m.g[t].w;
+      const int bc = (int)(((uint32_t)p * (uint32_t)k) / (uint32_t)L);
+      int first = -1, cnt = 0;
+      for (int bb = bc > 0 ? bc - 1 : 0; bb <= bc + 1 && bb < k; ++bb) {
+        const int p0 = (bb * L) / k, p1 = ((bb + 1) * L + k - 1) / k;
+        if (p >= p0 && p < p1) { if (first < 0) first = bb; ++cnt; }
+      }
+      v = (unsigned char)(first | (cnt << 4));
+    }
+    (isrow ? rowt : colt)[j] = v;
+  }
+  for (int i = threadIdx.x; i < 64; i += blockDim.x) {
+    const bool ish = i < 32;
+    const int j = ish ? i : i - 32, t = j >> 3, bb = j & 7;
+    unsigned short v = 1;
+    if (t < m.n) {
+      const int k = ish ? m.g[t].h : m.g[t].w, L = ish ? gx.h : gx.w;
+      if (bb < k) v = (unsigned short)(((bb + 1) * L + k - 1) / k - (bb * L) / k);
+    }
+    (ish ? exth : extw)[j] = v;
+  }
+  __syncthreads();
   const int G = gx.c / SEG;
   const int64_t total = (int64_t)gx.n * gx.h * gx.w * G;
   GRID_STRIDE(v, total) {
@@ -862,21 +898,16 @@ __global__ __launch_bounds__(256) void aap_bwd_multi_kernel(AapMulti m, myolo_te
     for (int t = 0; t < 4; ++t) {
       if (t >= m.n) break;
       const myolo_tensor& gout = m.g[t];
-      const int kb = gout.h, kw = gout.w;
-      const int byc = (int)(((uint32_t)y * (uint32_t)kb) / (uint32_t)gx.h), bxc = (int)(((uint32_t)xx * (uint32_t)kw) / (uint32_t)gx.w);
-      for (int by = byc > 0 ? byc - 1 : 0; by <= byc + 1 && by < kb; ++by) {
-        const int y0 = (by * gx.h) / kb, y1 = ((by + 1) * gx.h + kb - 1) / kb;
-        if (y < y0 || y >= y1) continue;
-        for (int bx = bxc > 0 ? bxc - 1 : 0; bx <= bxc + 1 && bx < kw; ++bx) {
-          const int x0 = (bx * gx.w) / kw, x1 = ((bx + 1) * gx.w + kw - 1) / kw;
-          if (xx < x0 || xx >= x1) continue;
+      const int rv = rowt[t * gx.h + y], cv = colt[t * gx.w + xx];
+      const int by0 = rv & 15, nby = rv >> 4, bx0 = cv & 15, nbx = cv >> 4;
+      for (int by = by0; by < by0 + nby; ++by)
+        for (int bx = bx0; bx < bx0 + nbx; ++bx) {
           float f[SEG];
           Vec<T>::unpack(ldg16(vptr<T>(gout, n, by, bx) + cg * SEG), f);
-          const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+          const float inv = 1.f / (float)((int)exth[t * 8 + by] * (int)extw[t * 8 + bx]);
 #pragma unroll
           for (int i = 0; i < SEG; ++i) a[i] += f[i] * inv;
         }
-      }
     }
     T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
     if (acc) {
@@ -1207,7 +1238,11 @@ extern "C" int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int c
     if (!vec_ok(&gouts[i]) || !same_nc(gx, &gouts[i])) return MYOLO_EINVAL;
     m.g[i] = gouts[i];
   }
-  DISPATCH(gx->dtype, aap_bwd_multi_kernel, grid_for(nvec(gx), 256), 256, 0, (hipStream_t)stream, m, *gx, accumulate);
+  for (int i = 0; i < count; ++i)
+    if (gouts[i].h > 8 || gouts[i].w > 8 || gouts[i].h > gx->h || gouts[i].w > gx->w) return MYOLO_EINVAL;   // bin tables: k <= 8
+  if (gx->h > 2040 || gx->w > 2040) return MYOLO_EINVAL;
+  const size_t smem = (size_t)4 * (gx->h + gx->w) + 128;
+  DISPATCH(gx->dtype, aap_bwd_multi_kernel, grid_for(nvec(gx), 256 * 4, 2048), 256, smem, (hipStream_t)stream, m, *gx, accumulate);
   return 0;
 }
 static int gate_fwd_impl(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, float one, void* stream) {
