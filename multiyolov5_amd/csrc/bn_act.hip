@@ -295,7 +295,7 @@ extern "C" int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats,
   if (G > 256) return MYOLO_EINVAL;
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int grid = grid_for(M, PPB * 2, 1024);           // two pixels per thread and pass; <= 4 workgroups per CU: each one's
+  const int grid = grid_for(M, PPB * 2, y->c >= 512 ? 256 : 1024);   // two pixels per thread and pass; <= 4 workgroups per CU (1 for wide layers): each one's
                                                          // prologue sums the MYOLO_STAT_COPIES partial statistics of every channel
   const size_t smem = (size_t)2 * y->c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
@@ -366,7 +366,7 @@ extern "C" int myolo_bn_act_bwd_apply_split(const myolo_tensor* gout, const myol
   if (G > 256) return MYOLO_EINVAL;
   const int PPB = 256 / G;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int grid = grid_for(M, PPB * 2, 1024);
+  const int grid = grid_for(M, PPB * 2, y->c >= 512 ? 256 : 1024);
   const size_t smem = (size_t)4 * y->c * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
