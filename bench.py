@@ -220,7 +220,7 @@ def conv_kernel_timing(trainer, nsteps=3):
         E.Call.__call__ = orig
         E.GRAPH_TRAIN = graph_mode
     tot_t = sum(e0.elapsed_time(e1) for _, e0, e1 in rec) * 1e-3 / nsteps
-    tot_b = sum(E.conv_call_bytes(c) for c, _, _ in rec) / nsteps
+    tot_b = sum(E.conv_call_bytes(c) + E.bnb_call_bytes(c) for c, _, _ in rec) / nsteps     # (+ the BatchNorm-backward reduce passes a dgrad launch carries)
     tot_f = sum(E.conv_call_flops(c) for c, _, _ in rec) / nsteps
     return tot_b, tot_f, tot_t, len(rec) // nsteps
 
@@ -428,7 +428,7 @@ def main():
                 traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/' + os.path.basename(pmc) + ': ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
-                               'kernel': 'myolo_conv launches of one step: conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad)',
+                               'kernel': 'myolo_conv launches of one step: conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below counts that reduce pass\'s gout + y bytes)',
                                'launches_per_step': n,
                                'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
                                'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,

@@ -994,8 +994,8 @@ class Plan:
         """fold `bn_act_bwd_reduce` of a Conv+BatchNorm layer into the dgrad launch that writes the LAST contribution to its output
         gradient (the values are final in that launch's epilogue): possible when that last writer is a convolution's dgrad covering
         the layer's whole channel range, over the same pixels.  MYOLO_BN_STATS_IN_DGRAD=0 keeps the separate reduce launches."""
-        if os.environ.get('MYOLO_BN_STATS_IN_DGRAD', '0') == '0':      # opt-in: measured neutral on the step (10.34 vs 10.41 ms) while it moves
-            return                                                     # ~0.4 ms of reduce work INTO the conv launches (conv roofline 0.145 -> 0.130)
+        if os.environ.get('MYOLO_BN_STATS_IN_DGRAD', '1') == '0':      # default on: 9.40 -> 9.29 ms on the final build of round 2 (it was neutral,
+            return                                                     # 10.34 vs 10.41 ms, before the chain lost ~70 launches); =0 keeps every reduce launch
         max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
         for op in self.ops:
             if not isinstance(op, ConvOp) or op.bn is None or op.det or op.bn2 is not None:
@@ -1358,6 +1358,17 @@ def conv_call_bytes(call):
     return (xin + yout + w) * es
 
 
+def bnb_call_bytes(call):
+    """algorithmic bytes of the BatchNorm-backward reduce passes a conv launch carries in its epilogue (myolo_conv_desc.bnb): the
+    unfused pass reads the output gradient and the raw conv output of every segment once"""
+    descs = _s2_descs(call)[:1] if call.name == 'myolo_conv_dgrad_s2' else [_conv_desc_of(call)]
+    tot = 0
+    for d in descs:
+        for i in range(d.nbnb if d.bnb else 0):
+            tot += _tensor_bytes(d.bnb[i].y) * 2
+    return tot
+
+
 def conv_call_flops(call):
     if call.name == 'myolo_conv_dgrad_s2':
         return sum(2.0 * d.y.n * d.y.h * d.y.w * d.y.c * d.ntaps * d.x.c for d in _s2_descs(call))
@@ -1403,4 +1414,6 @@ def plan_algorithmic_bytes(plan):
             b = call_algorithmic_bytes(c)
             if b is not None:
                 out[fam[c.name]] += b
+            if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2'):
+                out['batchnorm'] += bnb_call_bytes(c)          # (reduce passes folded into dgrad epilogues keep their unfused byte count)
     return out
