@@ -361,10 +361,11 @@ int myolo_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf,
  * counts int32[batch], cand float[batch][cap][6], cand_idx int32[batch][cap], sorted float[batch][max_nms][6];
  * cap >= A (A*nc when multi_label).  Results: out float[batch][max_det][6] = (x1,y1,x2,y2,conf,cls) in descending conf,
  * nkeep int32[batch].  class_mask: the `classes=` filter (general.py:476-477) as a bit set, bit j = keep class j; 0 = keep all
- * (nc <= 64 when non-zero). */
+ * (nc <= 64 when non-zero).  sort_ws (optional, device int32 [batch][3*65536 + cap]): the descending-score order is produced by a
+ * counting sort instead of the O(n^2) rank kernel -- for test.py's conf 0.001 / multi_label lists (1e5 candidates per image). */
 int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres, int multi_label,
               int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts, float* cand,
-              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, void* stream);
+              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, int32_t* sort_ws, void* stream);
 
 /* test.py:230-262 (true-positive matrix of one image, the input of ap_per_class): pred [n][6] = (x1,y1,x2,y2,conf,cls) in NMS order and
  * labels [m][5] = (cls,x1,y1,x2,y2), native image space, device float32; iouv device float[niou] (test.py:98 linspace(0.5,0.95,10));

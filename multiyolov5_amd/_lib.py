@@ -157,7 +157,7 @@ _PROTOS = {
                                           C.c_int, P, P]),
     'myolo_seg_blend': (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P, P, P]),
     'myolo_nms': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
-                            C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint64, P]),
+                            C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint64, P, P]),
 }
 
 

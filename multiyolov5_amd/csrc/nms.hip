@@ -22,38 +22,53 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
                                                          int cap, int* counts, float* cand, int* cand_idx, uint64_t class_mask) {
   const int b = blockIdx.y;
   const int nc = no - 5;
-  for (int a = blockIdx.x * blockDim.x + threadIdx.x; a < A; a += gridDim.x * blockDim.x) {
-    const int64_t row = ((int64_t)b * A + a) * no;
+  // fp16 predictions (detect.py --half): the reference's `x[:, 5:] *= x[:, 4:5]`, `xywh2xyxy` and threshold compares run in the input
+  // dtype (general.py:446-473) before torch.cat with `j.float()` promotes the rows to fp32 -- every such result is rounded to fp16
+  const bool hf = dt == MYOLO_F16;
+  auto rh = [hf](float v) { return hf ? (float)(half_t)v : v; };
+  conf = rh(conf);
+  const int lane = threadIdx.x & 63;
+  // one atomic per WAVE and append (not per candidate: same-address atomics retire at ~110 ns each -- 30 k candidates of a
+  // multi-label test.py call were 3 ms of nothing else): ballot, the first active lane reserves popcount slots, lanes take their rank
+  auto append = [&](bool pass, float x1, float y1, float x2, float y2, float sc, int cls, int idx) {
+    const unsigned long long m = __ballot(pass);
+    if (!m) return;
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counts + b, __popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    if (pass) {
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < cap) {
+        float* c = cand + ((int64_t)b * cap + slot) * 6;
+        c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = sc; c[5] = (float)cls;
+        cand_idx[(int64_t)b * cap + slot] = idx;
+      }
+    }
+  };
+  const int stride = gridDim.x * blockDim.x;
+  const int first = blockIdx.x * blockDim.x + threadIdx.x;
+  for (int a0 = first - lane; a0 < A; a0 += stride) {              // (whole waves iterate together: the ballots need every lane)
+    const int a = a0 + lane;
+    const bool in = a < A;
+    const int64_t row = ((int64_t)b * A + (in ? a : 0)) * no;
     const float obj = ldp(pred, row + 4, dt);
-    if (!(obj > conf)) continue;
+    const bool live = in && obj > conf;
+    if (!__ballot(live)) continue;
     const float x = ldp(pred, row, dt), y = ldp(pred, row + 1, dt), w = ldp(pred, row + 2, dt), h = ldp(pred, row + 3, dt);
-    const float x1 = x - w / 2, y1 = y - h / 2, x2 = x + w / 2, y2 = y + h / 2;
+    const float hw = rh(w / 2), hh = rh(h / 2);
+    const float x1 = rh(x - hw), y1 = rh(y - hh), x2 = rh(x + hw), y2 = rh(y + hh);
     if (multi && nc > 1) {
       for (int j = 0; j < nc; ++j) {
-        const float s = ldp(pred, row + 5 + j, dt) * obj;
-        if (s > conf && (!class_mask || ((class_mask >> j) & 1ull))) {
-          const int slot = atomicAdd(counts + b, 1);
-          if (slot < cap) {
-            float* c = cand + ((int64_t)b * cap + slot) * 6;
-            c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = s; c[5] = (float)j;
-            cand_idx[(int64_t)b * cap + slot] = a * nc + j;
-          }
-        }
+        const float s = rh(ldp(pred, row + 5 + j, dt) * obj);
+        append(live && s > conf && (!class_mask || ((class_mask >> j) & 1ull)), x1, y1, x2, y2, s, j, a * nc + j);
       }
     } else {
       float best = -INFINITY; int bj = 0;
       for (int j = 0; j < nc; ++j) {
-        const float s = ldp(pred, row + 5 + j, dt) * obj;
+        const float s = rh(ldp(pred, row + 5 + j, dt) * obj);
         if (s > best) { best = s; bj = j; }                        // first maximum (torch.max)
       }
-      if (best > conf && (!class_mask || ((class_mask >> bj) & 1ull))) {
-        const int slot = atomicAdd(counts + b, 1);
-        if (slot < cap) {
-          float* c = cand + ((int64_t)b * cap + slot) * 6;
-          c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = best; c[5] = (float)bj;
-          cand_idx[(int64_t)b * cap + slot] = a;
-        }
-      }
+      append(live && best > conf && (!class_mask || ((class_mask >> bj) & 1ull)), x1, y1, x2, y2, best, bj, a);
     }
   }
 }
@@ -89,6 +104,93 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, const 
     float* d = sorted + ((int64_t)b * max_nms + rank) * 6;
 #pragma unroll
     for (int q = 0; q < 6; ++q) d[q] = cb[(int64_t)i * 6 + q];
+  }
+}
+
+// ---- descending-score order for LONG candidate lists (test.py: conf 0.001, multi_label -> up to A*nc = 322 560 candidates per image,
+// 200 k typical): the rank-by-counting kernel above is O(n^2) (12 ms per image, 41 ms for a batch of 8).  Counting sort on the top
+// 18 bits of the (positive) fp32 score, then an exact rank inside the bucket:
+//   hist   : count per bucket (65 536 buckets per image: 9 mantissa bits per octave)
+//   starts : descending exclusive scan -> first sorted slot of every bucket (one workgroup per image)
+//   group  : every candidate takes a slot of its bucket in `order` (bucket-grouped candidate ids)
+//   place  : exact rank = bucket start + #{members with a higher score, or the same score and a lower original row};
+//            candidates ranked < max_nms are scattered into `sorted` (general.py:487-488)
+constexpr int NB = 65536;
+__device__ __forceinline__ int score_bucket(float s) { return (int)(__float_as_uint(s) >> 14); }     // 0 < s <= 1.0 -> < 0xFE01
+
+__global__ __launch_bounds__(256) void nms_hist_kernel(const int* counts, const float* cand, int cap, int* hist) {
+  const int b = blockIdx.y;
+  int n = counts[b];
+  if (n > cap) n = cap;
+  const float* cb = cand + (int64_t)b * cap * 6;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int k = score_bucket(cb[(int64_t)i * 6 + 4]);
+    atomicAdd(hist + (int64_t)b * NB + (k < NB ? k : NB - 1), 1);
+  }
+}
+
+__global__ __launch_bounds__(1024) void nms_starts_kernel(const int* hist, int* start) {
+  __shared__ int part[1024];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int* h = hist + (int64_t)b * NB;
+  // thread t owns buckets [hi - 63, hi], hi = NB - 1 - 64 t: the HIGHEST scores first
+  const int hi = NB - 1 - 64 * t;
+  int sum = 0;
+  for (int q = 0; q < 64; ++q) sum += h[hi - q];
+  part[t] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                    // inclusive scan over the threads (Hillis-Steele)
+    const int v = t >= o ? part[t - o] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = part[t] - sum;                                // candidates in all higher buckets
+  int* st = start + (int64_t)b * NB;
+  for (int q = 0; q < 64; ++q) { st[hi - q] = run; run += h[hi - q]; }
+}
+
+__global__ __launch_bounds__(256) void nms_group_kernel(const int* counts, const float* cand, int cap, const int* start, int* fill,
+                                                        int* order) {
+  const int b = blockIdx.y;
+  int n = counts[b];
+  if (n > cap) n = cap;
+  const float* cb = cand + (int64_t)b * cap * 6;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    int k = score_bucket(cb[(int64_t)i * 6 + 4]);
+    k = k < NB ? k : NB - 1;
+    const int pos = start[(int64_t)b * NB + k] + atomicAdd(fill + (int64_t)b * NB + k, 1);
+    order[(int64_t)b * cap + pos] = i;
+  }
+}
+
+__global__ __launch_bounds__(256) void nms_place_kernel(const int* counts, const float* cand, const int* cand_idx, int cap,
+                                                        const int* start, const int* hist, const int* order, int max_nms,
+                                                        float* sorted) {
+  const int b = blockIdx.y;
+  int n = counts[b];
+  if (n > cap) n = cap;
+  const float* cb = cand + (int64_t)b * cap * 6;
+  const int* ib = cand_idx + (int64_t)b * cap;
+  const int* ob = order + (int64_t)b * cap;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const float s = cb[(int64_t)i * 6 + 4];
+    const int id = ib[i];
+    int k = score_bucket(s);
+    k = k < NB ? k : NB - 1;
+    const int s0 = start[(int64_t)b * NB + k], m = hist[(int64_t)b * NB + k];
+    if (s0 >= max_nms) continue;                          // the whole bucket lies beyond the truncation
+    int rank = s0;
+    for (int q = 0; q < m; ++q) {
+      const int j = ob[s0 + q];
+      const float sj = cb[(int64_t)j * 6 + 4];
+      rank += (sj > s || (sj == s && ib[j] < id)) ? 1 : 0;
+    }
+    if (rank < max_nms) {
+      float* d = sorted + ((int64_t)b * max_nms + rank) * 6;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) d[q] = cb[(int64_t)i * 6 + q];
+    }
   }
 }
 
@@ -202,7 +304,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
 extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres,
                          int multi_label, int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts,
                          float* cand, int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask,
-                         void* stream) {
+                         int32_t* sort_ws, void* stream) {
   if (class_mask && no - 5 > 64) return MYOLO_EINVAL;
   if (!pred || (dtype != MYOLO_F16 && dtype != MYOLO_F32) || batch < 1 || A < 1 || no < 6 || cap < 1 || max_det < 1 ||
       max_nms < 1 || max_nms > MAXW * 64 || !counts || !cand || !cand_idx || !sorted || !out || !nkeep)
@@ -212,7 +314,21 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), 0, st, pred, dtype, A, no, conf_thres,
                      multi_label, cap, counts, cand, cand_idx, class_mask);
-  hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted);
+  if (sort_ws) {             // long lists: counting sort; sort_ws = int32 [batch][3*65536 + cap]
+    int* hist = sort_ws;
+    int* fill = hist + (int64_t)batch * NB;
+    int* start = fill + (int64_t)batch * NB;
+    int* order = start + (int64_t)batch * NB;
+    e = hipMemsetAsync(hist, 0, (size_t)2 * batch * NB * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    const int gx = grid_for(cap, 256, 1024);
+    hipLaunchKernelGGL(nms_hist_kernel, dim3(gx, batch), dim3(256), 0, st, counts, cand, cap, hist);
+    hipLaunchKernelGGL(nms_starts_kernel, dim3(batch), dim3(1024), 0, st, hist, start);
+    hipLaunchKernelGGL(nms_group_kernel, dim3(gx, batch), dim3(256), 0, st, counts, cand, cap, start, fill, order);
+    hipLaunchKernelGGL(nms_place_kernel, dim3(gx, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, start, hist, order, max_nms, sorted);
+  } else {
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted);
+  }
   const int scan_smem = MAXW * 8 + 64 * 8 + 64 * 16 + LDS_BOXES * 16;
   static bool attr_set = false;
   if (!attr_set) {

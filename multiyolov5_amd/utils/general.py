@@ -50,7 +50,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
                         labels=()):
     """general.py:421-509: list (one per image) of [n,6] tensors (x1, y1, x2, y2, conf, cls), descending conf, n <= 300.
     One batched launch sequence for all images; the only host synchronisation is reading the per-image keep counts.
-    fp16 predictions are scored and intersected in fp32 (the reference multiplies cls*obj in the input dtype)."""
+    fp16 predictions: as in the reference, cls*obj, xywh->xyxy and the threshold compares are rounded to fp16, the rows come
+    back as float32 (torch.cat with `j.float()` promotes them, general.py:470-473) and the IoU test runs in fp32."""
     if labels is not None and len(labels):
         raise NotImplementedError('labels= (auto-labelling priors, general.py:448-456) is not on the gfx950 hot path')
     class_mask = 0
@@ -61,7 +62,7 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         for c in cl:
             class_mask |= 1 << c
         if not cl:                                                # an empty filter keeps nothing
-            return [torch.zeros((0, 6), device=prediction.device, dtype=prediction.dtype) for _ in range(prediction.shape[0])]
+            return [torch.zeros((0, 6), device=prediction.device, dtype=torch.float32) for _ in range(prediction.shape[0])]
     _L.require_gpu(prediction)
     if prediction.dim() != 3 or prediction.dtype not in (torch.float16, torch.float32):
         raise _L.MyoloError('prediction must be a [B,A,5+nc] fp16/fp32 tensor')
@@ -78,12 +79,15 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     srt = torch.empty(B * max_nms * 6, dtype=torch.float32, device=dev)
     out = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
     nkeep = torch.empty(B, dtype=torch.int32, device=dev)
+    # long candidate lists (test.py: conf 0.001 + multi_label, 1e5 per image): counting sort instead of the O(n^2) rank kernel
+    ws = torch.empty(B * (3 * 65536 + cap), dtype=torch.int32, device=dev) if (multi or conf_thres < 0.05) else None
     _L.check(_L.lib().myolo_nms(_L.ptr(pred), _L.DT[pred.dtype], B, A, no, _C.c_float(conf_thres), _C.c_float(iou_thres),
                                 int(multi), int(bool(agnostic)), _C.c_float(max_wh), max_nms, max_det, cap, _L.ptr(counts),
-                                _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), class_mask, _L.stream_ptr()),
+                                _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), class_mask,
+                                _L.ptr(ws) if ws is not None else None, _L.stream_ptr()),
              'myolo_nms')
     n = nkeep.tolist()                                            # the one sync (the reference syncs per image, 446-495)
-    return [out[i, :n[i]].to(prediction.dtype) for i in range(B)]
+    return [out[i, :n[i]] for i in range(B)]
 
 
 def seg_argmax(seg, h0=None, w0=None, out_dtype=torch.int64):

@@ -243,6 +243,12 @@ def nms_case(ref):
         res = ref.general.non_max_suppression(pred.clone(), **kw)
         for i, r in enumerate(res):
             out[f'{name}_{i}'] = r.numpy()
+    # fp16 predictions (detect.py --half, BASELINE config 5): the reference's own arithmetic in the input dtype, on the CPU
+    for name, kw in (('single_f16', dict(conf_thres=0.25, iou_thres=0.45)), ('multi_f16', dict(conf_thres=0.001, iou_thres=0.6, multi_label=True))):
+        res = ref.general.non_max_suppression(pred.clone().half(), **kw)
+        for i, r in enumerate(res):
+            assert r.dtype == torch.float32
+            out[f'{name}_{i}'] = r.numpy()
     np.savez_compressed(os.path.join(GOLD, 'nms.npz'), **out)
     print('wrote nms', {k: v.shape for k, v in out.items()})
 
