@@ -80,6 +80,11 @@ class _OutSpec:
         return [_OutSpec.rebuild(s, vals) for s in v]
 
 
+def _os_env_flag(name, default):
+    import os
+    return os.environ.get(name, '1' if default else '0') != '0'
+
+
 class LazySegLogits(torch.Tensor):
     """The training-mode segmentation output `pred[1]` (models/yolo.py:163: the x8 bilinear upsample of the class logits).  The fused
     loss reads the LOW-resolution logits (utils/loss._SegCE) and never needs these 38 bytes per pixel; everything else --
@@ -188,13 +193,46 @@ class PlanFn(torch.autograd.Function):
             sc[1]['low'] = False
         holder.pending_bwd = False
         in_grads = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]
+        if _accumulate_in_place(holder, plan):
+            # gradient accumulation (train.py:364-401 runs a detection and a segmentation backward per iteration and steps the optimizer
+            # every `accumulate` iterations): every `p.grad` is still the view this function handed out of ONE flat buffer, so the
+            # ~230 per-parameter `grad += new` kernels autograd would launch are one add over the flat buffer
+            holder._accum_buf.add_(plan.flat_grad)
+            return (None, *in_grads, *([None] * len(plan.params)))
         flat = plan.flat_grad.clone()
         pg, off = [], 0
         for p in plan.params:
             n = p.numel()
             pg.append(flat[off:off + n].view(p.shape) if p.requires_grad else None)
             off += n
+        holder._accum_buf = flat
         return (None, *in_grads, *pg)
+
+
+FLAT_ACCUMULATE = _os_env_flag('MYOLO_FLAT_ACCUMULATE', True)
+
+
+def _accumulate_in_place(holder, plan):
+    """True when autograd would add this backward's parameter gradients, one kernel per parameter, into `.grad` tensors that are all
+    views of the flat buffer of this holder's previous backward -- and nothing hangs on the per-parameter accumulation: no tensor
+    hooks on the parameters, no stock DistributedDataParallel (its reducer hooks the gradient accumulators; with torch.distributed
+    initialised the shortcut is only taken under this package's own GradReducer)."""
+    buf = holder.__dict__.get('_accum_buf')
+    if buf is None or not FLAT_ACCUMULATE:
+        return False
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and holder.module.__dict__.get('_grad_reducer') is None:
+        return False
+    base, off = buf.data_ptr(), 0
+    for p in plan.params:
+        n = p.numel()
+        if p.requires_grad:
+            g = p.grad
+            if g is None or g.data_ptr() != base + off * 4 or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != p.shape:
+                return False
+            if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
+                return False
+        off += n
+    return True
 
 
 # eval-mode forwards (detect.py path) replay the launch list as ONE hipGraph (torch.cuda.graph == hipGraph on ROCm): the

@@ -176,3 +176,57 @@ def test_stock_sgd_step_equals_fused_sgd_step():
     for k in res[0]:
         check(f'dropin/sgd/{k}', res[1][k], res[0][k], 6e-3, collect=bad)      # two fp32 runs: measured <= 2.2e-3 (atomics reorder the sums)
     assert not bad, '\n'.join(bad[:10])
+
+
+def test_gradient_accumulation_over_two_backward_passes_equals_the_sum(monkeypatch):
+    """train.py:364-401: a detection backward and a segmentation backward accumulate into `.grad` before one optimizer step.  The
+    second backward adds its flat gradient buffer into the first one's in ONE kernel (runtime._accumulate_in_place) -- same values
+    as autograd's per-parameter accumulation, and any `.grad` the caller replaced switches back to that path"""
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
+    from oracle import loss_ref, synth
+    from tests.util import CFG, TAGS, synth_sd
+    torch.manual_seed(0)
+    m = Model(os.path.join(CFG, TAGS['s_psp']))
+    m.load_state_dict(synth_sd('s_psp'), strict=True)
+    m = m.to(DEV).train()
+    m.hyp, m.gr, m.nc = loss_ref.scaled_hyp(imgsz=128, nc=10, nl=3), 1.0, 10
+    x = synth.synth_images(2, 64, 128, seed=1).to(DEV)
+    targets = synth.synth_det_targets(2, 8, 10, seed=1).to(DEV)
+    mask = synth.synth_seg_targets(2, 64, 128, 19, seed=1).to(DEV)
+    cl, sl = ComputeLoss(m), SegmentationLosses()
+
+    def two_passes():
+        for p in m.parameters():
+            p.grad = None
+        det, seg = m(x)
+        cl(det, targets)[0].backward()
+        det, seg = m(x)
+        (sl(seg, mask) * 2).backward()
+        return [p.grad.clone() for p in m.parameters()]
+    calls = []
+    orig = R._accumulate_in_place
+    monkeypatch.setattr(R, '_accumulate_in_place', lambda h, p: calls.append(orig(h, p)) or calls[-1])
+    fast = two_passes()
+    assert calls == [False, True]                         # the second backward took the flat add
+    monkeypatch.setattr(R, 'FLAT_ACCUMULATE', False)
+    calls.clear()
+    slow = two_passes()
+    assert calls == [False, False]
+    for a, b in zip(fast, slow):
+        assert float((a - b).abs().max()) <= 1e-5 * (float(b.abs().max()) + 1e-12)
+    # a replaced .grad (not a view of the flat buffer) falls back to autograd's accumulation
+    monkeypatch.setattr(R, 'FLAT_ACCUMULATE', True)
+    for p in m.parameters():
+        p.grad = None
+    det, seg = m(x)
+    cl(det, targets)[0].backward()
+    first = next(m.parameters())
+    first.grad = first.grad.clone()
+    calls.clear()
+    det, seg = m(x)
+    (sl(seg, mask) * 2).backward()
+    assert calls == [False]
+    for a, p in zip(slow, m.parameters()):
+        assert float((a - p.grad).abs().max()) <= 1e-5 * (float(a.abs().max()) + 1e-12)
