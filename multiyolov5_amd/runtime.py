@@ -199,7 +199,14 @@ class PlanFn(torch.autograd.Function):
             # ~230 per-parameter `grad += new` kernels autograd would launch are one add over the flat buffer
             holder._accum_buf.add_(plan.flat_grad)
             return (None, *in_grads, *([None] * len(plan.params)))
-        flat = plan.flat_grad.clone()
+        # the buffer handed out as `.grad` views is REUSED once nothing references the previous hand-out any more (zero_grad() dropped
+        # the views): the gradients then keep their addresses from step to step, so pointer tables built over them (FusedSGD, ModelEMA:
+        # a rebuild is a blocking host-to-device copy, i.e. a device sync + ~2 ms of host work per step) stay valid
+        flat = holder.__dict__.get('_accum_buf')
+        if flat is not None and torch._C._storage_Use_Count(flat.untyped_storage()._cdata) <= 2:
+            flat.copy_(plan.flat_grad)
+        else:
+            flat = plan.flat_grad.clone()
         pg, off = [], 0
         for p in plan.params:
             n = p.numel()
