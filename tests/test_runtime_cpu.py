@@ -1,0 +1,100 @@
+"""CPU: host logic added in round 2 that needs no GPU -- the launch-list structure of a training plan (merged entry convs, grouped
+PyramidPooling passes, the fused-loss switch), the lazily materialised training logits and the flat gradient accumulation rule."""
+import os
+from collections import Counter
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from tests.util import CFG, TAGS
+
+
+def _plan(tag='s_psp', training=True, dt=torch.float16):
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    m = Model(os.path.join(CFG, TAGS[tag]))
+    m.train(training)
+    return R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), dt, training).plan
+
+
+def test_training_plan_launch_list_structure():
+    from multiyolov5_amd import engine as E
+    plan = _plan()
+    fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
+    bwd = Counter(c.name for op in plan.ops for c in op.bwd_calls)
+    # 8 C3 blocks + RFB2: two same-input 1x1 Conv+BN+SiLU as one convolution with split BatchNorm parameters (common.py:137,500-501)
+    assert fwd['myolo_bn_act_fwd_split'] == 9 and bwd['myolo_bn_act_bwd_apply_split'] == 9 and bwd['myolo_bn_act_bwd_reduce_split'] == 9
+    merged = [op for op in plan.ops if isinstance(op, E.ConvOp) and op.weight2 is not None]
+    assert len(merged) == 9 and all(op.cout == op.weight.shape[0] + op.weight2.shape[0] for op in merged)
+    # PyramidPooling: four pools / four upsamples, one backward pass each, one forward launch for the upsamples (common.py:521-537)
+    assert fwd['myolo_pyramid_upsample_fwd'] == 1 and bwd['myolo_pyramid_upsample_bwd'] == 1 and bwd['myolo_adaptive_avgpool_bwd_multi'] == 1
+    assert fwd['myolo_adaptive_avgpool_fwd'] == 5 and bwd['myolo_adaptive_avgpool_bwd'] == 1          # (FFM's global pool stays alone)
+    # the x8 upsample of the logits is deferred; its backward is chosen per step (full-resolution gradient | low-resolution fused CE)
+    seg = [op for op in plan.ops if isinstance(op, E.SegOutOp)]
+    assert len(seg) == 1 and seg[0].lazy_call is not None and fwd['myolo_seg_upsample_fwd'] == 0
+    sw = [c for c in seg[0].bwd_calls if isinstance(c, E.SwitchCall)]
+    assert len(sw) == 1 and sw[0].a.name == 'myolo_seg_upsample_bwd' and sw[0].b.name == 'myolo_seg_lowgrad_apply'
+    # weight gradients: one launch per weight tensor (two for a merged conv), all on the side stream
+    wg = [c for op in plan.ops for c in op.bwd_calls if c.name == 'myolo_conv_wgrad']
+    assert all(c.side for c in wg) and len(wg) == sum(2 if op.weight2 is not None else 1 for op in plan.ops if isinstance(op, E.ConvOp))
+    # one weight repack per forward, tiled
+    assert plan._pack_call is not None and plan._pack_call.args[3] == 0
+
+
+def test_eval_plan_keeps_the_eager_upsample_and_merges_too():
+    from multiyolov5_amd import engine as E
+    plan = _plan(training=False)
+    fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
+    assert fwd['myolo_seg_upsample_fwd'] == 1 and fwd['myolo_pyramid_upsample_fwd'] == 1
+    assert sum(1 for op in plan.ops if isinstance(op, E.ConvOp) and op.weight2 is not None) == 9
+    assert not any(op.bwd_calls for op in plan.ops)
+
+
+def test_lazy_logits_materialise_on_first_real_use_only():
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd import runtime as R
+    launches = []
+    holder = SimpleNamespace(generation=3)
+    op = SimpleNamespace(lazy_call=lambda st: launches.append(st))
+    base = torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4)
+    t = base.detach().as_subclass(R.LazySegLogits)
+    t._myolo_lazy_state = {'holder': holder, 'op': op, 'generation': 3, 'done': False}
+    orig = L.stream_ptr
+    L.stream_ptr = lambda: 'stream'
+    try:
+        assert tuple(t.shape) == (1, 2, 3, 4) and t.dtype == torch.float32 and t.dim() == 4 and t.stride() == (24, 12, 4, 1)
+        assert t.numel() == 24 and t.is_contiguous() and not t.requires_grad and t.device.type == 'cpu'
+        assert launches == []                                         # metadata only: nothing launched
+        s = t.sum()
+        assert launches == ['stream'] and type(s) is torch.Tensor and float(s) == float(base.sum())
+        (t * 2).float()
+        assert launches == ['stream']                                 # once
+        # a tensor of an older forward refuses to serve values
+        u = base.detach().as_subclass(R.LazySegLogits)
+        u._myolo_lazy_state = {'holder': holder, 'op': op, 'generation': 2, 'done': False}
+        assert tuple(u.shape) == (1, 2, 3, 4)
+        with pytest.raises(L.MyoloError):
+            u + 1
+    finally:
+        L.stream_ptr = orig
+
+
+def test_flat_accumulation_rule():
+    from multiyolov5_amd import runtime as R
+    ps = [torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(4), requires_grad=False)]
+    plan = SimpleNamespace(params=ps)
+    holder = SimpleNamespace(module=SimpleNamespace())
+    assert R._accumulate_in_place(holder, plan) is False              # no earlier hand-out
+    buf = torch.zeros(15)
+    holder._accum_buf = buf
+    assert R._accumulate_in_place(holder, plan) is False              # .grad is None (zero_grad(set_to_none=True)): autograd assigns
+    ps[0].grad, ps[1].grad = buf[0:6].view(2, 3), buf[6:11].view(5)
+    assert R._accumulate_in_place(holder, plan) is True
+    ps[1].grad = torch.zeros(5)                                       # replaced by the caller
+    assert R._accumulate_in_place(holder, plan) is False
+    ps[1].grad = buf[6:11].view(5)
+    h = ps[0].register_hook(lambda g: g)                              # a tensor hook must see its per-parameter gradient
+    assert R._accumulate_in_place(holder, plan) is False
+    h.remove()
+    assert R._accumulate_in_place(holder, plan) is True
