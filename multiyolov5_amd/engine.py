@@ -1199,13 +1199,18 @@ class Plan:
         side_ptr = C.c_void_p(side.cuda_stream) if side is not None else None
         st = L.stream_ptr()
         skip_side = os.environ.get('MYOLO_DBG_SKIP_WGRAD', '0') == '1'       # profiling only: how long is the step WITHOUT the weight gradients?
+        evs = self.__dict__.setdefault('_side_events', [])                   # one event per fork point, created once (78 per step:
+        k = 0                                                                # creating them anew was ~1 ms of host time per step)
         for hi, lo, ready in self._bwd_segments(reducer):
             for i in range(hi - 1, lo - 1, -1):
                 for c in self.ops[i].bwd_calls:
                     if c.side and skip_side:
                         continue
                     if c.side and side is not None:
-                        ev = torch.cuda.Event()
+                        if k == len(evs):
+                            evs.append(torch.cuda.Event())
+                        ev = evs[k]
+                        k += 1
                         ev.record(main)
                         side.wait_event(ev)
                         c(side_ptr)
