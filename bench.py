@@ -32,8 +32,8 @@ MFMA_F16_PEAK_TF = 2500.0      # dense fp16/bf16 MFMA
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--batch', type=int, default=16, help='per-GPU batch (configs[1]: 16)')
     ap.add_argument('--img', type=int, nargs=2, default=(512, 1024), help='H W')
     ap.add_argument('--cfg', default='yolov5s_city_seg.yaml')
@@ -41,6 +41,7 @@ def parse():
     ap.add_argument('--stage', default='train', choices=['train', 'fwdbwd', 'infer'],
                     help="dev only: 'fwdbwd' = model fwd+bwd with fixed output gradients (no loss/optimizer; NOT a valid "
                          "bench line), 'infer' = detect.py path FPS only")
+    ap.add_argument('--infer-size', type=int, nargs=2, default=(1024, 2048), help="--stage infer: frame H W")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -150,6 +151,21 @@ class Trainer:
         self.last = (loss, segloss)
 
 
+def step_checks(tr):
+    """after a timed region: the last step's losses are finite and the loss scaler never skipped an optimizer step (a skipped step
+    halves the scale; the growth interval is 2000 steps, so an untouched scale = no skip).  Raises instead of reporting an invalid rate."""
+    if tr.args.stage != 'train':
+        return None
+    loss, segloss = tr.last
+    vals = [float(loss), float(segloss)]
+    ok = all(v == v and abs(v) != float('inf') for v in vals)
+    scale = tr.scaler.get_scale() if tr.scaler.is_enabled() else None
+    found = float(tr.scaler._found) if (tr.scaler.is_enabled() and tr.scaler._found is not None) else 0.0
+    if not ok or found != 0.0 or (scale is not None and scale < 65536.0):
+        raise RuntimeError(f'invalid bench step: losses {vals}, loss scale {scale}, found_inf {found}')
+    return {'det_loss': vals[0], 'seg_loss_x_batch': vals[1], 'loss_scale': scale, 'optimizer_steps_skipped': 0}
+
+
 def train_py_step(tr):
     """one iteration of the reference's loop body as written (train.py:364-401): detection pass (forward, ComputeLoss, backward)
     on one batch, segmentation pass (forward, CE * batch_size, backward) on a second independent batch, optimizer / EMA every
@@ -225,8 +241,11 @@ def conv_kernel_timing(trainer, nsteps=3):
     return tot_b, tot_f, tot_t, len(rec) // nsteps
 
 
-def infer_fps(args, dev, frames=30, warm=5, H=1024, W=2048):
-    """detect.py path (detect.py:144-193): fused eval forward at 1x3xHxW fp16 (hipGraph replay) + NMS + seg upsample/argmax."""
+def infer_report(args, dev, frames=60, warm=8, H=1024, W=2048, cpu=False):
+    """detect.py path (detect.py:144-193): fused eval forward at 1x3xHxW fp16 (hipGraph replay) + NMS + seg upsample/argmax.
+    Returns the FPS of the whole frame loop (wall clock, the per-frame host sync of NMS included), the per-stage split measured with
+    HIP events on the launch stream, whether the forward really was a graph replay, and the frame's HBM roofline (SURVEY 8(d):
+    200.8 MB of conv input + weight + output bytes per 512x1024 image, fp16, + the NMS input rows + the label map)."""
     from multiyolov5_amd.models.yolo import Model
     from multiyolov5_amd.utils.general import non_max_suppression, seg_argmax
     from multiyolov5_amd import synth
@@ -236,23 +255,62 @@ def infer_fps(args, dev, frames=30, warm=5, H=1024, W=2048):
     img = synth.images(1, H, W, seed=7).to(dev, torch.float16)
     na = 3 * ((H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32))          # 129 024 at 1024x2048, 32 256 at 512x1024
     pred_syn = synth.nms_pred(1, na, 10, seed=3, img_w=W, img_h=H).to(dev, torch.float16)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
 
-    def frame():
+    def frame(timed=False):
         with torch.no_grad():
+            if timed:
+                ev[0].record()
             out = m(img)
+            if timed:
+                ev[1].record()
             # random-init heads give no candidates above conf 0.25: NMS is fed the synthetic prediction
             # tensor of the same shape/dtype so that suppression actually happens
             det = non_max_suppression(pred_syn, 0.25, 0.45)
+            if timed:
+                ev[2].record()
             lab = seg_argmax(out[1], H, W)
+            if timed:
+                ev[3].record()
         return det, lab
     for _ in range(warm):
-        frame()
+        det, _ = frame()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(frames):
         frame()
     torch.cuda.synchronize()
-    return frames / (time.perf_counter() - t0)
+    fps = frames / (time.perf_counter() - t0)
+    st = [0.0, 0.0, 0.0]
+    k = 10
+    for _ in range(k):
+        frame(timed=True)
+        torch.cuda.synchronize()
+        for i in range(3):
+            st[i] += ev[i].elapsed_time(ev[i + 1]) / k
+    holders = [h for h in m.__dict__.get('_plans', {}).values() if not h.plan.training]
+    replayed = bool(holders) and all(h.__dict__.get('_graph') is not None and not h.__dict__.get('_graph_failed') for h in holders)
+    from multiyolov5_amd import engine as E
+    conv_b = sum(E.conv_call_bytes(c) for h in holders[:1] for op in h.plan.ops for c in op.fwd_calls if c.name == 'myolo_conv')
+    nlaunch = sum(len(op.fwd_calls) for h in holders[:1] for op in h.plan.ops)
+    survey_b = 200.8e6 * (H * W) / (512 * 1024)
+    alg = survey_b + na * 15 * 2 + H * W * 8
+    r = {'value': fps, 'unit': 'frames/s',
+         'workload': f'pspv5s fused fp16 1x3x{H}x{W} fwd + NMS({na} rows, {int(det[0].shape[0])} kept) + x8 upsample+argmax (int64 labels)',
+         'ms_per_frame': 1e3 / fps,
+         'stage_ms': {'forward': st[0], 'nms': st[1], 'argmax': st[2],
+                      'what': 'HIP events on the launch stream, 10 frames; nms includes its device->host read of the keep counts'},
+         'graph_replayed': replayed, 'forward_launches': nlaunch,
+         'roofline': {'bound': 'hbm', 'achieved': alg * fps / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                      'frac': alg * fps / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_frame': alg,
+                      'what': 'SURVEY 8(d): conv input + weights + output once each, fp16 (200.8 MB per 512x1024 image) + NMS input rows + '
+                              'int64 label map, over the whole frame time',
+                      'conv_bytes_of_this_plan': conv_b,
+                      'forward_only_frac': survey_b / (st[0] * 1e-3) / 1e9 / HBM_PEAK_GBS if st[0] > 0 else None}}
+    if cpu:
+        from oracle import cpu_bench
+        r['cpu_baseline'] = cpu_bench.detect_frame(H=H, W=W, budget_s=8.0)
+    return r
 
 
 def cpu_baseline(args):
@@ -268,17 +326,35 @@ def cpu_baseline(args):
     return r
 
 
+SURVEY_FWD_BYTES_PER_IMAGE = {          # conv input + weights + output once each, fp16, one 512x1024 image, forward
+    'yolov5s_city_seg.yaml': 200.8e6, 'yolov5s_city_seg_base.yaml': 233.6e6, 'yolov5m_city_seg_lab.yaml': 333.6e6}
+
+
 def whole_step_roofline(tr, ms):
-    """algorithmic bytes of conv (fwd + dgrad) + weight-gradient + BatchNorm launches of one step / step time"""
+    """SURVEY 8(d) convention: a training step moves 3x the forward's conv bytes (forward + dgrad + wgrad; every conv operand once,
+    no fusion credit, nothing else counted) -- 3 x 200.8 MB x 16 = 9.64 GB for the benchmarked step -- over the WHOLE step time."""
+    a = tr.args
+    per = SURVEY_FWD_BYTES_PER_IMAGE.get(a.cfg)
+    if per is None or a.dtype != 'f16':
+        return None
+    tot = 3.0 * per * a.batch * (a.img[0] * a.img[1]) / (512 * 1024)
+    return {'bound': 'hbm', 'achieved': tot / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            'frac': tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': tot,
+            'what': 'SURVEY 8(d): 3 x (conv input + weights + output of the forward, fp16) x batch, over the whole step time'}
+
+
+def whole_step_launch_bytes(tr, ms):
+    """a DIFFERENT count, kept for continuity with rounds 1-2: the operand bytes of the launches this implementation actually issues
+    (conv + dgrad + weight-gradient + BatchNorm passes, every operand once) over the whole step time.  It counts the BatchNorm passes
+    as work, which SURVEY 8(d) does not -- it is NOT the roofline fraction."""
     from multiyolov5_amd import engine as E
     plans = [h.plan for h in tr.model.__dict__.get('_plans', {}).values() if h.plan.training]
     if not plans:
         return None
     by = E.plan_algorithmic_bytes(plans[0])
     tot = sum(by.values())
-    return {'bound': 'hbm', 'achieved': tot / (ms * 1e-3) / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-            'frac': tot / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_step': tot, 'by_family': by,
-            'what': 'conv + dgrad + weight-gradient + BatchNorm launches (every operand once) over the WHOLE step time'}
+    return {'GBps': tot / (ms * 1e-3) / 1e9, 'bytes_per_step': tot, 'by_family': by,
+            'what': 'operand bytes of the issued conv + dgrad + weight-gradient + BatchNorm launches (each once) / whole step time'}
 
 
 def second_config_rate(args, world, rank, dev, cfg='yolov5m_city_seg_lab.yaml', batch=8, steps=10, warm=4):
@@ -298,6 +374,8 @@ def second_config_rate(args, world, rank, dev, cfg='yolov5m_city_seg_lab.yaml', 
     r = {'value': batch / dt, 'unit': 'images/s', 'ms_per_step': dt * 1e3,
          'workload': f'{cfg} bs={batch}/GPU {args.img[1]}x{args.img[0]} {args.dtype} joint train step (BASELINE configs[3] per-GPU share)'}
     r['whole_step_roofline'] = whole_step_roofline(tr, dt * 1e3)
+    r['launch_operand_bytes'] = whole_step_launch_bytes(tr, dt * 1e3)
+    r['checks'] = step_checks(tr)
     return r
 
 
@@ -384,9 +462,11 @@ def main():
     _lib.lib()                                           # fail loudly if the HIP library is missing
     out = {}
     if args.stage == 'infer':
-        fps = infer_fps(args, dev)
+        H, W = args.infer_size
+        r = infer_report(args, dev, H=H, W=W, frames=args.steps, cpu=not args.no_cpu_baseline)
         if rank == 0:
-            print(json.dumps({'metric': 'detect.py FPS (fwd+NMS+argmax) 2048x1024', 'value': fps, 'unit': 'frames/s'}))
+            r['metric'] = f'detect.py FPS (fwd+NMS+argmax) {W}x{H}'
+            print(json.dumps(r))
         return
     tr = Trainer(args, world, rank, dev)
     for _ in range(args.warmup):
@@ -397,6 +477,7 @@ def main():
         tr.step()
     barrier(world)
     dt = time.perf_counter() - t0
+    checks = step_checks(tr)                             # finite losses, no skipped optimizer step in the timed region
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -414,6 +495,7 @@ def main():
                                    and args.dtype == 'f16' else '')),
                    'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'stage': args.stage},
     }
+    out['checks'] = checks
     if args.stage != 'train':
         out['metric'] = 'DEV ONLY fwd+bwd images/sec (no loss / optimizer) -- not a bench line'
     if rank == 0 and world == 1:
@@ -435,13 +517,13 @@ def main():
                                'conv_time_frac_of_step': t / (ms * 1e-3)}
         if args.stage == 'train':
             out['whole_step_roofline'] = whole_step_roofline(tr, ms)
+            out['launch_operand_bytes'] = whole_step_launch_bytes(tr, ms)
         if args.stage == 'train' and not args.no_infer:
             try:
-                out['detect_fps'] = {'value': infer_fps(args, dev), 'unit': 'frames/s',
-                                     'workload': 'pspv5s fused fp16 1x3x1024x2048 fwd + NMS(129024 cand) + x8 upsample+argmax'}
-                out['detect_fps_1024x512'] = {'value': infer_fps(args, dev, H=512, W=1024), 'unit': 'frames/s',
-                                              'workload': 'pspv5s fused fp16 1x3x512x1024 fwd + NMS(32256 cand) + x8 upsample+argmax '
-                                                          '(the resolution of BASELINE.md\'s ~141 FPS point, unstated NVIDIA GPU)'}
+                cpu = not args.no_cpu_baseline
+                out['detect_fps'] = infer_report(args, dev, cpu=cpu)                       # BASELINE configs[4]: 2048x1024
+                out['detect_fps_1024x512'] = infer_report(args, dev, H=512, W=1024, cpu=cpu)
+                out['detect_fps_1024x512']['workload'] += " (the resolution of BASELINE.md's ~141 FPS point, unstated NVIDIA GPU)"
             except Exception as e:                       # the secondary metric must not take the primary line down
                 out['detect_fps'] = {'value': None, 'error': repr(e)}
             try:

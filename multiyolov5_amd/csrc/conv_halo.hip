@@ -359,6 +359,7 @@ int myolo_conv_halo_set(const char* name, int value) {
   if (!strcmp(name, "halo_off")) { g_halo_off = value; return 0; }
   if (!strcmp(name, "halo_min_tiles")) { g_halo_min_tiles = value; return 0; }
   if (!strcmp(name, "halo_dbg")) { g_halo_dbg = value; return 0; }
+  if (!strncmp(name, "small_", 6)) return myolo_conv_small_set(name, value);
   return myolo_wgrad_tile_set(name, value);        // "wgrad_tile_off"
 }
 

@@ -432,7 +432,9 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   }
   if (dt == MYOLO_F16) {
     int done = 0;
-    int r = myolo_conv_halo_try(d, stream, &done);    // k x k stride-1 layers: input halo tiles staged in LDS (conv_halo.hip)
+    int r = myolo_conv_small_try(d, stream);          // small maps, eval epilogue: split-K over the waves, operands straight from L2 (conv_small.hip)
+    if (r != -1) return r;
+    r = myolo_conv_halo_try(d, stream, &done);    // k x k stride-1 layers: input halo tiles staged in LDS (conv_halo.hip)
     if (r == -1) r = myolo_conv_stream_try(d, stream, &done);      // HBM-bound 1x1 / strided layers: the streaming kernel (conv_stream.hip)
     if (r != -1) {
       if (r) return r;

@@ -191,6 +191,9 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
 // conv_halo.hip: LDS-staged input tiles for k x k stride-1 convolutions; -1 = layer does not qualify
 int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 int myolo_conv_halo_set(const char* name, int value);
+// conv_small.hip: split-K kernel for small maps (eval epilogues); -1 = layer does not qualify
+int myolo_conv_small_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_small_set(const char* name, int value);
 // conv_wgrad_tile.hip: weight gradient over LDS-staged spatial tiles; -1 = layer does not qualify
 int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, int* out_cop, int* out_cip, int* used_ws);
 int myolo_wgrad_tile_set(const char* name, int value);

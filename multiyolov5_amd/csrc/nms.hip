@@ -3,12 +3,12 @@
 //
 //   nms_filter : obj > conf (general.py:430,446), cls *= obj (462), xywh->xyxy (465), best class / multi-label (468-473),
 //                wave-aggregated compaction into per-image candidate lists
-//   nms_rank   : descending-score rank of every candidate (ties broken by the original row for determinism); candidates are
-//                scattered to their sorted slot, truncated to max_nms (487-488)
-//   nms_scan   : one workgroup per image walks the sorted list in chunks of 64: the wave resolves the chunk's internal
-//                suppressions with 64-bit lane masks, then all threads mark the later boxes the chunk's survivors suppress.
-//                IoU is taken on the class-offset boxes (box + cls*max_wh, 491-492) with torchvision's formula
-//                inter/(a+b-inter), strict '>'; stops once max_det boxes are kept (494-495).
+//   nms_rank   : (lists longer than 8192 only) descending-score rank of every candidate (ties broken by the original row for
+//                determinism); candidates are scattered to their sorted slot, truncated to max_nms (487-488)
+//   nms_scan   : one workgroup per image; sorts short lists itself (bitonic network over 64-bit keys in LDS), then walks the sorted
+//                list in chunks of 64 against the keep list (see the kernel).  IoU is taken on the class-offset boxes
+//                (box + cls*max_wh, 491-492) with torchvision's formula inter/(a+b-inter), strict '>'; stops once max_det boxes
+//                are kept (494-495).
 #include "myolo_dev.h"
 
 namespace {
@@ -73,15 +73,16 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
   }
 }
 
+constexpr int RANK_SKIP_BELOW = 8192;   // = SORT_MAX: lists this short are sorted in LDS by nms_scan_kernel
 __global__ __launch_bounds__(256) void nms_rank_kernel(const int* counts, const float* cand, const int* cand_idx, int cap,
-                                                       int max_nms, float* sorted) {
+                                                       int max_nms, float* sorted, int lds_sort) {
   __shared__ float ss[256];
   __shared__ int si[256];
   const int b = blockIdx.y;
   int n = counts[b];
   if (n > cap) n = cap;
   const int i0 = blockIdx.x * 256;
-  if (i0 >= n) return;
+  if (i0 >= n || (lds_sort && n <= RANK_SKIP_BELOW)) return;
   const int i = i0 + threadIdx.x;
   const float* cb = cand + (int64_t)b * cap * 6;
   const int* ib = cand_idx + (int64_t)b * cap;
@@ -194,109 +195,225 @@ __global__ __launch_bounds__(256) void nms_place_kernel(const int* counts, const
   }
 }
 
-__device__ __forceinline__ bool iou_gt(float ax1, float ay1, float ax2, float ay2, float bx1, float by1, float bx2, float by2,
-                                       float thr) {
-  // disjoint boxes (in particular boxes of different classes: their offsets differ by >= max_wh) have IoU exactly 0:
-  // four compares instead of the division.  Overlapping ones use torchvision's formula inter/(a+b-inter), strict '>'.
-  const float w = fminf(ax2, bx2) - fmaxf(ax1, bx1), h = fminf(ay2, by2) - fmaxf(ay1, by1);
-  if (w <= 0.f || h <= 0.f) return 0.f > thr;
-  const float aa = (ax2 - ax1) * (ay2 - ay1), ab = (bx2 - bx1) * (by2 - by1);
-  const float inter = w * h;
-  return inter / (aa + ab - inter) > thr;
+__device__ __forceinline__ float box_area(const f4_t a) { return __fmul_rn(a[2] - a[0], a[3] - a[1]); }
+
+// torchvision's test inter/(a+b-inter) > thr (strict), every operation individually rounded (no fused multiply-add: the areas are
+// separate float products in the CPU kernel).  Disjoint boxes (in particular boxes of different classes: their offsets differ by
+// >= max_wh) have IoU exactly 0: six min/max/sub and two compares; the division only runs when SOME lane of the wave overlaps.
+__device__ __forceinline__ bool iou_gt(const f4_t a, float aa, const f4_t b, float ab, float thr) {
+  const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]), h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+  const bool ov = w > 0.f && h > 0.f;
+  bool r = !ov && (0.f > thr);
+  if (__ballot(ov)) {
+    const float inter = __fmul_rn(w, h);
+    r = ov ? __fdiv_rn(inter, __fsub_rn(__fadd_rn(aa, ab), inter)) > thr : r;
+  }
+  return r;
 }
 
 constexpr int SCAN_THREADS = 1024;
-constexpr int MAXW = 1024;            // removed-bit words: up to 65536 sorted candidates per image
+constexpr int SCAN_WAVES = SCAN_THREADS / 64;
+constexpr int MAX_SORTED = 65536;     // sorted candidates one image's scan can walk (max_nms is 30000, general.py:435)
 constexpr int LDS_BOXES = 6144;       // class-offset boxes cached in LDS (96 KB); later ones are re-read from L2
+constexpr int SORT_MAX = 8192;        // candidate lists up to this length are sorted in LDS by the scan kernel itself (64 KB of keys)
+constexpr int SORT_PER_THREAD = SORT_MAX / SCAN_THREADS;
+constexpr int KEPT_MAX = 1024;        // max_det (300, general.py:434) boxes of the keep list in LDS
+constexpr int IDX_BITS = 19, SLOT_BITS = 13;     // LDS sort key: score (32) | inverted original row (19) | candidate slot (13)
+constexpr int NBKT = 64;              // class buckets of the keep list (class id mod 64)
+constexpr int NIL = 0xffff;
 
-__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* counts, const float* sorted, int cap, int max_nms,
-                                                                int max_det, float iou_thr, float max_wh, int agnostic,
-                                                                float* out, int* nkeep) {
+struct KeptBox { f4_t box; float area; int next; int pos; int pad; };     // 32 bytes: two ds_read_b128 per hop
+
+// Greedy suppression of one image's score-sorted candidates (torchvision.ops.nms, call site general.py:493), one workgroup per image.
+//  * short lists (detect.py: 1e3-1e4 candidates) are ordered HERE: 64-bit keys (score, original row, slot) go through a bitonic
+//    network in LDS -- no rank launch, no O(n^2) pass (round 2: 0.2 ms), the keys' LDS is re-used by the box cache afterwards;
+//  * the walk is LAZY: chunk c (64 boxes, one per lane) first learns which of its boxes the keep list so far suppresses, then the
+//    chunk's own 64x64 triangle (wave w: rows 4w..4w+3, a ballot per row) -- no atomics, nothing is ever marked in LATER chunks, so the
+//    work is bounded by n x kept pair tests and stops at max_det; wave 0 then resolves the chunk with scalar bit operations
+//    (find-first-set over the live mask, readlane of the row words) and appends the survivors to the keep list.  Two barriers per
+//    chunk, no global access inside the loop.  (Round 2 marked all later boxes per chunk through 64-bit LDS atomics: 1.15 ms for
+//    7.5 k candidates; a single CU tests 64 pairs per ~13 cycles, so the pair count is what has to shrink:)
+//  * the keep list is CHAINED per class bucket and wave (64 x 16 list heads): a lane only walks the kept boxes of its own class -- boxes
+//    of different classes cannot overlap once the class offset is added, PROVIDED the un-offset coordinates span less than max_wh
+//    (checked here over all candidates; otherwise every box goes to bucket 0 and the walk is exhaustive, like the reference's arithmetic).
+__global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* counts, const float* cand, const int* cand_idx,
+                                                                float* sorted, int cap, int max_nms, int max_det, float iou_thr,
+                                                                float max_wh, int agnostic, int lds_sort, float* out, int* nkeep) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  unsigned long long* removed = reinterpret_cast<unsigned long long*>(smem);              // [MAXW]
-  unsigned long long* cmask = removed + MAXW;                                              // [64] intra-chunk masks
-  f4_t* kbox = reinterpret_cast<f4_t*>(cmask + 64);                                        // [64] survivors of the chunk
-  f4_t* lbox = kbox + 64;                                                                  // [LDS_BOXES] offset boxes
-  __shared__ int s_nk, s_total;
+  f4_t* lbox = reinterpret_cast<f4_t*>(smem);                                              // [LDS_BOXES] offset boxes (after the sort)
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);                  // [SORT_MAX]  (before)
+  KeptBox* kept = reinterpret_cast<KeptBox*>(lbox + LDS_BOXES);                            // [KEPT_MAX] keep list
+  unsigned long long* partial = reinterpret_cast<unsigned long long*>(kept + KEPT_MAX);    // [SCAN_WAVES]
+  unsigned long long* cmask = partial + SCAN_WAVES;                                        // [64]
+  unsigned short* khead = reinterpret_cast<unsigned short*>(cmask + 64);                   // [NBKT][SCAN_WAVES] chain heads
+  float* srange = reinterpret_cast<float*>(khead + NBKT * SCAN_WAVES);                     // [2][SCAN_WAVES] coordinate min / max per wave
+  unsigned char* lcls = reinterpret_cast<unsigned char*>(srange + 2 * SCAN_WAVES);         // [LDS_BOXES] class bucket of the cached boxes
+  __shared__ int s_total;
   const int b = blockIdx.x;
   int m = counts[b];
   if (m > cap) m = cap;
-  if (m > max_nms) m = max_nms;
-  const float* sb = sorted + (int64_t)b * max_nms * 6;
-  const int tid = threadIdx.x;
-  const int words = (m + 63) >> 6;
+  const bool sort_here = lds_sort && m <= SORT_MAX;
+  const float* cb = cand + (int64_t)b * cap * 6;
+  float* sb = sorted + (int64_t)b * max_nms * 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float off = agnostic ? 0.f : max_wh;
-  for (int i = tid; i < words; i += SCAN_THREADS) removed[i] = 0ull;
-  for (int i = tid; i < m && i < LDS_BOXES; i += SCAN_THREADS) {
-    const float o = sb[(int64_t)i * 6 + 5] * off;                     // class offset (general.py:491-492), fp32 like the reference
-    lbox[i] = f4_t{sb[(int64_t)i * 6] + o, sb[(int64_t)i * 6 + 1] + o, sb[(int64_t)i * 6 + 2] + o, sb[(int64_t)i * 6 + 3] + o};
-  }
   if (tid == 0) s_total = 0;
+  for (int i = tid; i < NBKT * SCAN_WAVES; i += SCAN_THREADS) khead[i] = (unsigned short)NIL;
+  float cmin = INFINITY, cmax = -INFINITY;                                                  // range of the un-offset coordinates
+  if (sort_here) {
+    int npow = 64;
+    while (npow < m) npow <<= 1;
+    const int* ib = cand_idx + (int64_t)b * cap;
+    for (int i = tid; i < npow; i += SCAN_THREADS) {
+      unsigned long long k = 0ull;                                                          // padding sorts last (real scores are > 0)
+      if (i < m)
+        k = ((unsigned long long)__float_as_uint(cb[(int64_t)i * 6 + 4]) << 32) |
+            ((unsigned long long)(((1u << IDX_BITS) - 1u) - (unsigned)ib[i]) << SLOT_BITS) | (unsigned)i;
+      keys[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (npow >> 1); t += SCAN_THREADS) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i + j;
+          const unsigned long long x = keys[i], y = keys[l];
+          if ((x < y) == ((i & k) == 0)) { keys[i] = y; keys[l] = x; }                      // descending overall
+        }
+        __syncthreads();
+      }
+    }
+    if (m > max_nms) m = max_nms;                                                           // general.py:487-488
+    int slot[SORT_PER_THREAD];
+#pragma unroll
+    for (int q = 0; q < SORT_PER_THREAD; ++q) {
+      const int p = tid + q * SCAN_THREADS;
+      slot[q] = p < m ? (int)(keys[p] & ((1u << SLOT_BITS) - 1u)) : -1;
+    }
+    __syncthreads();                                                                        // the keys' LDS becomes the box cache
+#pragma unroll
+    for (int q = 0; q < SORT_PER_THREAD; ++q) {
+      const int p = tid + q * SCAN_THREADS;
+      if (slot[q] < 0) continue;
+      const float* c = cb + (int64_t)slot[q] * 6;
+      float r[6];
+#pragma unroll
+      for (int e = 0; e < 6; ++e) r[e] = c[e];
+      float* d = sb + (int64_t)p * 6;                                                       // the sorted rows (output rows are copied from here)
+#pragma unroll
+      for (int e = 0; e < 6; ++e) d[e] = r[e];
+      cmin = fminf(cmin, fminf(fminf(r[0], r[1]), fminf(r[2], r[3])));
+      cmax = fmaxf(cmax, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+      const float o = r[5] * off;                                                           // class offset (general.py:491-492), fp32 like the reference
+      if (p < LDS_BOXES) { lbox[p] = f4_t{r[0] + o, r[1] + o, r[2] + o, r[3] + o}; lcls[p] = (unsigned char)((int)r[5] & (NBKT - 1)); }
+    }
+  } else {
+    if (m > max_nms) m = max_nms;
+    for (int i = tid; i < m; i += SCAN_THREADS) {
+      const float* r = sb + (int64_t)i * 6;
+      cmin = fminf(cmin, fminf(fminf(r[0], r[1]), fminf(r[2], r[3])));
+      cmax = fmaxf(cmax, fmaxf(fmaxf(r[0], r[1]), fmaxf(r[2], r[3])));
+      const float o = r[5] * off;
+      if (i < LDS_BOXES) { lbox[i] = f4_t{r[0] + o, r[1] + o, r[2] + o, r[3] + o}; lcls[i] = (unsigned char)((int)r[5] & (NBKT - 1)); }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { cmin = fminf(cmin, __shfl_xor(cmin, o, 64)); cmax = fmaxf(cmax, __shfl_xor(cmax, o, 64)); }
+  if (lane == 0) { srange[wv] = cmin; srange[SCAN_WAVES + wv] = cmax; }
+  __threadfence_block();
   __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SCAN_WAVES; ++q) { cmin = fminf(cmin, srange[q]); cmax = fmaxf(cmax, srange[SCAN_WAVES + q]); }
+  // classes are disjoint after the offset iff every class's coordinate range [c*max_wh + cmin, c*max_wh + cmax] ends before the next
+  // one begins (NaN coordinates fail the compare: exhaustive walk)
+  const bool by_class = !agnostic && (cmax - cmin < max_wh);
   auto obox = [&](int i) -> f4_t {
     if (i < LDS_BOXES) return lbox[i];
-    const float o = sb[(int64_t)i * 6 + 5] * off;
-    return f4_t{sb[(int64_t)i * 6] + o, sb[(int64_t)i * 6 + 1] + o, sb[(int64_t)i * 6 + 2] + o, sb[(int64_t)i * 6 + 3] + o};
+    const volatile float* r = sb + (int64_t)i * 6;                                          // (rows this workgroup may have written itself)
+    const float o = r[5] * off;
+    return f4_t{r[0] + o, r[1] + o, r[2] + o, r[3] + o};
   };
+  const int words = (m + 63) >> 6;
+  int total = 0;
   for (int c = 0; c < words; ++c) {
     const int base = c << 6;
     const int lim = m - base < 64 ? m - base : 64;
     const unsigned long long limmask = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
-    if ((~removed[c] & limmask) == 0ull) continue;     // every box of the chunk is already suppressed (uniform: read after a barrier)
-    if (tid < 64) cmask[tid] = 0ull;
-    __syncthreads();
-    // (a) the chunk's 64x64 suppression bits, all threads: pair (i, j > i)
-    for (int pr = tid; pr < 64 * 64; pr += SCAN_THREADS) {
-      const int i = pr >> 6, j = pr & 63;
-      if (j > i && j < lim) {
-        const f4_t a = obox(base + i), bb = obox(base + j);
-        if (iou_gt(a[0], a[1], a[2], a[3], bb[0], bb[1], bb[2], bb[3], iou_thr)) atomicOr(&cmask[i], 1ull << j);
-      }
+    const bool valid = lane < lim;
+    const f4_t bj = valid ? obox(base + lane) : f4_t{0.f, 0.f, 0.f, 0.f};
+    const float aj = box_area(bj);
+    int bkt = 0;
+    if (by_class && valid)
+      bkt = base + lane < LDS_BOXES ? (int)lcls[base + lane] : (((int)*(const volatile float*)(sb + (int64_t)(base + lane) * 6 + 5)) & (NBKT - 1));
+    // (a) this chunk against the keep list so far: wave wv walks chain (bucket, wv); one ballot = the wave's removed word
+    bool dead = false;
+    int k = valid ? khead[bkt * SCAN_WAVES + wv] : NIL;
+    while (__ballot(k != NIL)) {
+      const bool act = k != NIL;
+      const KeptBox kb = kept[act ? k : 0];
+      const bool hit = iou_gt(kb.box, kb.area, bj, aj, iou_thr);
+      dead = dead || (act && hit);
+      k = act ? kb.next : NIL;
     }
-    __syncthreads();
-    // (b) wave 0 resolves the chunk serially with lane-held masks
-    if (tid < 64) {
-      const unsigned long long mask = cmask[tid];
-      unsigned long long rem = removed[c];
-      unsigned long long keepbits = 0ull;
-      for (int i2 = 0; i2 < lim; ++i2) {
-        const unsigned int lo = __shfl((unsigned int)mask, i2, 64), hi = __shfl((unsigned int)(mask >> 32), i2, 64);
-        if (!((rem >> i2) & 1ull)) {
-          keepbits |= 1ull << i2;
-          rem |= ((unsigned long long)hi << 32) | lo;
-        }
-      }
-      const bool mine = (keepbits >> tid) & 1ull;
-      const int pos = __popcll(keepbits & ((1ull << tid) - 1ull));
-      const int total = s_total;
-      if (mine) {
-        kbox[pos] = obox(base + tid);
-        const int o = total + pos;
-        if (o < max_det) {
-          float* d = out + ((int64_t)b * max_det + o) * 6;
+    const unsigned long long dw = __ballot(dead && valid);
+    if (lane == 0) partial[wv] = dw;
+    // (b) the chunk's own upper triangle: row i suppresses column j > i
 #pragma unroll
-          for (int q = 0; q < 6; ++q) d[q] = sb[(int64_t)(base + tid) * 6 + q];
+    for (int r = 0; r < 64 / SCAN_WAVES; ++r) {
+      const int i = wv * (64 / SCAN_WAVES) + r;
+      unsigned long long rw = 0ull;
+      if (i < lim) {
+        const f4_t bi = obox(base + i);
+        rw = __ballot(iou_gt(bi, box_area(bi), bj, aj, iou_thr) && valid && lane > i);
+      }
+      if (lane == 0) cmask[i] = rw;
+    }
+    __syncthreads();
+    if (wv == 0) {
+      unsigned long long remv = ~limmask;
+#pragma unroll
+      for (int q = 0; q < SCAN_WAVES; ++q) remv |= partial[q];
+      const unsigned long long rowv = cmask[lane];
+      const unsigned int row_lo = (unsigned int)rowv, row_hi = (unsigned int)(rowv >> 32);
+      // wave-uniform from here: scalar registers
+      // (the builtins return int: without the unsigned casts a set bit 31 of the low word would sign-extend over the high word)
+      unsigned long long rem = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)(remv >> 32)) << 32) |
+                               (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)remv);
+      unsigned long long keepbits = 0ull;
+      int budget = max_det - total;
+      while (~rem != 0ull && budget > 0) {
+        const int i = __ffsll((long long)~rem) - 1;
+        keepbits |= 1ull << i;
+        --budget;
+        const unsigned long long rw = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_hi, i) << 32) |
+                                      (unsigned long long)(unsigned int)__builtin_amdgcn_readlane(row_lo, i);
+        rem |= rw | (1ull << i);
+      }
+      const bool mine = (keepbits >> lane) & 1ull;
+      const int rel = __popcll(keepbits & ((1ull << lane) - 1ull));
+      const int pos = total + rel;
+      const int nk = __popcll(keepbits);
+      // survivors join their chain (bucket, pos % 16); 16 at a time, so that no two lanes of a round share a chain head
+      for (int r0 = 0; r0 < nk; r0 += SCAN_WAVES) {
+        if (mine && rel >= r0 && rel < r0 + SCAN_WAVES) {
+          const int ch = bkt * SCAN_WAVES + (pos & (SCAN_WAVES - 1));
+          KeptBox kb;
+          kb.box = bj; kb.area = aj; kb.next = khead[ch]; kb.pos = base + lane; kb.pad = 0;
+          kept[pos] = kb;
+          khead[ch] = (unsigned short)pos;
         }
       }
-      if (tid == 0) { s_nk = __popcll(keepbits); s_total = total + __popcll(keepbits); }
+      if (lane == 0) s_total = total + nk;
     }
     __syncthreads();
-    const int nk = s_nk;
-    if (s_total >= max_det) break;
-    // (c) later boxes suppressed by this chunk's survivors
-    for (int j = base + 64 + tid; j < m; j += SCAN_THREADS) {
-      if ((removed[j >> 6] >> (j & 63)) & 1ull) continue;
-      const f4_t bj = obox(j);
-      bool dead = false;
-      for (int q = 0; q < nk && !dead; ++q) {
-        const f4_t kq = kbox[q];
-        dead = iou_gt(kq[0], kq[1], kq[2], kq[3], bj[0], bj[1], bj[2], bj[3], iou_thr);
-      }
-      if (dead) atomicOr(&removed[j >> 6], 1ull << (j & 63));
-    }
-    __syncthreads();
+    total = s_total;
+    if (total >= max_det) break;
   }
-  if (tid == 0) nkeep[b] = s_total < max_det ? s_total : max_det;
+  // the kept rows, in keep order (= descending score): x1, y1, x2, y2, conf, cls as the filter wrote them
+  for (int e = tid; e < total * 6; e += SCAN_THREADS) {
+    const int k = e / 6, q = e - k * 6;
+    out[((int64_t)b * max_det + k) * 6 + q] = *(const volatile float*)(sb + (int64_t)kept[k].pos * 6 + q);
+  }
+  if (tid == 0) nkeep[b] = total;
 }
 
 }  // namespace
@@ -307,13 +424,16 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
                          int32_t* sort_ws, void* stream) {
   if (class_mask && no - 5 > 64) return MYOLO_EINVAL;
   if (!pred || (dtype != MYOLO_F16 && dtype != MYOLO_F32) || batch < 1 || A < 1 || no < 6 || cap < 1 || max_det < 1 ||
-      max_nms < 1 || max_nms > MAXW * 64 || !counts || !cand || !cand_idx || !sorted || !out || !nkeep)
+      max_det > KEPT_MAX || max_nms < 1 || max_nms > MAX_SORTED || !counts || !cand || !cand_idx || !sorted || !out || !nkeep)
     return MYOLO_EINVAL;
+  static_assert(RANK_SKIP_BELOW == SORT_MAX && SORT_MAX == (1 << SLOT_BITS), "LDS sort key layout");
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(counts, 0, batch * sizeof(int32_t), st);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), 0, st, pred, dtype, A, no, conf_thres,
                      multi_label, cap, counts, cand, cand_idx, class_mask);
+  // short single-label lists are ordered inside the scan kernel (original rows must fit the key's 19 bits)
+  const int lds_sort = (!sort_ws && (int64_t)cap <= (1ll << IDX_BITS)) ? 1 : 0;
   if (sort_ws) {             // long lists: counting sort; sort_ws = int32 [batch][3*65536 + cap]
     int* hist = sort_ws;
     int* fill = hist + (int64_t)batch * NB;
@@ -327,17 +447,19 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
     hipLaunchKernelGGL(nms_group_kernel, dim3(gx, batch), dim3(256), 0, st, counts, cand, cap, start, fill, order);
     hipLaunchKernelGGL(nms_place_kernel, dim3(gx, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, start, hist, order, max_nms, sorted);
   } else {
-    hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted);
+    hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted,
+                       lds_sort);
   }
-  const int scan_smem = MAXW * 8 + 64 * 8 + 64 * 16 + LDS_BOXES * 16;
+  const int scan_smem = LDS_BOXES * 16 + KEPT_MAX * (int)sizeof(KeptBox) + SCAN_WAVES * 8 + 64 * 8 + NBKT * SCAN_WAVES * 2 + 2 * SCAN_WAVES * 4 + LDS_BOXES;
+  static_assert(SORT_MAX * 8 <= LDS_BOXES * 16, "the sort keys live in the box cache's LDS");
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(nms_scan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, scan_smem);
     if (ea != hipSuccess) return (int)ea;
     attr_set = true;
   }
-  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), scan_smem, st, counts, sorted, cap, max_nms, max_det, iou_thres,
-                     max_wh, agnostic, out, nkeep);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), scan_smem, st, counts, cand, cand_idx, sorted, cap, max_nms,
+                     max_det, iou_thres, max_wh, agnostic, lds_sort, out, nkeep);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

@@ -800,7 +800,8 @@ class SegOutOp(Op):
             # K15: utils.loss can run upsample + CE + both backwards in one pass over the low-res logits (myolo_seg_upce_fwd_grad); it
             # leaves the classifier's unnormalised fp32 gradient in glow32 and sets gstate['low'] -- the backward then only rescales it
             self.glow32 = torch.zeros(lw.n, lw.h, lw.w, lw.c, dtype=torch.float32, device=plan.device)
-            out._myolo_low_grad = self.glow32
+            if not GRAPH_TRAIN:          # a captured backward bakes in ONE branch of the switch below (the full-resolution one, chosen
+                out._myolo_low_grad = self.glow32    # at capture time): the fused low-resolution loss is not offered under MYOLO_GRAPH_TRAIN
             self.gstate['low'] = False
             low = Call('myolo_seg_lowgrad_apply', (L.ptr(self.glow32), C.byref(self.gld), self.acc, L.ptr(self.gscale)),
                        keep=(self.glow32, self.gscale))

@@ -413,6 +413,15 @@ class PlannedModule(nn.Module):
         else:
             h.bind_inputs(tensors)
             h.plan.run_fwd()
+            if self.training:
+                # train mode without autograd (`with torch.no_grad(): model(x)`: BatchNorm recalibration, train-mode validation): the
+                # deferred x8 upsample of the logits has no LazySegLogits wrapper to trigger it -- run it now
+                st = L.stream_ptr()
+                for op in h.plan.ops:
+                    lazy = getattr(op, 'lazy_call', None)
+                    if lazy is not None:
+                        lazy(st)
+                h.generation += 1
             outs = h.output_tensors()
         return _OutSpec.rebuild(h.out_spec, list(outs))
 

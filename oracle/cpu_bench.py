@@ -61,3 +61,49 @@ def joint_step(cfg='yolov5s_city_seg.yaml', batch=2, H=512, W=1024, budget_s=20.
     return {'value': batch / best, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
             'sample': f'{n} joint steps (fwd + ComputeLoss + seg CE + bwd) of {cfg} at {batch}x3x{H}x{W} fp32, torch CPU, '
                       f'{cores} threads, best of {n} after 1 warm-up ({best * 1e3:.0f} ms/step)'}
+
+
+def detect_frame(cfg='yolov5s_city_seg.yaml', H=1024, W=2048, budget_s=12.0, max_threads=16):
+    """detect.py:144-193 on the host cores: fused eval forward (torch CPU fp32) + non_max_suppression on the bench's synthetic
+    prediction tensor + bilinear resize / argmax of the class logits, per frame.  Bounded sample: the warm-up frame plus as many
+    frames as fit in `budget_s` (at most 5); the best frame is reported."""
+    import numpy as np
+    from . import nms_ref
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, max_threads))
+    torch.set_num_threads(cores)
+    with open(os.path.join(ROOT, 'multiyolov5_amd', 'cfg', cfg)) as f:
+        cfgd = yaml.safe_load(f)
+    sd = model_ref.fuse_state_dict(synth.synth_state_dict(shapes.template_state_dict(cfgd), 0))
+    x = synth.synth_images(1, H, W, seed=7)
+    na = 3 * ((H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32))
+    pred = synth.synth_nms_pred(1, na, 10, seed=3, img_w=W, img_h=H).numpy()
+
+    def frame():
+        t = [time.perf_counter()]
+        with torch.no_grad():
+            det, seg = model_ref.forward(cfgd, sd, x, training=False)
+        t.append(time.perf_counter())
+        nms_ref.non_max_suppression(pred, 0.25, 0.45)
+        t.append(time.perf_counter())
+        segs = seg[0] if isinstance(seg, (list, tuple)) else seg
+        lab = torch.nn.functional.interpolate(segs, size=(H, W), mode='bilinear', align_corners=True).argmax(1)   # detect.py:191-193
+        t.append(time.perf_counter())
+        return [b - a for a, b in zip(t, t[1:])], lab
+
+    t0 = time.perf_counter()
+    best, _ = frame()
+    n = 0
+    while time.perf_counter() - t0 < budget_s and n < 5:
+        cur, _ = frame()
+        n += 1
+        if sum(cur) < sum(best):
+            best = cur
+    tot = sum(best)
+    return {'value': 1.0 / tot, 'unit': 'frames/s', 'cores': cores, 'kind': 'port',
+            'stage_ms': {'forward': best[0] * 1e3, 'nms': best[1] * 1e3, 'argmax': best[2] * 1e3},
+            'sample': f'{n + 1} frames of fused {cfg} at 1x3x{H}x{W} fp32 (torch CPU eval forward + numpy NMS of the synthetic '
+                      f'{na}-row prediction + bilinear resize/argmax), {cores} threads, best frame {tot * 1e3:.0f} ms'}

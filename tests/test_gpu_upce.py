@@ -193,3 +193,53 @@ def test_training_logits_are_materialised_only_on_demand(monkeypatch):
     assert not isinstance(out3, R.LazySegLogits)
     ref = out3.detach().float().cpu()                             # (two forwards differ in the last bits: the BatchNorm sums are fp32 atomics)
     assert float((ref - vals).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_train_mode_without_autograd_returns_real_logits(monkeypatch):
+    """`model.train(); with torch.no_grad(): model(x)` (BatchNorm recalibration, train-mode validation): no LazySegLogits wrapper is
+    there to trigger the deferred x8 upsample, so the forward itself must run it -- the logits equal the eager path's"""
+    from multiyolov5_amd import engine as E, runtime as R
+    mod, xs_cpu, _ = _psp_head()
+    with torch.no_grad():
+        out = mod([x.to(DEV) for x in xs_cpu])
+    assert not isinstance(out, R.LazySegLogits) and tuple(out.shape) == (2, 19, 128, 256)
+    vals = out.detach().float().cpu().clone()
+    assert torch.isfinite(vals).all()
+    monkeypatch.setattr(E, 'LAZY_SEG', False)
+    mod2, _, _ = _psp_head()
+    with torch.no_grad():
+        ref = mod2([x.to(DEV) for x in xs_cpu]).detach().float().cpu()
+    assert float((ref - vals).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # and a second no_grad forward on new data overwrites the same storage with the new values (nothing stale is served)
+    with torch.no_grad():
+        out_b = mod([(x * 0.5).to(DEV) for x in xs_cpu]).detach().float().cpu()
+    assert float((out_b - vals).abs().max()) > 1e-3
+
+
+def test_graph_train_segmentation_gradients_match_eager(monkeypatch):
+    """MYOLO_GRAPH_TRAIN=1: the captured backward bakes in the full-resolution branch of the segmentation gradient switch, so the
+    fused low-resolution loss must not be offered -- head gradients of graph replays (step 3 onwards) equal the eager ones"""
+    from multiyolov5_amd import engine as E
+    from multiyolov5_amd.utils import loss as loss_mod
+
+    def grads(graph):
+        monkeypatch.setattr(E, 'GRAPH_TRAIN', graph)
+        mod, xs_cpu, tgt = _psp_head()
+        out_g = None
+        for _ in range(4):                          # two eager warm-up runs, capture, replay
+            for p in mod.parameters():
+                p.grad = None
+            xs = [x.to(DEV).requires_grad_() for x in xs_cpu]
+            loss = loss_mod.seg_cross_entropy(mod(xs), tgt)
+            loss.backward()
+            out_g = [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.parameters()]
+        torch.cuda.synchronize()
+        return float(loss), out_g
+
+    l0, g0 = grads(False)
+    l1, g1 = grads(True)
+    assert abs(l0 - l1) <= 1e-5 * abs(l0)
+    assert any(float(g.abs().max()) > 0 for g in g1[3:])
+    for a, b in zip(g1, g0):
+        den = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) / den <= 5e-4, float((a - b).abs().max()) / den
