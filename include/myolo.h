@@ -362,10 +362,16 @@ int myolo_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf,
  * cap >= A (A*nc when multi_label).  Results: out float[batch][max_det][6] = (x1,y1,x2,y2,conf,cls) in descending conf,
  * nkeep int32[batch].  class_mask: the `classes=` filter (general.py:476-477) as a bit set, bit j = keep class j; 0 = keep all
  * (nc <= 64 when non-zero).  sort_ws (optional, device int32 [batch][3*65536 + cap]): the descending-score order is produced by a
- * counting sort instead of the O(n^2) rank kernel -- for test.py's conf 0.001 / multi_label lists (1e5 candidates per image). */
+ * counting sort instead of the O(n^2) rank kernel -- for test.py's conf 0.001 / multi_label lists (1e5 candidates per image).
+ * mws (optional, device, 16-byte aligned, >= myolo_nms_ws_bytes(batch, cap) bytes; single-label calls, cap == A, max_det <= 320):
+ * images with at most 8192 candidates (detect.py) take the device-wide path -- rank, scatter and the n x n suppression bit matrix on all
+ * CUs, then one wave per image walks the sorted list with bit operations only; longer lists and callers without mws keep the
+ * single-workgroup lazy scan.  Identical results either way. */
+int64_t myolo_nms_ws_bytes(int batch, int cap);
 int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres, int multi_label,
               int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts, float* cand,
-              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, int32_t* sort_ws, void* stream);
+              int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask, int32_t* sort_ws, void* mws,
+              int64_t mws_bytes, void* stream);
 
 /* test.py:230-262 (true-positive matrix of one image, the input of ap_per_class): pred [n][6] = (x1,y1,x2,y2,conf,cls) in NMS order and
  * labels [m][5] = (cls,x1,y1,x2,y2), native image space, device float32; iouv device float[niou] (test.py:98 linspace(0.5,0.95,10));
@@ -454,6 +460,35 @@ typedef struct myolo_mosaic_desc {
   uint8_t* out_hwc;
 } myolo_mosaic_desc;
 int myolo_mosaic_warp(const myolo_mosaic_desc* d, void* stream);
+
+/* ---- native plan executor (csrc/plan_exec.hip) ---------------------------------------------------------
+ * Replaces the reference's Python interpreter loop over the layers (models/yolo.py:293-316 forward_once: one module call per
+ * layer, each several ATen launches) AND this package's own round-1/2 loop of one ctypes call per launch: a plan's forward or
+ * backward launch list is serialised once into myolo_prog_op records and one myolo_prog_run() call issues a [first, last) range
+ * of them.  Every argument of the target entry point except its trailing stream occupies one 8-byte slot: pointers as addresses
+ * (descriptor structs stay owned by the caller and must outlive the program), integers sign-extended, floats as their IEEE bit
+ * pattern in the low 32 bits.  cond != 0: the op only runs while *(const int32_t*)cond == cond_val (host memory, read at run time;
+ * the per-step choice between the full-resolution and the fused low-resolution segmentation gradient).
+ * CALL_SIDE forks to `side_stream` behind an event recorded on `main_stream` (weight gradients: nothing on the backward chain
+ * depends on them); JOIN makes main_stream wait for side_stream; MEMSET zeroes a[1] bytes at a[0] on main_stream.  With a NULL
+ * side stream everything runs on main_stream.  No allocation, no synchronisation, no host read besides `cond`. */
+#define MYOLO_PROG_MAX_ARGS 24
+enum { MYOLO_OP_CALL = 0, MYOLO_OP_CALL_SIDE = 1, MYOLO_OP_JOIN = 2, MYOLO_OP_MEMSET = 3 };
+typedef struct myolo_prog_op {
+  int32_t  kind;                 /* MYOLO_OP_* */
+  int32_t  fn;                   /* myolo_prog_fn_id() of the entry point (CALL / CALL_SIDE) */
+  int32_t  nargs;                /* must equal myolo_prog_fn_nargs(fn) */
+  int32_t  cond_val;
+  uint64_t cond;                 /* host address of an int32 or 0 */
+  uint64_t a[MYOLO_PROG_MAX_ARGS];
+} myolo_prog_op;
+int   myolo_prog_fn_id(const char* name);          /* -1: this entry point cannot be part of a program */
+int   myolo_prog_fn_nargs(int fn);                 /* argument slots (the stream excluded) */
+void* myolo_prog_create(const myolo_prog_op* ops, int n);      /* copies the records, creates the fork/join events; NULL on a bad record */
+void  myolo_prog_destroy(void* prog);
+uint64_t* myolo_prog_slot(void* prog, int op, int arg);        /* address of one argument slot (to re-bind caller tensors per run) */
+int   myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream);  /* 0 or the failing launch's error */
+int   myolo_prog_last_op(void* prog);              /* index of the op the last failing run stopped at */
 
 #ifdef __cplusplus
 }

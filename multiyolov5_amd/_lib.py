@@ -82,6 +82,16 @@ class SgdHyper(C.Structure):
                 ('nesterov', C.c_int32), ('reserved', C.c_int32)]
 
 
+PROG_MAX_ARGS = 24
+OP_CALL, OP_CALL_SIDE, OP_JOIN, OP_MEMSET = 0, 1, 2, 3
+
+
+class ProgOp(C.Structure):
+    """include/myolo.h myolo_prog_op: one record of a native launch program (csrc/plan_exec.hip)"""
+    _fields_ = [('kind', C.c_int32), ('fn', C.c_int32), ('nargs', C.c_int32), ('cond_val', C.c_int32), ('cond', C.c_uint64),
+                ('a', C.c_uint64 * PROG_MAX_ARGS)]
+
+
 class MyoloError(RuntimeError):
     pass
 
@@ -156,8 +166,16 @@ _PROTOS = {
     'myolo_frame_resize_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P,
                                           C.c_int, P, P]),
     'myolo_seg_blend': (C.c_int, [P, C.c_int, P, C.c_int, C.c_int, P, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, P, P, P]),
+    'myolo_prog_fn_id': (C.c_int, [C.c_char_p]),
+    'myolo_prog_fn_nargs': (C.c_int, [C.c_int]),
+    'myolo_prog_create': (C.c_void_p, [C.POINTER(ProgOp), C.c_int]),
+    'myolo_prog_destroy': (None, [C.c_void_p]),
+    'myolo_prog_slot': (C.POINTER(C.c_uint64), [C.c_void_p, C.c_int, C.c_int]),
+    'myolo_prog_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    'myolo_prog_last_op': (C.c_int, [C.c_void_p]),
+    'myolo_nms_ws_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'myolo_nms': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
-                            C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint64, P, P]),
+                            C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint64, P, P, C.c_int64, P]),
 }
 
 

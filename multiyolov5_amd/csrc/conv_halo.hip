@@ -321,10 +321,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
 template <int BN, int MF, int NVT, int EPI, int EXTRA, int S2 = 0, int BNS = 0>
 int launch4(const ConvH& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
   auto kern = conv_halo_kernel<BN, MF, NVT, EPI, EXTRA, S2, BNS>;
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-  }
+  MYOLO_ENSURE_DYN_SMEM(kern, smem);
   hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;

@@ -383,10 +383,7 @@ int launch_conv4(ConvK k, int grid_x, int ntile_n, hipStream_t st) {
   k.bn_off = smem;
   if (BNS) smem += 4 * BN * 4;
   auto kern = conv_igemm_kernel<T, BN, BM, KS, BNS>;
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-  }
+  MYOLO_ENSURE_DYN_SMEM(kern, smem);
   hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;

@@ -323,10 +323,7 @@ __global__ __launch_bounds__(THREADS) void conv_stream_kernel(const ConvS p) {
 template <int BN, int KB, int EPI, int EXTRA, int BNS = 0>
 int launch3(const ConvS& k, int grid_x, int ntile_n, int smem, hipStream_t st) {
   auto kern = conv_stream_kernel<BN, KB, EPI, EXTRA, BNS>;
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-  }
+  MYOLO_ENSURE_DYN_SMEM(kern, smem);
   hipLaunchKernelGGL(kern, dim3(grid_x, ntile_n), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;
@@ -353,6 +350,7 @@ static inline int panel_pitch(int K) {                    // bytes; multiple of 
 }
 
 // returns -1 when the layer does not qualify (caller falls back to the LDS-tiled kernel), else a hipError_t / 0
+extern int g_nms_dbg;                    // nms.hip
 static int g_stream_min_tiles = -1;      // -1: from the environment (MYOLO_STREAM_MIN_TILES) or 2048
 static int g_stream_off = -1;
 static int g_stream_dbg = -1;           // profiling only: 1 no stores, 2 no activation loads
@@ -364,6 +362,7 @@ extern "C" int myolo_set_option(const char* name, int value) {
   if (!strcmp(name, "stream_off")) { g_stream_off = value; return 0; }
   if (!strcmp(name, "stream_dbg")) { g_stream_dbg = value; return 0; }
   if (!strcmp(name, "stream_per_cu")) { g_stream_per_cu = value; return 0; }
+  if (!strcmp(name, "nms_dbg")) { g_nms_dbg = value; return 0; }
   return myolo_conv_halo_set(name, value);      // "halo_off", "halo_min_tiles"
 
 }

@@ -183,10 +183,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
 template <int NT, int COF, int CIF>
 int launch(const WgT& k, int out_tiles, int smem, hipStream_t st) {
   auto kern = wgrad_tile_kernel<NT, COF, CIF>;
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) return (int)e;
-  }
+  MYOLO_ENSURE_DYN_SMEM(kern, smem);
   hipLaunchKernelGGL(kern, dim3(out_tiles, k.ksplit), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;

@@ -16,6 +16,20 @@ typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
     if (e__ != hipSuccess) return (int)e__;                   \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize once per kernel instantiation and size (the expansion site's static: a template
+// launcher gets one per instantiation).  Calling hipFuncSetAttribute on EVERY launch was a driver round trip per convolution: the
+// native executor measured 8.2 us of host time per launch (r3).
+#include <atomic>
+#define MYOLO_ENSURE_DYN_SMEM(kern, smem)                                                                             \
+  do {                                                                                                                \
+    static std::atomic<int> cur__{64 * 1024};                                                                         \
+    if ((smem) > cur__.load(std::memory_order_relaxed)) {                                                             \
+      hipError_t e__ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (smem)); \
+      if (e__ != hipSuccess) return (int)e__;                                                                         \
+      cur__.store((smem), std::memory_order_relaxed);                                                                 \
+    }                                                                                                                 \
+  } while (0)
+
 // element traits: a "segment" is one 16-byte vector (8 halves / 4 floats)
 template <typename T> struct ET;
 template <> struct ET<half_t> { static constexpr int SEG = 8; static constexpr int KC = 32; };

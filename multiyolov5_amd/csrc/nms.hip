@@ -19,7 +19,8 @@ __device__ __forceinline__ float ldp(const void* p, int64_t i, int dt) {
 
 // class_mask: bit j set = class j passes the `classes=` filter of general.py:476-477 (0 = no filter)
 __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int dt, int A, int no, float conf, int multi,
-                                                         int cap, int* counts, float* cand, int* cand_idx, uint64_t class_mask) {
+                                                         int cap, int* counts, float* cand, int* cand_idx, uint64_t class_mask,
+                                                         unsigned long long* keys, int* rank, int64_t pred_bytes) {
   const int b = blockIdx.y;
   const int nc = no - 5;
   // fp16 predictions (detect.py --half): the reference's `x[:, 5:] *= x[:, 4:5]`, `xywh2xyxy` and threshold compares run in the input
@@ -28,44 +29,74 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
   auto rh = [hf](float v) { return hf ? (float)(half_t)v : v; };
   conf = rh(conf);
   const int lane = threadIdx.x & 63;
-  // one atomic per WAVE and append (not per candidate: same-address atomics retire at ~110 ns each -- 30 k candidates of a
-  // multi-label test.py call were 3 ms of nothing else): ballot, the first active lane reserves popcount slots, lanes take their rank
+  // one atomic per WORKGROUP and append (same-address atomics retire at ~18-110 ns each whatever else the chip does: one per
+  // candidate made a multi-label test.py call 3 ms of nothing else, one per wave still 2016 x 18 ns = 36 us for the 129 k rows of a
+  // 2048x1024 frame): wave ballots meet in LDS, thread 0 reserves the workgroup's slots, every lane takes its rank.  Called uniformly by
+  // all four waves (two barriers per call; the LDS cells alternate between calls so a fast wave cannot overwrite a slow wave's input).
+  __shared__ int s_wc[2][4], s_base[2];
+  int call_parity = 0;
   auto append = [&](bool pass, float x1, float y1, float x2, float y2, float sc, int cls, int idx) {
     const unsigned long long m = __ballot(pass);
-    if (!m) return;
-    int base = 0;
-    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counts + b, __popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1, 64);
+    const int wave = threadIdx.x >> 6, par = call_parity;
+    call_parity ^= 1;
+    if (lane == 0) s_wc[par][wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int tot = s_wc[par][0] + s_wc[par][1] + s_wc[par][2] + s_wc[par][3];
+      s_base[par] = tot ? atomicAdd(counts + b, tot) : 0;
+    }
+    __syncthreads();
+    int base = s_base[par];
+    for (int w = 0; w < wave; ++w) base += s_wc[par][w];
     if (pass) {
       const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
       if (slot < cap) {
         float* c = cand + ((int64_t)b * cap + slot) * 6;
         c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = sc; c[5] = (float)cls;
         cand_idx[(int64_t)b * cap + slot] = idx;
+        // descending order = descending key: score bits (positive floats order like integers), ties broken by the LOWER original row
+        if (keys) keys[(int64_t)b * cap + slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (0xffffffffu - (unsigned)idx);
       }
     }
   };
-  const int stride = gridDim.x * blockDim.x;
-  const int first = blockIdx.x * blockDim.x + threadIdx.x;
-  for (int a0 = first - lane; a0 < A; a0 += stride) {              // (whole waves iterate together: the ballots need every lane)
-    const int a = a0 + lane;
-    const bool in = a < A;
-    const int64_t row = ((int64_t)b * A + (in ? a : 0)) * no;
-    const float obj = ldp(pred, row + 4, dt);
+  // a workgroup takes 256 consecutive rows (256 * no elements, contiguous) per pass: 16-byte loads into LDS, then every thread reads its
+  // own row from there (a row is 15 halves = 30 bytes: per-thread element loads were 2-byte accesses 30 bytes apart, 29 us for 129 k rows)
+  extern __shared__ __attribute__((aligned(16))) char frow[];
+  const int es = hf ? 2 : 4;
+  const int64_t img = (int64_t)b * A * no;
+  for (int r0 = blockIdx.x * 256; r0 < A; r0 += gridDim.x * 256) {
+    const int nrow = A - r0 < 256 ? A - r0 : 256;
+    const int64_t byte0 = (img + (int64_t)r0 * no) * es;            // first byte of the pass; the prediction base is 16-byte aligned (host)
+    const int64_t nbytes = (int64_t)nrow * no * es;
+    const int64_t lo = byte0 & ~15ll, hi = (byte0 + nbytes + 15) & ~15ll;       // whole 16-byte vectors; nothing past the tensor's last byte is read
+    const int shift = (int)(byte0 - lo);
+    __syncthreads();
+    for (int64_t v = lo + (int64_t)threadIdx.x * 16; v < hi; v += 256 * 16) {
+      uint4 q = uint4{0u, 0u, 0u, 0u};
+      if (v + 16 <= pred_bytes) q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(pred) + v);
+      else for (int k = 0; k < 16; ++k) if (v + k < pred_bytes) reinterpret_cast<char*>(&q)[k] = reinterpret_cast<const char*>(pred)[v + k];
+      *reinterpret_cast<uint4*>(frow + (v - lo)) = q;
+    }
+    __syncthreads();
+    const int a = r0 + threadIdx.x;
+    const bool in = threadIdx.x < nrow;
+    if (rank && in) rank[(int64_t)b * cap + a] = 0;                 // (single-label lists: cap == A, every slot is some row's index)
+    const char* rowp = frow + shift + (int64_t)(in ? threadIdx.x : 0) * no * es;
+    auto ld = [&](int k) -> float { return hf ? (float)reinterpret_cast<const half_t*>(rowp)[k] : reinterpret_cast<const float*>(rowp)[k]; };
+    const float obj = ld(4);
     const bool live = in && obj > conf;
-    if (!__ballot(live)) continue;
-    const float x = ldp(pred, row, dt), y = ldp(pred, row + 1, dt), w = ldp(pred, row + 2, dt), h = ldp(pred, row + 3, dt);
+    const float x = ld(0), y = ld(1), w = ld(2), h = ld(3);
     const float hw = rh(w / 2), hh = rh(h / 2);
     const float x1 = rh(x - hw), y1 = rh(y - hh), x2 = rh(x + hw), y2 = rh(y + hh);
     if (multi && nc > 1) {
       for (int j = 0; j < nc; ++j) {
-        const float s = rh(ldp(pred, row + 5 + j, dt) * obj);
+        const float s = rh(ld(5 + j) * obj);
         append(live && s > conf && (!class_mask || ((class_mask >> j) & 1ull)), x1, y1, x2, y2, s, j, a * nc + j);
       }
     } else {
       float best = -INFINITY; int bj = 0;
       for (int j = 0; j < nc; ++j) {
-        const float s = rh(ldp(pred, row + 5 + j, dt) * obj);
+        const float s = rh(ld(5 + j) * obj);
         if (s > best) { best = s; bj = j; }                        // first maximum (torch.max)
       }
       append(live && best > conf && (!class_mask || ((class_mask >> bj) & 1ull)), x1, y1, x2, y2, best, bj, a);
@@ -238,7 +269,7 @@ struct KeptBox { f4_t box; float area; int next; int pos; int pad; };     // 32 
 //    (checked here over all candidates; otherwise every box goes to bucket 0 and the walk is exhaustive, like the reference's arithmetic).
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* counts, const float* cand, const int* cand_idx,
                                                                 float* sorted, int cap, int max_nms, int max_det, float iou_thr,
-                                                                float max_wh, int agnostic, int lds_sort, float* out, int* nkeep) {
+                                                                float max_wh, int agnostic, int lds_sort, float* out, int* nkeep, int dbg, int skip_short) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f4_t* lbox = reinterpret_cast<f4_t*>(smem);                                              // [LDS_BOXES] offset boxes (after the sort)
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);                  // [SORT_MAX]  (before)
@@ -252,6 +283,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
   const int b = blockIdx.x;
   int m = counts[b];
   if (m > cap) m = cap;
+  if (skip_short && m <= SORT_MAX) return;                          // (the matrix path has this image)
   const bool sort_here = lds_sort && m <= SORT_MAX;
   const float* cb = cand + (int64_t)b * cap * 6;
   float* sb = sorted + (int64_t)b * max_nms * 6;
@@ -332,7 +364,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
     const float o = r[5] * off;
     return f4_t{r[0] + o, r[1] + o, r[2] + o, r[3] + o};
   };
-  const int words = (m + 63) >> 6;
+  const int words = (dbg & 1) ? 0 : (m + 63) >> 6;      // dbg: profiling only (1 sort only, 2 no keep-list walk, 4 no triangle, 8 no resolve)
   int total = 0;
   for (int c = 0; c < words; ++c) {
     const int base = c << 6;
@@ -346,7 +378,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
       bkt = base + lane < LDS_BOXES ? (int)lcls[base + lane] : (((int)*(const volatile float*)(sb + (int64_t)(base + lane) * 6 + 5)) & (NBKT - 1));
     // (a) this chunk against the keep list so far: wave wv walks chain (bucket, wv); one ballot = the wave's removed word
     bool dead = false;
-    int k = valid ? khead[bkt * SCAN_WAVES + wv] : NIL;
+    int k = (valid && !(dbg & 2)) ? khead[bkt * SCAN_WAVES + wv] : NIL;
     while (__ballot(k != NIL)) {
       const bool act = k != NIL;
       const KeptBox kb = kept[act ? k : 0];
@@ -361,7 +393,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
     for (int r = 0; r < 64 / SCAN_WAVES; ++r) {
       const int i = wv * (64 / SCAN_WAVES) + r;
       unsigned long long rw = 0ull;
-      if (i < lim) {
+      if (i < lim && !(dbg & 4)) {
         const f4_t bi = obox(base + i);
         rw = __ballot(iou_gt(bi, box_area(bi), bj, aj, iou_thr) && valid && lane > i);
       }
@@ -380,6 +412,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
                                (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((unsigned int)remv);
       unsigned long long keepbits = 0ull;
       int budget = max_det - total;
+      if (dbg & 8) rem = ~0ull;
       while (~rem != 0ull && budget > 0) {
         const int i = __ffsll((long long)~rem) - 1;
         keepbits |= 1ull << i;
@@ -416,12 +449,208 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
   if (tid == 0) nkeep[b] = total;
 }
 
+
+// ---- SHORT lists (detect.py: <= 8192 candidates): the pair tests leave the sequential walk altogether ---------------------------
+//   rank2   : descending rank of every candidate, the whole device: [i block] x [j slice] workgroups count keys greater than their own
+//             (keys are unique), partial counts meet in one atomicAdd per (candidate, slice)
+//   scatter : candidates to their sorted slot (general.py:487-488 truncation) + the class-offset boxes (491-492)
+//   mask    : the suppression bit matrix, upper triangle, one 64 x 64 tile per wave and pass: bit j of word (row, cc) = IoU(row, cc*64+j) > thr
+//             -- n^2/2 pair tests spread over all CUs (7.5 k candidates: 28 M tests, ~5 us) instead of ~250 k per 64-box chunk on one CU
+//   mscan   : ONE wave per image walks the chunks with bit operations only and no barrier.  Chunk c needs (1) the OR over all kept rows
+//             of their word c: every lane gathers the words of up to MS_KR kept rows, issued MS_P chunks ahead for the keep list as it stood
+//             then; (2) the contribution of boxes kept during the last MS_P chunks: those chunks' own rows were loaded as a BAND of MS_P+1
+//             words (diagonal + the next MS_P), so a survivor's later words are readlane'd into MS_P scalar accumulators the moment it is
+//             kept; (3) the diagonal words of its own 64 rows (the band's first word).  All loads are address-predictable MS_P chunks
+//             ahead: the dependent chain per chunk is a cross-lane OR, a find-first-set loop and a few readlanes.
+constexpr int MS_P = 4;
+constexpr int MS_KR = 5;                       // kept rows gathered per lane: max_det <= 64 * MS_KR = 320 (general.py:434 uses 300)
+constexpr int MS_RS = SORT_MAX / 64 + 8;       // mask row stride in 64-bit words (the band may read MS_P words past the last chunk)
+
+__global__ __launch_bounds__(256) void nms_rank2_kernel(const int* counts, const unsigned long long* keys, int cap, int* rank) {
+  __shared__ unsigned long long sk[256];
+  const int b = blockIdx.z;
+  int n = counts[b];
+  if (n > cap) n = cap;
+  if (n > SORT_MAX || (int)blockIdx.x * 256 >= n) return;
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  const unsigned long long* kb = keys + (int64_t)b * cap;
+  const unsigned long long ki = i < n ? kb[i] : ~0ull;
+  const int per = (n + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int j0 = blockIdx.y * per, j1 = j0 + per < n ? j0 + per : n;
+  int cnt = 0;
+  for (int jt = j0; jt < j1; jt += 256) {
+    sk[tid] = jt + tid < j1 ? kb[jt + tid] : 0ull;
+    __syncthreads();
+    const int lim = j1 - jt < 256 ? j1 - jt : 256;
+    for (int q = 0; q < lim; ++q) cnt += sk[q] > ki ? 1 : 0;
+    __syncthreads();
+  }
+  if (i < n && cnt) atomicAdd(rank + (int64_t)b * cap + i, cnt);
+}
+
+__global__ __launch_bounds__(256) void nms_scatter_kernel(const int* counts, const float* cand, const int* rank, int cap, int max_nms,
+                                                          float max_wh, int agnostic, float* sorted, f4_t* obx) {
+  const int b = blockIdx.y;
+  int n = counts[b];
+  if (n > cap) n = cap;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (n > SORT_MAX || i >= n) return;
+  const int r = rank[(int64_t)b * cap + i];
+  if (r >= max_nms) return;
+  const float* c = cand + ((int64_t)b * cap + i) * 6;
+  float v[6];
+#pragma unroll
+  for (int e = 0; e < 6; ++e) v[e] = c[e];
+  float* d = sorted + ((int64_t)b * max_nms + r) * 6;
+#pragma unroll
+  for (int e = 0; e < 6; ++e) d[e] = v[e];
+  const float o = v[5] * (agnostic ? 0.f : max_wh);               // class offset (general.py:491-492), fp32 like the reference
+  obx[(int64_t)b * SORT_MAX + r] = f4_t{v[0] + o, v[1] + o, v[2] + o, v[3] + o};
+}
+
+__device__ __forceinline__ float rl_f(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
+__device__ __forceinline__ unsigned long long rl_u64(unsigned long long v, int i) {
+  return ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), i) << 32) |
+         (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, i);
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(const int* counts, const f4_t* obx, unsigned long long* mask, int cap, int max_nms,
+                                                       float thr) {
+  const int b = blockIdx.y;
+  int m = counts[b];
+  if (m > cap) m = cap;
+  if (m > SORT_MAX) return;
+  if (m > max_nms) m = max_nms;
+  const int words = (m + 63) >> 6;
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nw = gridDim.x * 4;
+  const f4_t* ob = obx + (int64_t)b * SORT_MAX;
+  unsigned long long* M = mask + (int64_t)b * SORT_MAX * MS_RS;
+  const f4_t zero = f4_t{0.f, 0.f, 0.f, 0.f};
+  for (int t = gw; t < words * words; t += nw) {
+    const int rc = t / words, cc = t - rc * words;
+    if (cc < rc) continue;                                          // upper triangle: later boxes only
+    const int row = rc * 64 + lane, col = cc * 64 + lane;
+    const f4_t bi = row < m ? ob[row] : zero;
+    const f4_t bc = col < m ? ob[col] : zero;                       // lane j holds column box j (a zero box overlaps nothing)
+    const float ai = box_area(bi), ac = box_area(bc);
+    unsigned long long w = 0ull;
+    for (int j = 0; j < 64; ++j) {
+      const f4_t bj = f4_t{rl_f(bc[0], j), rl_f(bc[1], j), rl_f(bc[2], j), rl_f(bc[3], j)};
+      if (iou_gt(bi, ai, bj, rl_f(ac, j), thr)) w |= 1ull << j;
+    }
+    if (cc == rc) w &= lane < 63 ? ~0ull << (lane + 1) : 0ull;      // the diagonal tile: strictly later boxes
+    if (row < m) M[(int64_t)row * MS_RS + cc] = w;
+  }
+}
+
+// OR over the 64 lanes, result wave-uniform (scalar): four DPP row rotations leave every lane with the OR of its 16-lane row, four
+// readlanes + scalar ORs combine the rows (a __shfl_xor butterfly is 12 dependent LDS-crossbar permutes: ~0.25 us per chunk)
+__device__ __forceinline__ unsigned int row_or32(unsigned int v) {
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);     // row_ror:1
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);     // row_ror:2
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);     // row_ror:4
+  v |= (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);     // row_ror:8
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
+  const unsigned int lo = row_or32((unsigned int)v), hi = row_or32((unsigned int)(v >> 32));
+  unsigned int slo = 0, shi = 0;
+#pragma unroll
+  for (int r = 0; r < 64; r += 16) {
+    slo |= (unsigned int)__builtin_amdgcn_readlane((int)lo, r);
+    shi |= (unsigned int)__builtin_amdgcn_readlane((int)hi, r);
+  }
+  return ((unsigned long long)shi << 32) | slo;
+}
+typedef __attribute__((address_space(1))) unsigned long long g_u64_t;
+__device__ __forceinline__ unsigned long long ldg_u64(const unsigned long long* p) { return *(const g_u64_t*)p; }
+
+__global__ __launch_bounds__(64) void nms_mscan_kernel(const int* counts, const float* sorted, const unsigned long long* mask, int cap,
+                                                       int max_nms, int max_det, float* out, int* nkeep) {
+  __shared__ int kpos[MS_KR * 64];
+  const int b = blockIdx.x, lane = threadIdx.x;
+  int m = counts[b];
+  if (m > cap) m = cap;
+  if (m > SORT_MAX) return;                                         // the lazy kernel owns longer lists
+  if (m > max_nms) m = max_nms;
+  const unsigned long long* M = mask + (int64_t)b * SORT_MAX * MS_RS;
+  const float* sb = sorted + (int64_t)b * max_nms * 6;
+  const int words = (m + 63) >> 6;
+  unsigned long long G[MS_P][MS_KR], B[MS_P][MS_P + 1], near[MS_P];
+  int total = 0;
+  auto issue = [&](int c, unsigned long long* g, unsigned long long* bd, int tot) {
+    int row = c * 64 + lane;
+    if (row > SORT_MAX - 1) row = SORT_MAX - 1;                     // (past the list: any in-bounds row, the words are never used)
+    const unsigned long long* rp = M + (int64_t)row * MS_RS + c;
+#pragma unroll
+    for (int d = 0; d <= MS_P; ++d) bd[d] = ldg_u64(rp + d);
+#pragma unroll
+    for (int r = 0; r < MS_KR; ++r) {
+      const int t = lane + 64 * r;
+      const bool ok = t < tot;
+      const int k = kpos[ok ? t : 0];
+      g[r] = ldg_u64(ok ? M + (int64_t)k * MS_RS + c : reinterpret_cast<const unsigned long long*>(zero_page()));
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < MS_P; ++s) { issue(s, G[s], B[s], 0); near[s] = 0ull; }
+  bool done = false;
+  for (int c0 = 0; c0 < words && !done; c0 += MS_P) {
+#pragma unroll
+    for (int s = 0; s < MS_P; ++s) {
+      const int c = c0 + s;
+      if (c >= words || done) continue;                             // uniform
+      const int lim = m - c * 64 < 64 ? m - c * 64 : 64;
+      const unsigned long long limmask = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+      unsigned long long g = G[s][0];
+#pragma unroll
+      for (int r = 1; r < MS_KR; ++r) g |= G[s][r];
+      unsigned long long rem = wave_or64(g) | near[s] | ~limmask;
+      unsigned long long nacc[MS_P];
+#pragma unroll
+      for (int d = 0; d < MS_P; ++d) nacc[d] = 0ull;
+      unsigned long long keepbits = 0ull;
+      int budget = max_det - total;
+      while (~rem != 0ull && budget > 0) {
+        const int i = __ffsll((long long)~rem) - 1;
+        keepbits |= 1ull << i;
+        --budget;
+        rem |= rl_u64(B[s][0], i) | (1ull << i);
+#pragma unroll
+        for (int d = 0; d < MS_P; ++d) nacc[d] |= rl_u64(B[s][d + 1], i);            // this survivor's words c+1 .. c+MS_P
+      }
+      // word c+d joins accumulator (s+d) % MS_P; d = MS_P re-uses this chunk's own (consumed) accumulator
+#pragma unroll
+      for (int d = 1; d < MS_P; ++d) near[(s + d) % MS_P] |= nacc[d - 1];
+      near[s] = nacc[MS_P - 1];
+      if ((keepbits >> lane) & 1ull) kpos[total + __popcll(keepbits & ((1ull << lane) - 1ull))] = c * 64 + lane;
+      total += __popcll(keepbits);
+      if (total >= max_det) { done = true; continue; }
+      issue(c + MS_P, G[s], B[s], total);
+    }
+  }
+  // the kept rows, in keep order (= descending score): x1, y1, x2, y2, conf, cls as the filter wrote them
+  for (int e = lane; e < total * 6; e += 64) {
+    const int k = e / 6, q = e - k * 6;
+    out[((int64_t)b * max_det + k) * 6 + q] = sb[(int64_t)kpos[k] * 6 + q];
+  }
+  if (lane == 0) nkeep[b] = total;
+}
+
 }  // namespace
+
+int g_nms_dbg = 0;      // myolo_set_option("nms_dbg", bits): profiling only
+
+extern "C" int64_t myolo_nms_ws_bytes(int batch, int cap) {
+  if (batch < 1 || cap < 1) return 0;
+  return (int64_t)batch * ((int64_t)SORT_MAX * 16 + (int64_t)SORT_MAX * MS_RS * 8 + (int64_t)cap * 8 + (int64_t)cap * 4);
+}
 
 extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres,
                          int multi_label, int agnostic, float max_wh, int max_nms, int max_det, int cap, int32_t* counts,
                          float* cand, int32_t* cand_idx, float* sorted, float* out, int32_t* nkeep, uint64_t class_mask,
-                         int32_t* sort_ws, void* stream) {
+                         int32_t* sort_ws, void* mws, int64_t mws_bytes, void* stream) {
   if (class_mask && no - 5 > 64) return MYOLO_EINVAL;
   if (!pred || (dtype != MYOLO_F16 && dtype != MYOLO_F32) || batch < 1 || A < 1 || no < 6 || cap < 1 || max_det < 1 ||
       max_det > KEPT_MAX || max_nms < 1 || max_nms > MAX_SORTED || !counts || !cand || !cand_idx || !sorted || !out || !nkeep)
@@ -430,9 +659,27 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(counts, 0, batch * sizeof(int32_t), st);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), 0, st, pred, dtype, A, no, conf_thres,
-                     multi_label, cap, counts, cand, cand_idx, class_mask);
-  // short single-label lists are ordered inside the scan kernel (original rows must fit the key's 19 bits)
+  // lists of up to SORT_MAX candidates (single label, cap == A): rank / scatter / bit matrix on the whole device + the one-wave scan
+  const bool matrix = !sort_ws && mws && !((uintptr_t)mws & 15) && mws_bytes >= myolo_nms_ws_bytes(batch, cap) && cap == A &&
+                      max_det <= 64 * MS_KR && !(g_nms_dbg & 16);
+  f4_t* obx = reinterpret_cast<f4_t*>(mws);
+  unsigned long long* mask = matrix ? reinterpret_cast<unsigned long long*>(obx + (int64_t)batch * SORT_MAX) : nullptr;
+  unsigned long long* keys = matrix ? mask + (int64_t)batch * SORT_MAX * MS_RS : nullptr;
+  int* rank = matrix ? reinterpret_cast<int*>(keys + (int64_t)batch * cap) : nullptr;
+  const int es = dtype == MYOLO_F16 ? 2 : 4;
+  const int filter_smem = 256 * no * es + 32;
+  if (((uintptr_t)pred & 15) || filter_smem > 64 * 1024) return MYOLO_EINVAL;
+  hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), filter_smem, st, pred, dtype, A, no, conf_thres,
+                     multi_label, cap, counts, cand, cand_idx, class_mask, keys, rank, (int64_t)batch * A * no * es);
+  if (matrix) {
+    hipLaunchKernelGGL(nms_rank2_kernel, dim3(SORT_MAX / 256, 16, batch), dim3(256), 0, st, counts, keys, cap, rank);
+    hipLaunchKernelGGL(nms_scatter_kernel, dim3(SORT_MAX / 256, batch), dim3(256), 0, st, counts, cand, rank, cap, max_nms, max_wh,
+                       agnostic, sorted, obx);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(1024, batch), dim3(256), 0, st, counts, obx, mask, cap, max_nms, iou_thres);
+    hipLaunchKernelGGL(nms_mscan_kernel, dim3(batch), dim3(64), 0, st, counts, sorted, mask, cap, max_nms, max_det, out, nkeep);
+  }
+  // longer lists (and callers without the matrix workspace): the lazy scan; it orders lists of up to SORT_MAX candidates itself
+  // (original rows must fit the key's 19 bits)
   const int lds_sort = (!sort_ws && (int64_t)cap <= (1ll << IDX_BITS)) ? 1 : 0;
   if (sort_ws) {             // long lists: counting sort; sort_ws = int32 [batch][3*65536 + cap]
     int* hist = sort_ws;
@@ -448,7 +695,7 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
     hipLaunchKernelGGL(nms_place_kernel, dim3(gx, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, start, hist, order, max_nms, sorted);
   } else {
     hipLaunchKernelGGL(nms_rank_kernel, dim3((cap + 255) / 256, batch), dim3(256), 0, st, counts, cand, cand_idx, cap, max_nms, sorted,
-                       lds_sort);
+                       lds_sort | (matrix ? 1 : 0));
   }
   const int scan_smem = LDS_BOXES * 16 + KEPT_MAX * (int)sizeof(KeptBox) + SCAN_WAVES * 8 + 64 * 8 + NBKT * SCAN_WAVES * 2 + 2 * SCAN_WAVES * 4 + LDS_BOXES;
   static_assert(SORT_MAX * 8 <= LDS_BOXES * 16, "the sort keys live in the box cache's LDS");
@@ -459,7 +706,7 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
     attr_set = true;
   }
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), scan_smem, st, counts, cand, cand_idx, sorted, cap, max_nms,
-                     max_det, iou_thres, max_wh, agnostic, lds_sort, out, nkeep);
+                     max_det, iou_thres, max_wh, agnostic, lds_sort, out, nkeep, g_nms_dbg, matrix ? 1 : 0);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

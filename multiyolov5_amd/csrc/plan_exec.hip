@@ -1,0 +1,154 @@
+// Native executor of a static launch plan: ONE C call walks a serialised launch list (the forward or the backward of a
+// multiyolov5_amd.engine.Plan: ~330 + ~340 libmyolo launches for yolov5s+PSP) instead of one ctypes call per launch from Python
+// (round 2: 8.0 ms of host time per 9.3 ms step, DESIGN section 7 lead 0).
+//
+//   * an op is a fixed-size record: kind, function id, 8-byte argument slots (pointers, integers sign-extended, floats as their bit
+//     pattern in the low word).  The typed call is rebuilt by a per-entry-point thunk generated from the function's own signature
+//     (template over the argument pack), so the records carry no type tags and a new entry point costs one REG() line;
+//   * descriptors (myolo_conv_desc ...) are built once by the host mirror and referenced by address; the few slots that change per
+//     run (the caller's input tensors) are patched in place through myolo_prog_slot();
+//   * weight gradients fork to the side stream exactly like the Python loop did: event record on the main stream, wait on the side
+//     stream, launch there; a JOIN makes the main stream wait for the side stream.  Events are created once per program;
+//   * a run is a [first, last) range of ops, so the caller can interleave its RCCL gradient slices (parallel.GradReducer) between
+//     ranges.  Nothing here allocates, synchronises or touches the host after create: hipGraph-capturable like the launches themselves.
+//
+// Not a reference interface: the reference's forward is Python (models/yolo.py:293-316); this replaces the interpreter loop around it.
+#include "myolo_dev.h"
+#include <string.h>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+namespace {
+
+template <class T> struct Unpack {
+  static T get(uint64_t v) {
+    if constexpr (std::is_pointer<T>::value) return reinterpret_cast<T>(static_cast<uintptr_t>(v));
+    else if constexpr (std::is_same<T, float>::value) { const uint32_t b = (uint32_t)v; float f; memcpy(&f, &b, 4); return f; }
+    else return static_cast<T>(static_cast<int64_t>(v));
+  }
+};
+
+template <class... Args, size_t... I>
+int call_impl(int (*fn)(Args...), const uint64_t* a, void* st, std::index_sequence<I...>) {
+  using Tup = std::tuple<Args...>;
+  return fn(Unpack<std::tuple_element_t<I, Tup>>::get(a[I])..., st);
+}
+template <class... Args>
+int call_packed(int (*fn)(Args...), const uint64_t* a, void* st) {
+  static_assert(sizeof...(Args) >= 1 && sizeof...(Args) - 1 <= MYOLO_PROG_MAX_ARGS, "argument slots");
+  return call_impl(fn, a, st, std::make_index_sequence<sizeof...(Args) - 1>{});
+}
+
+typedef int (*thunk_t)(const uint64_t*, void*);
+struct Entry { const char* name; thunk_t fn; int nargs; };
+template <class... Args> constexpr int nargs_of(int (*)(Args...)) { return (int)sizeof...(Args) - 1; }
+
+#define REG(f) {#f, [](const uint64_t* a, void* st) -> int { return call_packed(&f, a, st); }, nargs_of(&f)}
+const Entry g_table[] = {
+    REG(myolo_pack_weight), REG(myolo_pack_weights_mt), REG(myolo_focus_pack), REG(myolo_conv), REG(myolo_conv_dgrad_s2),
+    REG(myolo_conv_wgrad), REG(myolo_bn_act_fwd), REG(myolo_bn_act_bwd_reduce), REG(myolo_bn_act_bwd_apply),
+    REG(myolo_bn_act_fwd_split), REG(myolo_bn_act_bwd_reduce_split), REG(myolo_bn_act_bwd_apply_split), REG(myolo_spp_pool_fwd),
+    REG(myolo_spp_pool_bwd), REG(myolo_copy_up_fwd), REG(myolo_copy_up_bwd), REG(myolo_bilinear_fwd), REG(myolo_bilinear_bwd),
+    REG(myolo_adaptive_avgpool_fwd), REG(myolo_adaptive_avgpool_bwd), REG(myolo_adaptive_avgpool_bwd_multi),
+    REG(myolo_pyramid_upsample_fwd), REG(myolo_pyramid_upsample_bwd), REG(myolo_gate_fwd), REG(myolo_gate_bwd),
+    REG(myolo_gate_mul_fwd), REG(myolo_gate_mul_bwd), REG(myolo_add), REG(myolo_fill_zero), REG(myolo_cast_from_f32),
+    REG(myolo_dropout_fwd), REG(myolo_dropout_bwd), REG(myolo_seg_upsample_fwd), REG(myolo_seg_upsample_bwd),
+    REG(myolo_seg_lowgrad_apply), REG(myolo_detect_unpermute), REG(myolo_detect_decode),
+};
+#undef REG
+constexpr int NFN = (int)(sizeof(g_table) / sizeof(g_table[0]));
+
+struct Prog {
+  std::vector<myolo_prog_op> ops;
+  std::vector<hipEvent_t> evs;        // one per op that needs one (FORK / JOIN), else nullptr
+  int last_op = -1;
+};
+
+}  // namespace
+
+extern "C" int myolo_prog_fn_id(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < NFN; ++i)
+    if (!strcmp(g_table[i].name, name)) return i;
+  return -1;
+}
+
+extern "C" int myolo_prog_fn_nargs(int fn) { return (fn >= 0 && fn < NFN) ? g_table[fn].nargs : -1; }
+
+extern "C" void* myolo_prog_create(const myolo_prog_op* ops, int n) {
+  if (!ops || n < 0) return nullptr;
+  for (int i = 0; i < n; ++i) {
+    const myolo_prog_op& o = ops[i];
+    if (o.kind < MYOLO_OP_CALL || o.kind > MYOLO_OP_MEMSET) return nullptr;
+    if ((o.kind == MYOLO_OP_CALL || o.kind == MYOLO_OP_CALL_SIDE) && (o.fn < 0 || o.fn >= NFN || o.nargs != g_table[o.fn].nargs)) return nullptr;
+  }
+  Prog* p = new Prog;
+  p->ops.assign(ops, ops + n);
+  p->evs.assign(n, nullptr);
+  for (int i = 0; i < n; ++i)
+    if (ops[i].kind == MYOLO_OP_CALL_SIDE || ops[i].kind == MYOLO_OP_JOIN) {
+      if (hipEventCreateWithFlags(&p->evs[i], hipEventDisableTiming) != hipSuccess) {
+        for (hipEvent_t e : p->evs) if (e) (void)hipEventDestroy(e);
+        delete p;
+        return nullptr;
+      }
+    }
+  return p;
+}
+
+extern "C" void myolo_prog_destroy(void* prog) {
+  Prog* p = static_cast<Prog*>(prog);
+  if (!p) return;
+  for (hipEvent_t e : p->evs) if (e) (void)hipEventDestroy(e);
+  delete p;
+}
+
+extern "C" uint64_t* myolo_prog_slot(void* prog, int op, int arg) {
+  Prog* p = static_cast<Prog*>(prog);
+  if (!p || op < 0 || op >= (int)p->ops.size() || arg < 0 || arg >= MYOLO_PROG_MAX_ARGS) return nullptr;
+  return &p->ops[op].a[arg];
+}
+
+extern "C" int myolo_prog_last_op(void* prog) { return prog ? static_cast<Prog*>(prog)->last_op : -1; }
+
+extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream) {
+  Prog* p = static_cast<Prog*>(prog);
+  if (!p || first < 0 || last > (int)p->ops.size() || first > last) return MYOLO_EINVAL;
+  hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+  for (int i = first; i < last; ++i) {
+    const myolo_prog_op& o = p->ops[i];
+    if (o.cond && *reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o.cond)) != o.cond_val) continue;
+    int r = 0;
+    switch (o.kind) {
+      case MYOLO_OP_CALL:
+        r = g_table[o.fn].fn(o.a, main_stream);
+        break;
+      case MYOLO_OP_CALL_SIDE:
+        if (ss) {                                   // fork: the side stream picks up behind everything enqueued on the main stream so far
+          hipError_t e = hipEventRecord(p->evs[i], ms);
+          if (e == hipSuccess) e = hipStreamWaitEvent(ss, p->evs[i], 0);
+          r = e != hipSuccess ? (int)e : g_table[o.fn].fn(o.a, side_stream);
+        } else {
+          r = g_table[o.fn].fn(o.a, main_stream);
+        }
+        break;
+      case MYOLO_OP_JOIN:
+        if (ss) {
+          hipError_t e = hipEventRecord(p->evs[i], ss);
+          if (e == hipSuccess) e = hipStreamWaitEvent(ms, p->evs[i], 0);
+          r = (int)e;
+        }
+        break;
+      case MYOLO_OP_MEMSET: {
+        const hipError_t e = hipMemsetAsync(reinterpret_cast<void*>(static_cast<uintptr_t>(o.a[0])), 0, (size_t)o.a[1], ms);
+        r = (int)e;
+        break;
+      }
+      default:
+        r = MYOLO_EINVAL;
+    }
+    if (r) { p->last_op = i; return r; }
+  }
+  return 0;
+}

@@ -9,6 +9,7 @@ hipGraph-capturable (torch.cuda.graph == hipGraph on ROCm).  There is no CPU pat
 import ctypes as C
 import math
 import os
+import struct
 
 import torch
 
@@ -27,6 +28,10 @@ GRAPH_BWD = os.environ.get('MYOLO_GRAPH_BWD', 'seg')
 WGRAD_WG = int(os.environ.get('MYOLO_WGRAD_WG_HINT', '0'))                 # 0: library default (128)
 WGRAD_WG_TAIL = int(os.environ.get('MYOLO_WGRAD_WG_TAIL', '0'))
 WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
+
+# MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
+# executor (csrc/plan_exec.hip: one C call per launch list)
+NATIVE_EXEC = os.environ.get('MYOLO_NATIVE_EXEC', '1') != '0'
 
 SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
@@ -106,11 +111,12 @@ class Call:
 class SwitchCall:
     """one of two launches, chosen when it is issued: `b` if state[key] (set by the consumer of the plan's output for this step) else
     `a`.  A captured backward graph bakes in the choice made at capture time."""
-    __slots__ = ('a', 'b', 'state', 'key', 'name', 'side', 'args', 'keep')
+    __slots__ = ('a', 'b', 'state', 'key', 'name', 'side', 'args', 'keep', 'cell')
 
     def __init__(self, a, b, state, key):
         self.a, self.b, self.state, self.key = a, b, state, key
         self.name, self.side, self.args, self.keep = a.name, False, a.args, (a, b)
+        self.cell = C.c_int32(0)          # the choice as the native executor reads it (refreshed from `state` before every run)
 
     def __call__(self, st):
         (self.b if self.state[self.key] else self.a)(st)
@@ -228,6 +234,13 @@ class ConvOp(Op):
                  weight2=None, bn2=None, bias2=None):
         """weight2 / bn2 / bias2: a SECOND Conv(+BN) of the same geometry on the same input, run in the same launches; its output
         channels follow the first one's (`out` holds c1out + c2out channels; C3.cv2 | C3.cv1, common.py:137)."""
+        for b_ in (bn, bn2):
+            if isinstance(b_, torch.nn.SyncBatchNorm):
+                # train.py:190-193 `--sync-bn`: convert_sync_batchnorm swaps the BatchNorm2d modules of the mirror for SyncBatchNorm.  The
+                # fused statistics kernels reduce over THIS GPU's batch only; running them under that name would silently train with
+                # per-GPU statistics.  (The cross-rank exchange of the per-channel sums is not built: SURVEY 8(e) lists it as optional.)
+                raise L.MyoloError('nn.SyncBatchNorm (train.py --sync-bn) is not supported by the gfx950 BatchNorm kernels: they use '
+                                   'per-GPU batch statistics (plain DistributedDataParallel semantics); drop --sync-bn')
         self.x, self.out, self.weight, self.bn, self.bias = x, out, weight, bn, bias
         self.weight2, self.bn2, self.bias2 = weight2, bn2, bias2
         self.k, self.s, self.d, self.act, self.res, self.det = k, s, d, act, res, det
@@ -835,6 +848,109 @@ class ExportOp(Op):
                                                                   self.acc, None), keep=g))
 
 
+
+def _slot_value(arg, argtype):
+    """one ctypes call argument as the 8-byte slot of a myolo_prog_op (include/myolo.h)"""
+    if arg is None:
+        return 0
+    if argtype is C.c_float:
+        v = arg.value if isinstance(arg, C.c_float) else float(arg)
+        return struct.unpack('<I', struct.pack('<f', v))[0]
+    if argtype in (C.c_int32, C.c_int64, C.c_uint64, C.c_int, C.c_long):
+        return int(arg.value if hasattr(arg, 'value') else arg) & 0xFFFFFFFFFFFFFFFF
+    if isinstance(arg, C.c_void_p):
+        return arg.value or 0
+    if hasattr(arg, '_obj'):                         # C.byref(x)
+        return C.addressof(arg._obj)
+    if isinstance(arg, (C.Array, C.Structure)):
+        return C.addressof(arg)
+    if isinstance(arg, C._Pointer):
+        return C.cast(arg, C.c_void_p).value or 0
+    if isinstance(arg, int):
+        return arg & 0xFFFFFFFFFFFFFFFF
+    raise TypeError(f'cannot serialise launch argument {arg!r}')
+
+
+class NativeProg:
+    """a launch list serialised for csrc/plan_exec.hip.  `items`: Call | SwitchCall | ('memset', tensor, nbytes) | ('join',) | ('mark',
+    key) -- a mark records the op index reached (range boundaries for the caller)."""
+
+    def __init__(self, items, mutable_cells=()):
+        lib = L.lib()
+        recs, self.names, self.marks, self.switches, self.fixups = [], [], {}, [], []
+        self.keep = []
+        mut = {id(c): c for c in mutable_cells}
+
+        def add_call(c, kind, cond=None, cond_val=0):
+            fn = lib.myolo_prog_fn_id(c.name.encode())
+            if fn < 0:
+                raise KeyError(c.name)
+            argtypes = L._PROTOS[c.name][1][:-1]
+            if len(argtypes) != len(c.args) or len(c.args) > L.PROG_MAX_ARGS:
+                raise TypeError(f'{c.name}: {len(c.args)} arguments for {len(argtypes)} parameters')
+            r = L.ProgOp()
+            r.kind, r.fn, r.nargs = kind, fn, len(c.args)
+            if cond is not None:
+                r.cond, r.cond_val = C.addressof(cond), cond_val
+            for i, (a, t) in enumerate(zip(c.args, argtypes)):
+                r.a[i] = _slot_value(a, t)
+                if id(a) in mut:
+                    self.fixups.append((len(recs), i, a, t))
+            recs.append(r)
+            self.names.append(c.name)
+            self.keep.append(c)
+
+        for it in items:
+            if isinstance(it, SwitchCall):
+                self.switches.append(it)
+                add_call(it.a, L.OP_CALL, it.cell, 0)
+                add_call(it.b, L.OP_CALL, it.cell, 1)
+            elif isinstance(it, Call):
+                add_call(it, L.OP_CALL_SIDE if it.side else L.OP_CALL)
+            elif it[0] == 'memset':
+                r = L.ProgOp()
+                r.kind = L.OP_MEMSET
+                r.a[0], r.a[1] = it[1].data_ptr(), int(it[2])
+                recs.append(r)
+                self.names.append('memset')
+                self.keep.append(it[1])
+            elif it[0] == 'join':
+                r = L.ProgOp()
+                r.kind = L.OP_JOIN
+                recs.append(r)
+                self.names.append('join')
+            elif it[0] == 'mark':
+                self.marks[it[1]] = len(recs)
+            else:
+                raise TypeError(it)
+        self.n = len(recs)
+        arr = (L.ProgOp * max(self.n, 1))(*recs)
+        self.handle = lib.myolo_prog_create(arr, self.n)
+        if not self.handle:
+            raise L.MyoloError('myolo_prog_create rejected the launch program')
+        self.slots = [(lib.myolo_prog_slot(self.handle, op, i), cell, t) for op, i, cell, t in self.fixups]
+        self._lib = lib
+
+    def run(self, first=0, last=None, side=None):
+        for sw in self.switches:
+            sw.cell.value = 1 if sw.state[sw.key] else 0
+        for slot, cell, t in self.slots:                          # caller tensors re-bound for this run
+            slot[0] = _slot_value(cell, t)
+        last = self.n if last is None else last
+        st = torch.cuda.current_stream().cuda_stream
+        e = self._lib.myolo_prog_run(self.handle, first, last, st, side)
+        if e:
+            i = self._lib.myolo_prog_last_op(self.handle)
+            L.check(e, self.names[i] if 0 <= i < self.n else 'myolo_prog_run')
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self._lib.myolo_prog_destroy(self.handle)
+        except Exception:   # noqa: BLE001 -- interpreter shutdown
+            pass
+
+
 class Plan:
     """A built forward (+backward) launch plan for one (module, input shapes, dtype, mode)."""
 
@@ -1042,6 +1158,7 @@ class Plan:
         if self._pack_call is not None and self._pack_key != tuple((j[0].data_ptr(), j[8].data_ptr() if j[8] is not None else 0) for j in self._pack_jobs):
             self._build_pack_table()                          # a parameter was re-allocated (.to(), load): new table, new graphs
             self.__dict__.pop('_graphs', None)
+            self.__dict__.pop('_nprog_fwd', None)
 
     def _fwd_lists(self):
         """(ops reading caller tensors -> eager, every other op -> graph)"""
@@ -1060,11 +1177,36 @@ class Plan:
     def graphable(self):
         return GRAPH_TRAIN and self.training and torch.device(self.device).type == 'cuda'
 
+    def native_ok(self):
+        return NATIVE_EXEC and torch.device(self.device).type == 'cuda' and os.environ.get('MYOLO_DBG_SKIP_WGRAD', '0') != '1'
+
+    def _native_fwd(self):
+        """the forward launch list as a native program (None: an entry point outside the executor's table -> the Python loop)"""
+        np_ = self.__dict__.get('_nprog_fwd')
+        if np_ is None:
+            items = []
+            if self._used[0]:
+                items.append(('memset', self._arena[0], self._used[0] * 4))
+            if self._pack_call is not None:
+                items.append(self._pack_call)
+            for op in self.ops:
+                items += list(op.fwd_calls)
+            try:
+                np_ = NativeProg(items, list(self.in_ptr) + list(getattr(self, 'mutable_cells', ())))
+            except KeyError:
+                np_ = False
+            self._nprog_fwd = np_
+        return np_ or None
+
     def run_fwd(self):
         st = L.stream_ptr()
         self._check_pack_table()
         if not self.graphable():
-            self._fwd_body(st, self.ops)
+            np_ = self._native_fwd() if self.native_ok() else None
+            if np_ is not None:
+                np_.run()
+            else:
+                self._fwd_body(st, self.ops)
             return
         g = self.__dict__.setdefault('_graphs', {'warm': 0})
         eager, rest = self._fwd_lists()
@@ -1188,9 +1330,50 @@ class Plan:
             g['failed'] = True
             return False
 
+    def _native_bwd(self, reducer):
+        """the backward launch list as a native program, cut at the gradient-slice boundaries of `reducer`"""
+        cache = self.__dict__.setdefault('_nprog_bwd', {})
+        key = id(reducer)
+        if key not in cache:
+            items = []
+            if self._used[1]:
+                items.append(('memset', self._arena[1], self._used[1] * 4))
+            items.append(('memset', self.flat_grad, self.flat_grad.numel() * 4))
+            segs = self._bwd_segments(reducer)
+            for si, (hi, lo, ready) in enumerate(segs):
+                for i in range(hi - 1, lo - 1, -1):
+                    items += list(self.ops[i].bwd_calls)
+                if ready:
+                    items.append(('join',))
+                items.append(('mark', si))
+            items.append(('join',))
+            try:
+                cache[key] = NativeProg(items)
+            except KeyError:
+                cache[key] = False
+        return cache[key] or None
+
+    def _bwd_native(self, np_, reducer):
+        side = self._side_stream().cuda_stream if self.use_side_stream else None
+        first = 0
+        for si, (hi, lo, ready) in enumerate(self._bwd_segments(reducer)):
+            if ready:                                         # every kernel writing into these slices has been enqueued (and joined)
+                np_.run(first, np_.marks[si], side)
+                first = np_.marks[si]
+                for a, b in ready:
+                    reducer.reduce_slice(self.flat_grad, a, b)
+        np_.run(first, np_.n, side)
+        if reducer is not None:
+            reducer.finish(self.flat_grad)
+
     def _bwd_eager(self, reducer):
         """the backward launch list call by call on the CURRENT stream (also the body of the 'fork' capture): weight-gradient launches
         are forked to the side stream behind an event each, gradient slices go to the reducer as soon as they are final"""
+        if self.native_ok() and self.flat_grad.is_cuda and not torch.cuda.is_current_stream_capturing():
+            np_ = self._native_bwd(reducer)
+            if np_ is not None:
+                self._bwd_native(np_, reducer)
+                return
         cuda = self.flat_grad.is_cuda
         main = torch.cuda.current_stream() if cuda else None
         side = self._side_stream() if (cuda and self.use_side_stream) else None
@@ -1323,6 +1506,7 @@ class DecodeOp(Op):
             sd = C.c_float(0.0)
             self.anch.append(wh)
             self.strd.append(sd)
+            plan.__dict__.setdefault('mutable_cells', []).append(sd)   # (a launch-time HOST value: re-read by the native executor per run)
             self.fwd_calls.append(Call('myolo_detect_decode', (L.ptr(c.det_out), L.DT[plan.dtype], n, na, c.out.h, c.out.w, no,
                                                                sd, wh, L.ptr(self.z), a_total, row0)))
             row0 += rows[i]

@@ -21,6 +21,7 @@ class GradReducer:
         self.nbuckets = max(1, int(nbuckets))
         self.stream = None
         self._works = []
+        self.exposed = None            # bench.py: [(event before, event after)] around the main stream's wait for the exchange
         model.__dict__['_grad_reducer'] = self         # consulted by runtime.PlanFn.backward
 
     # ---- bucket layout (called once per plan) ---------------------------------------------------------
@@ -76,6 +77,13 @@ class GradReducer:
             for w in self._works:
                 w.wait()
         self._works = []
+        if self.exposed is not None:   # how long the main stream sits in this wait = the part of the exchange the backward did not hide
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            e1.record()
+            self.exposed.append((e0, e1))
+            return
         torch.cuda.current_stream().wait_stream(self.stream)
 
     def wait(self):

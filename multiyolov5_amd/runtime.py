@@ -143,6 +143,15 @@ class PlanFn(torch.autograd.Function):
         plan.run_fwd()
         plan.capture_bwd(holder.module.__dict__.get('_grad_reducer'))      # no-op until the forward graph exists / once captured
         holder.generation += 1                       # activations / BN statistics / dropout masks of this forward
+        outs = PlanFn._wrap_outputs(holder)
+        for sc in plan.output_scales.values():        # (a fused low-resolution CE of an earlier forward that never ran its backward)
+            sc[1]['low'] = False
+        ctx.generation = holder.generation
+        holder.pending_bwd = True
+        return outs
+
+    @staticmethod
+    def _wrap_outputs(holder):
         outs = []
         for o in holder.output_tensors():
             d = o.detach()
@@ -154,12 +163,7 @@ class PlanFn(torch.autograd.Function):
                 if hasattr(o, attr):
                     setattr(d, attr, getattr(o, attr))
             outs.append(d)
-        outs = tuple(outs)
-        for sc in plan.output_scales.values():        # (a fused low-resolution CE of an earlier forward that never ran its backward)
-            sc[1]['low'] = False
-        ctx.generation = holder.generation
-        holder.pending_bwd = True
-        return outs
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
@@ -168,6 +172,13 @@ class PlanFn(torch.autograd.Function):
         if not holder.pending_bwd or ctx.generation != holder.generation:
             raise L.MyoloError('backward through a plan whose activations were overwritten by a newer forward '
                                '(one outstanding forward per module/shape; call backward before the next forward)')
+        PlanFn._take_output_grads(holder, plan, grads)
+        plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
+        return PlanFn._finish_backward(holder, plan)
+
+    @staticmethod
+    def _take_output_grads(holder, plan, grads):
+        """the incoming output gradients -> the plan's gradient buffers (the fused losses already wrote theirs in place)"""
         for s, g in enumerate(grads):
             dst = holder.output_grad_tensor(s)
             sc = plan.output_scales.get(s)
@@ -188,7 +199,9 @@ class PlanFn(torch.autograd.Function):
                 elif state['dirty']:
                     scale.fill_(1.0)
                     state['dirty'] = False
-        plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
+
+    @staticmethod
+    def _finish_backward(holder, plan):
         for sc in plan.output_scales.values():
             sc[1]['low'] = False
         holder.pending_bwd = False
@@ -214,6 +227,156 @@ class PlanFn(torch.autograd.Function):
             off += n
         holder._accum_buf = flat
         return (None, *in_grads, *pg)
+
+
+
+# ---- the backward as a CHAIN of autograd nodes -------------------------------------------------------------------------------
+# train.py:243-245 wraps the model in stock DistributedDataParallel: its reducer learns that a gradient is final from the
+# AccumulateGrad hook of the parameter.  With ONE autograd node for the whole plan every hook fires after the last backward launch
+# and the all-reduce of 31 MB starts when nothing is left to overlap it with.  Here the plan's backward launch list is cut
+# at the same bucket boundaries parallel.GradReducer uses (parameters in backward-completion order, 3 slices of the flat gradient
+# buffer): stage 0 runs the forward and, in backward, the launches that complete slice 0 (Detect / segmentation head / neck), hands
+# those parameter gradients to autograd -- whose engine runs their AccumulateGrad nodes (DDP's hooks: bucket ready -> all-reduce on
+# DDP's stream) BEFORE the next node -- then stage 1 runs the next piece of the launch list, and so on.  The stages are chained through
+# a dummy token tensor; the model inputs hang on the LAST stage (their gradient is complete when the whole list has run).
+STAGED_BWD = _os_env_flag('MYOLO_STAGED_BWD', True)
+STAGES = 3
+
+
+class StageCuts:
+    """bucket layout of the flat gradient buffer without an exchange of its own (stock DDP / single GPU): parallel.GradReducer's rule"""
+    world = 1
+
+    def __init__(self, nbuckets=STAGES):
+        self.nbuckets = nbuckets
+
+    def layout(self, sizes, first_op):
+        from .parallel import GradReducer
+        return GradReducer.layout(self, sizes, first_op)
+
+    def reduce_slice(self, flat, lo, hi):
+        return
+
+    def finish(self, flat):
+        return
+
+
+def _stage_plan(holder):
+    """[(param index range, [flat slices], program op range)] per stage for this holder's plan, or None when the staged form does not
+    apply (no native executor, a single bucket)"""
+    plan = holder.plan
+    if not (STAGED_BWD and plan.training and plan.native_ok() and not plan.graphable()):
+        return None
+    red = holder.module.__dict__.get('_grad_reducer')
+    cuts = red if red is not None else holder.__dict__.setdefault('_stage_cuts', StageCuts())
+    key = id(cuts)
+    st = holder.__dict__.get('_stages')
+    if st is not None and st[0] == key:
+        return st[1]
+    stages = None
+    if plan.flat_grad.is_cuda:
+        np_ = plan._native_bwd(cuts)
+        if np_ is not None:
+            offs, off = [], 0
+            for p in plan.params:
+                offs.append(off)
+                off += p.numel()
+            stages, first = [], 0
+            segs = plan._bwd_segments(cuts)
+            pend = []
+            for si, (hi, lo, ready) in enumerate(segs):
+                pend += ready
+                last = si == len(segs) - 1
+                if ready and not last:
+                    stages.append({'ops': (first, np_.marks[si]), 'slices': list(pend)})
+                    first, pend = np_.marks[si], []
+                elif last:
+                    stages.append({'ops': (first, np_.n), 'slices': list(pend)})
+            for sg in stages:
+                sg['params'] = [i for i, o in enumerate(offs) if any(a <= o < b for a, b in sg['slices'])]
+            covered = sorted(i for sg in stages for i in sg['params'])
+            if len(stages) < 2 or covered != [i for i in range(len(plan.params)) if plan.params[i].numel() > 0]:
+                stages = None
+            else:
+                holder._stage_prog, holder._stage_cut_obj = np_, cuts
+    holder._stages = (key, stages)
+    return stages
+
+
+class PlanStageFn(torch.autograd.Function):
+    """stage k of a plan's backward chain (k = 0: also the forward).  forward(holder, k, nstage, token | model inputs..., params of the stage)"""
+
+    @staticmethod
+    def forward(ctx, holder, k, nstage, n_lead, *args):
+        ctx.holder, ctx.k, ctx.nstage, ctx.n_lead = holder, k, nstage, n_lead
+        ctx.set_materialize_grads(False)
+        plan = holder.plan
+        if k == nstage - 1:                           # the deepest stage sees the model inputs
+            holder.bind_inputs(args[:n_lead])
+        if k > 0:
+            return torch.zeros((), device=plan.device)                      # the token
+        plan.run_fwd()
+        holder.generation += 1
+        outs = PlanFn._wrap_outputs(holder)
+        for sc in plan.output_scales.values():
+            sc[1]['low'] = False
+        ctx.generation = holder.generation
+        holder.pending_bwd = True
+        return outs
+
+    @staticmethod
+    def backward(ctx, *grads):
+        holder, k, nstage = ctx.holder, ctx.k, ctx.nstage
+        plan = holder.plan
+        stages = holder._stages[1]
+        sg = stages[k]
+        np_, cuts = holder._stage_prog, holder._stage_cut_obj
+        red = cuts if hasattr(cuts, 'stream') else None                      # a parallel.GradReducer (else StageCuts: nothing to exchange)
+        if k == 0:
+            if not holder.pending_bwd or ctx.generation != holder.generation:
+                raise L.MyoloError('backward through a plan whose activations were overwritten by a newer forward '
+                                   '(one outstanding forward per module/shape; call backward before the next forward)')
+            PlanFn._take_output_grads(holder, plan, grads)
+            holder._bwd_accumulate = _accumulate_in_place(holder, plan)
+            if not holder._bwd_accumulate:
+                flat = holder.__dict__.get('_accum_buf')
+                if flat is None or torch._C._storage_Use_Count(flat.untyped_storage()._cdata) > 2:
+                    flat = torch.empty_like(plan.flat_grad)
+                holder._accum_buf = flat
+        side = plan._side_stream().cuda_stream if plan.use_side_stream else None
+        np_.run(sg['ops'][0], sg['ops'][1], side)
+        last = k == nstage - 1
+        acc = holder._bwd_accumulate
+        flat = holder._accum_buf
+        for a, b in sg['slices']:
+            if acc:
+                if red is not None:
+                    red.reduce_slice(plan.flat_grad, a, b)
+            else:
+                flat[a:b].copy_(plan.flat_grad[a:b])
+                if red is not None:
+                    red.reduce_slice(flat, a, b)
+        if last:
+            if red is not None:
+                red.finish(plan.flat_grad if acc else flat)
+            if acc:
+                flat.add_(plan.flat_grad)
+            for sc in plan.output_scales.values():
+                sc[1]['low'] = False
+            holder.pending_bwd = False
+        lead = [None] * ctx.n_lead
+        if last:
+            lead = [plan.input_grads.get(i) if holder.in_requires_grad[i] else None for i in range(holder.n_in)]
+        elif ctx.n_lead:
+            lead = [torch.zeros((), device=plan.device)]                     # the next stage's token: runs that node
+        if acc:
+            pg = [None] * len(sg['params'])
+        else:
+            pg, offs = [], holder._param_offsets()
+            for i in sg['params']:
+                p = plan.params[i]
+                pg.append(flat[offs[i]:offs[i] + p.numel()].view(p.shape) if p.requires_grad else None)
+        return (None, None, None, None, *lead, *pg)
 
 
 FLAT_ACCUMULATE = _os_env_flag('MYOLO_FLAT_ACCUMULATE', True)
@@ -334,6 +497,16 @@ class PlanHolder:
                 outs.append(self.plan.outputs[s])
         return outs
 
+    def _param_offsets(self):
+        offs = self.__dict__.get('_poffs')
+        if offs is None:
+            offs, off = [], 0
+            for p in self.plan.params:
+                offs.append(off)
+                off += p.numel()
+            self._poffs = offs
+        return offs
+
     def output_grad_tensor(self, s):
         if s in self.ospec.det_slots:
             return self.ospec.det_slots[s].gdet
@@ -407,7 +580,15 @@ class PlannedModule(nn.Module):
         spec = _flatten(x, tensors)
         h, grad = self._holder(tensors, spec)
         if grad:
-            outs = PlanFn.apply(h, *tensors, *h.plan.params)
+            stages = _stage_plan(h)
+            if stages is None:
+                outs = PlanFn.apply(h, *tensors, *h.plan.params)
+            else:
+                n, params = len(stages), h.plan.params
+                tok = PlanStageFn.apply(h, n - 1, n, len(tensors), *tensors, *[params[i] for i in stages[n - 1]['params']])
+                for k in range(n - 2, 0, -1):
+                    tok = PlanStageFn.apply(h, k, n, 1, tok, *[params[i] for i in stages[k]['params']])
+                outs = PlanStageFn.apply(h, 0, n, 1, tok, *[params[i] for i in stages[0]['params']])
         elif not self.training and GRAPH_EVAL:
             outs = h.run_graphed(tensors)
         else:

@@ -81,10 +81,16 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     nkeep = torch.empty(B, dtype=torch.int32, device=dev)
     # long candidate lists (test.py: conf 0.001 + multi_label, 1e5 per image): counting sort instead of the O(n^2) rank kernel
     ws = torch.empty(B * (3 * 65536 + cap), dtype=torch.int32, device=dev) if (multi or conf_thres < 0.05) else None
+    # short single-label lists (detect.py): rank / bit matrix on the whole device + a one-wave scan (csrc/nms.hip); 9 MB per image
+    mws, mws_bytes = None, 0
+    if ws is None and B <= 64:
+        mws_bytes = int(_L.lib().myolo_nms_ws_bytes(B, cap))
+        mws = torch.empty(mws_bytes, dtype=torch.uint8, device=dev)
     _L.check(_L.lib().myolo_nms(_L.ptr(pred), _L.DT[pred.dtype], B, A, no, _C.c_float(conf_thres), _C.c_float(iou_thres),
                                 int(multi), int(bool(agnostic)), _C.c_float(max_wh), max_nms, max_det, cap, _L.ptr(counts),
                                 _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), class_mask,
-                                _L.ptr(ws) if ws is not None else None, _L.stream_ptr()),
+                                _L.ptr(ws) if ws is not None else None, _L.ptr(mws) if mws is not None else None, mws_bytes,
+                                _L.stream_ptr()),
              'myolo_nms')
     n = nkeep.tolist()                                            # the one sync (the reference syncs per image, 446-495)
     return [out[i, :n[i]] for i in range(B)]

@@ -255,9 +255,10 @@ def detect(ctx, p, xs, nc, stride):  # yolo.py:206-230
     return raw if ctx.training else (torch.cat(z, 1), raw)
 
 
-def forward(cfg, sd, x, training, dropout_p=0.1, record=None):
-    """Model.forward_once (yolo.py:293-316): returns [det_out, seg_out]."""
+def forward(cfg, sd, x, training, dropout_p=0.1, record=None, dropout_fn=None):
+    """Model.forward_once (yolo.py:293-316): returns [det_out, seg_out].  dropout_fn: tests replay a given keep-mask (Ctx.dropout_fn)."""
     ctx = Ctx(sd, training, dropout_p, record)
+    ctx.dropout_fn = dropout_fn
     gd, gw, nc = cfg['depth_multiple'], cfg['width_multiple'], cfg['nc']
     ys = []
     for i, (f, n, m, args) in enumerate(cfg['backbone'] + cfg['head']):

@@ -18,4 +18,13 @@ import cProfile, pstats
 pr=cProfile.Profile(); pr.enable()
 for _ in range(5): tr.step()
 pr.disable(); torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats('tottime').print_stats(14)
+# the native executor alone: one forward launch list, host time of the C call
+from multiyolov5_amd import engine as E
+plan=[h.plan for h in tr.model.__dict__['_plans'].values() if h.plan.training][0]
+np_=plan._native_fwd()
+if np_ is not None:
+    torch.cuda.synchronize(); t0=time.perf_counter()
+    for _ in range(10): np_.run()
+    t1=time.perf_counter(); torch.cuda.synchronize()
+    print('native forward program: %d ops, host %.3f ms per run (%.2f us per op)' % (np_.n, (t1-t0)/10*1e3, (t1-t0)/10/np_.n*1e6))

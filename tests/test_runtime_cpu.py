@@ -98,3 +98,46 @@ def test_flat_accumulation_rule():
     assert R._accumulate_in_place(holder, plan) is False
     h.remove()
     assert R._accumulate_in_place(holder, plan) is True
+
+
+def test_sync_batchnorm_is_rejected_loudly():
+    """train.py:190-193 --sync-bn converts the mirror's BatchNorm2d modules: the per-GPU statistics kernels must not run under that name"""
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    m = Model(os.path.join(CFG, TAGS['s_psp']))
+    m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m).train()
+    assert any(isinstance(x, torch.nn.SyncBatchNorm) for x in m.modules())
+    with pytest.raises(L.MyoloError, match='SyncBatchNorm'):
+        R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float16, True)
+
+
+def test_native_program_serialises_every_launch_of_a_training_plan():
+    """csrc/plan_exec.hip: every entry point a training plan launches has a thunk, argument slots carry addresses / sign-extended integers /
+    float bit patterns, caller-bound input pointers are registered for per-run patching, the fused-loss switch becomes two conditional ops"""
+    import ctypes as C
+    import struct
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd import engine as E
+    plan = _plan()
+    lib = L.lib()
+    fwd = [c for op in plan.ops for c in op.fwd_calls]
+    bwd = [c for op in plan.ops for c in op.bwd_calls]
+    for c in fwd + bwd:
+        fn = lib.myolo_prog_fn_id(c.name.encode())
+        assert fn >= 0, c.name
+        nargs = len(c.a.args) if isinstance(c, E.SwitchCall) else len(c.args)
+        assert lib.myolo_prog_fn_nargs(fn) == nargs == len(L._PROTOS[c.name][1]) - 1, c.name
+    prog = E.NativeProg(fwd, plan.in_ptr)
+    assert prog.n == len(fwd) and len(prog.fixups) == 1                     # the image pointer of FocusPackOp
+    op_i, arg_i, cell, _ = prog.fixups[0]
+    assert prog.names[op_i] == 'myolo_focus_pack' and cell is plan.in_ptr[0]
+    plan.in_ptr[0].value = 0x1234560
+    assert E._slot_value(plan.in_ptr[0], C.c_void_p) == 0x1234560
+    # slot encodings
+    assert E._slot_value(C.c_float(1.5), C.c_float) == struct.unpack('<I', struct.pack('<f', 1.5))[0]
+    assert E._slot_value(-1, C.c_int) == 0xFFFFFFFFFFFFFFFF and E._slot_value(None, C.c_void_p) == 0
+    d = L.Tensor()
+    assert E._slot_value(C.byref(d), C.POINTER(L.Tensor)) == C.addressof(d)
+    sw = [c for c in bwd if isinstance(c, E.SwitchCall)]
+    assert len(sw) == 1 and isinstance(sw[0].cell, C.c_int32)
