@@ -220,6 +220,10 @@ int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int acc
 /* nn.AdaptiveAvgPool2d(k) (common.py:521-524, 214): out [n,k,k,c].  scratch (optional): fp32[n*k*k*c] ZEROED by the caller;
  * with it, big bins are summed by many workgroups in parallel. */
 int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, float* scratch, void* stream);
+/* PyramidPooling's pools (common.py:521-524: AdaptiveAvgPool2d(1), (2), (3), (6) of the SAME map) in one pass over x: outs[0..count)
+ * (count <= 4) are the [n,k,k,c] results, scratch fp32 [n][sum of k*k][c] ZEROED by the caller (left dirty).  MYOLO_EINVAL when the
+ * map is too narrow for the kernel's bin bookkeeping (x.w / 256*seg/c + 2 > x.w / kmax): use the single-pool entry point then. */
+int myolo_adaptive_avgpool_fwd_multi(const myolo_tensor* x, const myolo_tensor* outs, int count, float* scratch, void* stream);
 int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
 /* the backward of up to four adaptive average pools of ONE input (PyramidPooling, common.py:521-524): gouts = array of `count`
  * pooled-gradient views; gx (+)= sum over them -- the input gradient is read-modified-written once instead of once per pool */

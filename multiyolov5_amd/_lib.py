@@ -123,6 +123,7 @@ _PROTOS = {
     'myolo_bilinear_bwd': (C.c_int, [TP, TP, C.c_int, P, P]),
     'myolo_adaptive_avgpool_fwd': (C.c_int, [TP, TP, P, P]),
     'myolo_adaptive_avgpool_bwd': (C.c_int, [TP, TP, C.c_int, P]),
+    'myolo_adaptive_avgpool_fwd_multi': (C.c_int, [TP, P, C.c_int, P, P]),
     'myolo_gate_fwd': (C.c_int, [TP, TP, TP, P]),
     'myolo_gate_bwd': (C.c_int, [TP, TP, TP, TP, C.c_int, P, P]),
     'myolo_gate_mul_fwd': (C.c_int, [TP, TP, TP, P]),

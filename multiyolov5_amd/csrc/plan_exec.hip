@@ -50,7 +50,7 @@ const Entry g_table[] = {
     REG(myolo_conv_wgrad), REG(myolo_bn_act_fwd), REG(myolo_bn_act_bwd_reduce), REG(myolo_bn_act_bwd_apply),
     REG(myolo_bn_act_fwd_split), REG(myolo_bn_act_bwd_reduce_split), REG(myolo_bn_act_bwd_apply_split), REG(myolo_spp_pool_fwd),
     REG(myolo_spp_pool_bwd), REG(myolo_copy_up_fwd), REG(myolo_copy_up_bwd), REG(myolo_bilinear_fwd), REG(myolo_bilinear_bwd),
-    REG(myolo_adaptive_avgpool_fwd), REG(myolo_adaptive_avgpool_bwd), REG(myolo_adaptive_avgpool_bwd_multi),
+    REG(myolo_adaptive_avgpool_fwd), REG(myolo_adaptive_avgpool_fwd_multi), REG(myolo_adaptive_avgpool_bwd), REG(myolo_adaptive_avgpool_bwd_multi),
     REG(myolo_pyramid_upsample_fwd), REG(myolo_pyramid_upsample_bwd), REG(myolo_gate_fwd), REG(myolo_gate_bwd),
     REG(myolo_gate_mul_fwd), REG(myolo_gate_mul_bwd), REG(myolo_add), REG(myolo_fill_zero), REG(myolo_cast_from_f32),
     REG(myolo_dropout_fwd), REG(myolo_dropout_bwd), REG(myolo_seg_upsample_fwd), REG(myolo_seg_upsample_bwd),

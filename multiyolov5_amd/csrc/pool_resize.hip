@@ -806,6 +806,114 @@ __global__ __launch_bounds__(256) void aap_finish_kernel(myolo_tensor x, myolo_t
   }
 }
 
+
+// ---- PyramidPooling's pools (AdaptiveAvgPool2d(1), (2), (3), (6) of the SAME map, common.py:521-524) in ONE pass over x ----------------
+// Four separate passes read the 128-channel map four times (4 x 29 us for the 128x256 map of a 2048x1024 frame, plus four finish launches).
+// Here a workgroup owns a strip of rows; a thread owns 8 channels (one 16-byte vector) and a contiguous x range of W/PL pixels, which is
+// narrower than any bin, so per pool it touches at most three horizontal bins: three register accumulators per pool, added to the
+// workgroup's [bins][C] fp32 table in LDS once per row (rows map to one or two vertical bins), the table goes to the global scratch with
+// one atomic per touched (bin, channel).  Bin b of k over H is [floor(b*H/k), ceil((b+1)*H/k)): pixel y lies in bin y*k/H and, on a
+// fractional boundary, in ONE neighbour.
+constexpr int AAP_MAXP = 4;
+struct AapFwdMulti { int np; int k[AAP_MAXP]; int bin0[AAP_MAXP]; int nbins; };
+
+// bins of `k` over `n` that contain coordinate v: b (always) and nb (-1 if none)
+__device__ __forceinline__ void aap_bins(int v, int n, int k, int& b, int& nb) {
+  b = (int)(((uint32_t)v * (uint32_t)k) / (uint32_t)n);
+  nb = -1;
+  if (b > 0 && v < ((b * n + k - 1) / k)) nb = b - 1;                 // v < ceil(b*n/k): still inside bin b-1
+  else if (b + 1 < k && v >= ((b + 1) * n) / k) nb = b + 1;           // v >= floor((b+1)*n/k): already inside bin b+1
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapFwdMulti mp, int rows_per_wg, float* scratch) {
+  constexpr int SEG = ET<T>::SEG;
+  extern __shared__ float sbin[];                                      // [nbins][C]
+  const int C = x.c, G = C / SEG, PL = 256 / G;
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  const int n = blockIdx.y;
+  const int r0 = blockIdx.x * rows_per_wg, r1 = r0 + rows_per_wg < x.h ? r0 + rows_per_wg : x.h;
+  for (int i = threadIdx.x; i < mp.nbins * C; i += 256) sbin[i] = 0.f;
+  __syncthreads();
+  const int xa = (int)(((int64_t)pl * x.w) / PL), xb = (int)(((int64_t)(pl + 1) * x.w) / PL);
+  int bA[AAP_MAXP];
+#pragma unroll
+  for (int p = 0; p < AAP_MAXP; ++p) {
+    int b = 0, nb = -1;
+    if (p < mp.np && xa < xb) aap_bins(xa, x.w, mp.k[p], b, nb);
+    bA[p] = (nb >= 0 && nb < b) ? nb : b;                             // lowest bin this thread's range can touch
+  }
+  for (int y = r0; y < r1; ++y) {
+    float acc[AAP_MAXP][3][SEG];
+#pragma unroll
+    for (int p = 0; p < AAP_MAXP; ++p)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) acc[p][j][i] = 0.f;
+    for (int xx = xa; xx < xb; ++xx) {
+      float f[SEG];
+      Vec<T>::unpack(ldg16(vptr<T>(x, n, y, xx) + cg * SEG), f);
+#pragma unroll
+      for (int p = 0; p < AAP_MAXP; ++p) {
+        if (p >= mp.np) continue;
+        int b, nb;
+        aap_bins(xx, x.w, mp.k[p], b, nb);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float m = (b == bA[p] + j || nb == bA[p] + j) ? 1.f : 0.f;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < AAP_MAXP; ++p) {
+      if (p >= mp.np) continue;
+      const int k = mp.k[p];
+      int by, nby;
+      aap_bins(y, x.h, k, by, nby);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int bx = bA[p] + j;
+        if (bx >= k) continue;
+        float* d0 = sbin + (mp.bin0[p] + by * k + bx) * C + cg * SEG;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) if (acc[p][j][i] != 0.f) atomicAdd(d0 + i, acc[p][j][i]);
+        if (nby >= 0) {
+          float* d1 = sbin + (mp.bin0[p] + nby * k + bx) * C + cg * SEG;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) if (acc[p][j][i] != 0.f) atomicAdd(d1 + i, acc[p][j][i]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = scratch + (int64_t)n * mp.nbins * C;
+  for (int i = threadIdx.x; i < mp.nbins * C; i += 256) {
+    const float v = sbin[i];
+    if (v != 0.f) atomicAdd(dst + i, v);
+  }
+}
+// scale + cast of every pool's bins: outs[p] [n, k, k, C]
+struct AapOuts { myolo_tensor o[AAP_MAXP]; };
+template <typename T>
+__global__ __launch_bounds__(256) void aap_finish_multi_kernel(int H, int W, int C, int N, AapFwdMulti mp, AapOuts outs, const float* scratch) {
+  const int64_t total = (int64_t)N * mp.nbins * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C); int64_t r = i / C;
+    const int bin = (int)(r % mp.nbins); const int n = (int)(r / mp.nbins);
+    int p = 0;
+#pragma unroll
+    for (int q = 1; q < AAP_MAXP; ++q) if (q < mp.np && bin >= mp.bin0[q]) p = q;
+    const int k = mp.k[p], lb = bin - mp.bin0[p];
+    const int by = lb / k, bx = lb - by * k;
+    const int y0 = (by * H) / k, y1 = ((by + 1) * H + k - 1) / k;
+    const int x0 = (bx * W) / k, x1 = ((bx + 1) * W + k - 1) / k;
+    vptr<T>(outs.o[p], n, by, bx)[c] = (T)(scratch[i] / (float)((y1 - y0) * (x1 - x0)));
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void aap_bwd_kernel(myolo_tensor gout, myolo_tensor gx, int acc) {
   constexpr int SEG = ET<T>::SEG;
@@ -1174,6 +1282,43 @@ extern "C" int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_ten
     return 0;
   }
   DISPATCH(x->dtype, aap_fwd_kernel, bins, 256, 0, (hipStream_t)stream, *x, *out);
+  return 0;
+}
+extern "C" int myolo_adaptive_avgpool_fwd_multi(const myolo_tensor* x, const myolo_tensor* outs, int count, float* scratch, void* stream) {
+  if (!x || !outs || !scratch || count < 1 || count > AAP_MAXP || !vec_ok(x)) return MYOLO_EINVAL;
+  const int seg = x->dtype == MYOLO_F16 ? 8 : 4;
+  const int G = x->c / seg;
+  if (G < 1 || G > 256 || 256 % G) return MYOLO_EINVAL;
+  const int PL = 256 / G;
+  AapFwdMulti mp;
+  AapOuts ao;
+  mp.np = count; mp.nbins = 0;
+  int kmax = 1;
+  for (int p = 0; p < AAP_MAXP; ++p) { mp.k[p] = 1; mp.bin0[p] = 0; ao.o[p] = outs[0]; }
+  for (int p = 0; p < count; ++p) {
+    const myolo_tensor& o = outs[p];
+    if (!vec_ok(&o) || !same_nc(x, &o) || o.h != o.w || o.h < 1 || o.h > x->h || o.w > x->w) return MYOLO_EINVAL;
+    mp.k[p] = o.h; mp.bin0[p] = mp.nbins; mp.nbins += o.h * o.w; ao.o[p] = o;
+    if (o.h > kmax) kmax = o.h;
+  }
+  // a thread's x range (W/PL pixels, +1 for rounding) must be narrower than a bin minus its one-pixel overlaps: at most 3 bins per range
+  if ((x->w + PL - 1) / PL + 2 > x->w / kmax || x->w < PL) return MYOLO_EINVAL;
+  const int smem = mp.nbins * x->c * 4;
+  if (smem > 60 * 1024) return MYOLO_EINVAL;
+  int rows = (int)(((int64_t)x->h * x->n + 511) / 512);        // ~512 workgroups
+  if (rows < 1) rows = 1;
+  const int gx = (x->h + rows - 1) / rows;
+  hipStream_t st = (hipStream_t)stream;
+  if (x->dtype == MYOLO_F16) {
+    hipLaunchKernelGGL(aap_fwd_multi_kernel<half_t>, dim3(gx, x->n), dim3(256), smem, st, *x, mp, rows, scratch);
+    hipLaunchKernelGGL(aap_finish_multi_kernel<half_t>, dim3(grid_for((int64_t)x->n * mp.nbins * x->c, 256)), dim3(256), 0, st, x->h, x->w, x->c,
+                       x->n, mp, ao, scratch);
+  } else {
+    hipLaunchKernelGGL(aap_fwd_multi_kernel<float>, dim3(gx, x->n), dim3(256), smem, st, *x, mp, rows, scratch);
+    hipLaunchKernelGGL(aap_finish_multi_kernel<float>, dim3(grid_for((int64_t)x->n * mp.nbins * x->c, 256)), dim3(256), 0, st, x->h, x->w, x->c,
+                       x->n, mp, ao, scratch);
+  }
+  MYOLO_CHECK_LAUNCH();
   return 0;
 }
 extern "C" int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate,

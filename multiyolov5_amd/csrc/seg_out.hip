@@ -76,6 +76,53 @@ __global__ __launch_bounds__(256) void seg_argmax_kernel(myolo_tensor low, void*
   }
 }
 
+// tiled form of seg_argmax_kernel: a workgroup owns 256 consecutive pixels of one output row; the two low-resolution rows it interpolates
+// between go through LDS ONCE (x8 upsample: ~35 columns x C classes x 2 rows as fp32), every thread then reads its 4 taps x C classes from
+// there -- the per-pixel kernel above issued 4 x C two-byte global loads per pixel (79 us for a 2048x1024 label map; the map is 16 MB of
+// int64 writes = ~4 us of HBM time).  Same expression per class, same first-maximum rule.
+template <typename T>
+__global__ __launch_bounds__(256) void seg_argmax_tile_kernel(myolo_tensor low, void* labels, int label_dtype, int H, int W, float sy,
+                                                              float sx, int tiles_x, int maxcol) {
+  extern __shared__ float sl[];                                   // [2][maxcol][C]
+  const int C = low.c;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x; bid /= tiles_x;
+  const int y = bid % H; const int n = bid / H;
+  const int xa = tx * 256, xb = (xa + 255 < W ? xa + 255 : W - 1);
+  const float fy = sy * (float)y;
+  const int y0 = (int)fy;
+  const int y1 = y0 + 1 < low.h ? y0 + 1 : low.h - 1;
+  const float ly = fy - (float)y0;
+  const int c0 = (int)(sx * (float)xa);
+  int c1 = (int)(sx * (float)xb) + 1;
+  if (c1 > low.w - 1) c1 = low.w - 1;
+  const int ncol = c1 - c0 + 1;                                   // <= maxcol (host)
+  const T* src = reinterpret_cast<const T*>(low.ptr);
+  for (int e = threadIdx.x; e < 2 * ncol * C; e += 256) {
+    const int r = e / (ncol * C); const int rem = e - r * ncol * C;
+    const int col = rem / C, c = rem - col * C;
+    sl[(r * maxcol + col) * C + c] = (float)src[(int64_t)n * low.sn + (int64_t)(r ? y1 : y0) * low.sh + (int64_t)(c0 + col) * low.sw + c];
+  }
+  __syncthreads();
+  const int x = xa + threadIdx.x;
+  if (x >= W) return;
+  const float fx = sx * (float)x;
+  const int x0 = (int)fx;
+  const int x1 = x0 + 1 < low.w ? x0 + 1 : low.w - 1;
+  const float lx = fx - (float)x0;
+  const float* p00 = sl + (x0 - c0) * C; const float* p01 = sl + (x1 - c0) * C;
+  const float* p10 = sl + (maxcol + x0 - c0) * C; const float* p11 = sl + (maxcol + x1 - c0) * C;
+  float best = -INFINITY; int arg = 0;
+  for (int c = 0; c < C; ++c) {
+    const float a = p00[c], b = p01[c], cc = p10[c], d = p11[c];
+    float v = (1.f - ly) * ((1.f - lx) * a + lx * b) + ly * ((1.f - lx) * cc + lx * d);
+    if (sizeof(T) == 2) v = (float)(half_t)v;                     // the reference materialises fp16 logits before max
+    if (v > best) { best = v; arg = c; }                          // first maximum wins (torch.max)
+  }
+  const int64_t i = ((int64_t)n * H + y) * W + x;
+  if (label_dtype == MYOLO_I64) ((int64_t*)labels)[i] = arg; else ((uint8_t*)labels)[i] = (uint8_t)arg;
+}
+
 __device__ __forceinline__ void out_range(int i, int in, int out, float s, int& lo, int& hi) {
   if (out == 1 || in == 1 || s <= 0.f) { lo = 0; hi = out - 1; return; }
   lo = (int)floorf(((float)i - 1.f) / s) - 1; hi = (int)ceilf(((float)i + 1.f) / s) + 1;
@@ -394,6 +441,23 @@ extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, 
 extern "C" int myolo_seg_argmax(const myolo_tensor* low, void* labels, int label_dtype, int H, int W, void* stream) {
   if (!low || !low->ptr || !labels || (label_dtype != MYOLO_U8 && label_dtype != MYOLO_I64)) return MYOLO_EINVAL;
   const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
+  {
+    // up-scaling (detect.py:191: the x8 head output, or a resize to the source frame): rows staged through LDS
+    const int maxcol = (int)(sx * 255.f) + 3;
+    const int smem = 2 * maxcol * low->c * 4;
+    const int tiles_x = (W + 255) / 256;
+    const int64_t blocks = (int64_t)low->n * H * tiles_x;
+    if ((low->dtype == MYOLO_F16 || low->dtype == MYOLO_F32) && low->c <= 32 && smem <= 48 * 1024 && blocks < 0x7fffffff && W >= 64) {
+      if (low->dtype == MYOLO_F16)
+        hipLaunchKernelGGL(seg_argmax_tile_kernel<half_t>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, *low, labels, label_dtype, H,
+                           W, sy, sx, tiles_x, maxcol);
+      else
+        hipLaunchKernelGGL(seg_argmax_tile_kernel<float>, dim3((int)blocks), dim3(256), smem, (hipStream_t)stream, *low, labels, label_dtype, H,
+                           W, sy, sx, tiles_x, maxcol);
+      MYOLO_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   hipLaunchKernelGGL(seg_argmax_kernel, dim3(grid_for((int64_t)low->n * H * W, 256, 8192)), dim3(256), 0,
                      (hipStream_t)stream, *low, labels, label_dtype, H, W, sy, sx);
   MYOLO_CHECK_LAUNCH();

@@ -632,8 +632,32 @@ class AvgPoolOp(SimpleOp):
             self.acc, z = claim(self.src)
             self.zero_first = [(self.src, a, b) for a, b in z]
 
+    def _fwd_multi(self, plan):
+        """PyramidPooling: the pools of one map as ONE pass over it (myolo_adaptive_avgpool_fwd_multi) -- the conditions of that entry point"""
+        g = self.group
+        if g is None or len(g) < 2 or len(g) > 4 or os.environ.get('MYOLO_NO_AAP_MULTI', '0') == '1':
+            return False
+        s0, seg = g[0].src, SEG[plan.dtype]
+        G = s0.c // seg
+        if s0.c % seg or G < 1 or G > 256 or 256 % G:
+            return False
+        PL, kmax = 256 // G, max(o.dst.h for o in g)
+        if any(o.src is not s0 or o.dst.h != o.dst.w or o.dst.c != s0.c for o in g):
+            return False
+        if (s0.w + PL - 1) // PL + 2 > s0.w // kmax or s0.w < PL:
+            return False
+        return sum(o.dst.h * o.dst.w for o in g) * s0.c * 4 <= 60 * 1024
+
     def emit_fwd(self, plan):
         d = self.dst
+        if self._fwd_multi(plan):
+            g = self.group
+            if self is g[0]:
+                nb = sum(o.dst.h * o.dst.w for o in g)
+                self.scratch = plan.f32_fwd_zero(d.n * nb * self.src.c)
+                self.fouts = (CT * len(g))(*[o.dst.desc() for o in g])
+                self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd_multi', (C.byref(self.sd), self.fouts, len(g), L.ptr(self.scratch))))
+            return
         self.scratch = plan.f32_fwd_zero(d.n * d.h * d.w * d.buf.c)
         self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd', (C.byref(self.sd), C.byref(self.dd), L.ptr(self.scratch))))
 

@@ -291,7 +291,10 @@ def _stage_plan(holder):
                     stages.append({'ops': (first, np_.marks[si]), 'slices': list(pend)})
                     first, pend = np_.marks[si], []
                 elif last:
-                    stages.append({'ops': (first, np_.n), 'slices': list(pend)})
+                    if pend or not stages:
+                        stages.append({'ops': (first, np_.n), 'slices': list(pend)})
+                    else:                                  # nothing but the final join is left: it belongs to the last real stage (a stage
+                        stages[-1]['ops'] = (stages[-1]['ops'][0], np_.n)    # without parameters would be pruned by autograd)
             for sg in stages:
                 sg['params'] = [i for i, o in enumerate(offs) if any(a <= o < b for a, b in sg['slices'])]
             covered = sorted(i for sg in stages for i in sg['params'])
