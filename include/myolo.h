@@ -221,7 +221,8 @@ int myolo_bilinear_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int acc
  * with it, big bins are summed by many workgroups in parallel. */
 int myolo_adaptive_avgpool_fwd(const myolo_tensor* x, const myolo_tensor* out, float* scratch, void* stream);
 /* PyramidPooling's pools (common.py:521-524: AdaptiveAvgPool2d(1), (2), (3), (6) of the SAME map) in one pass over x: outs[0..count)
- * (count <= 4) are the [n,k,k,c] results, scratch fp32 [n][sum of k*k][c] ZEROED by the caller (left dirty).  MYOLO_EINVAL when the
+ * (count <= 4; 1 = a single pool, e.g. FFM's global average) are the [n,k,k,c] results, scratch fp32 [8][n][sum of k*k][c] ZEROED by
+ * the caller (left dirty; 8 replicas spread the same-address atomics).  MYOLO_EINVAL when the
  * map is too narrow for the kernel's bin bookkeeping (x.w / 256*seg/c + 2 > x.w / kmax): use the single-pool entry point then. */
 int myolo_adaptive_avgpool_fwd_multi(const myolo_tensor* x, const myolo_tensor* outs, int count, float* scratch, void* stream);
 int myolo_adaptive_avgpool_bwd(const myolo_tensor* gout, const myolo_tensor* gx, int accumulate, void* stream);
@@ -306,6 +307,14 @@ int myolo_seg_ce_scale(const double* acc, const float* gout, float* scale, void*
 int myolo_seg_upce_fwd_grad(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, double* acc,
                             float* loss, float* glow32, void* stream);
 int myolo_seg_lowgrad_apply(const float* glow32, const myolo_tensor* glow, int accumulate, const float* scale, void* stream);
+/* OhemCELoss (utils/loss.py:303-328) over the LOW-resolution logits of the head, the x8 bilinear upsample (yolo.py:163) folded in like
+ * myolo_seg_upce_fwd_grad: _pix writes the per-pixel losses (float [n][H][W], 0 on ignored pixels) and acc[1] = valid count;
+ * myolo_ohem_select then picks the hard pixels; _grad recomputes every pixel's softmax and folds (softmax - onehot) * selection weight
+ * into glow32 (fp32 [n][h][w][19], overwritten) -- the caller scales by gout / sel.denom (myolo_seg_lowgrad_apply).  19 classes. */
+int myolo_seg_upce_ohem_pix(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, double* acc, float* pix,
+                            void* stream);
+int myolo_seg_upce_ohem_grad(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, const float* pix,
+                             const float* sel, float thresh, float* glow32, void* stream);
 /* OhemCELoss.forward_once (utils/loss.py:321-328) on the per-pixel losses: mean of losses > thresh, or, if fewer than
  * n_min = acc[1]//16 qualify, mean of the n_min largest (device radix select, no host sync).
  * st: double[5] scratch, ws: uint32[2052] scratch, loss: float[1], sel: float[4] selection record for the backward. */

@@ -143,6 +143,8 @@ _PROTOS = {
     'myolo_pyramid_upsample_fwd': (C.c_int, [P, C.c_int, TP, P]),
     'myolo_pyramid_upsample_bwd': (C.c_int, [TP, P, C.c_int, P, P, P]),
     'myolo_seg_upce_fwd_grad': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, P, P]),
+    'myolo_seg_upce_ohem_pix': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, P]),
+    'myolo_seg_upce_ohem_grad': (C.c_int, [TP, C.c_int, C.c_int, P, C.c_int, P, P, C.c_float, P, P]),
     'myolo_seg_lowgrad_apply': (C.c_int, [P, TP, C.c_int, P, P]),
     'myolo_seg_ce_fwd_grad': (C.c_int, [P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P, C.c_int, P, P, P]),
     'myolo_seg_ce_scale': (C.c_int, [P, P, P, P]),

@@ -391,10 +391,16 @@ __device__ __forceinline__ void up_out_range(int i, int in, int out, float s, in
   if (hi > out - 1) hi = out - 1;
 }
 
-template <typename T, int CC>
+// MODE 0: mean CE -- loss sums + the unnormalised gradient (softmax - onehot) folded into the low-resolution map
+// MODE 1: OhemCELoss first pass (loss.py:321-322): the per-pixel losses (`reduction='none'`: 0 on ignored pixels) to `pix`, the valid count
+// MODE 2: OhemCELoss gradient pass: the same walk, every pixel's (softmax - onehot) weighted by the selection myolo_ohem_select left in
+//         `sel` (loss > thresh, or the n_min largest with the tied ones sharing what is left, loss.py:323-327), folded into the low map
+template <typename T, int CC, int MODE = 0>
 __global__ __launch_bounds__(256) void seg_upce_kernel(myolo_tensor low, int H, int W, float sy, float sx, int TY, const int64_t* tgt,
-                                                       int ignore, double* acc, float* g32) {
+                                                       int ignore, double* acc, float* g32, float* pix, const OhemSel* sel, float thresh) {
   constexpr int C = CC;
+  int omode = 0; float okth = 0.f, otie = 0.f;
+  if (MODE == 2) { omode = (int)sel->mode; okth = sel->kth; otie = sel->tie_w; }
   __shared__ float fb[256 * C];
   __shared__ double shd[4];
   const int strips = (W + 255) / 256, nyb = (H + TY - 1) / TY;
@@ -462,7 +468,7 @@ __global__ __launch_bounds__(256) void seg_upce_kernel(myolo_tensor low, int H, 
     const int y0 = (int)fy;
     const float ly = fy - (float)y0;
     while (j != y0) {                                   // uniform over the workgroup: the walk left low row j
-      flush(j, at);
+      if (MODE != 1) flush(j, at);
       ++j;
 #pragma unroll
       for (int c = 0; c < C; ++c) { at[c] = ab[c]; ab[c] = 0.f; top[c] = bot[c]; }
@@ -481,22 +487,38 @@ __global__ __launch_bounds__(256) void seg_upce_kernel(myolo_tensor low, int H, 
         v[c] = __builtin_amdgcn_exp2f(fmaf(v[c], LOG2E, mb));
         sm += v[c];
       }
-      lsum += (double)((m + __builtin_amdgcn_logf(sm) * LN2) - xt);
+      const float l = (m + __builtin_amdgcn_logf(sm) * LN2) - xt;
+      lsum += (double)l;
       lcnt += 1.0;
-      const float inv = __builtin_amdgcn_rcpf(sm);
+      if (MODE == 1) {
+        if (live) pix[((int64_t)n * H + y) * W + x] = l;
+      } else {
+        float wgt = 1.f;
+        if (MODE == 2) {                                // the loss value the selection was made on (bit-identical: written by MODE 1)
+          const float lp = pix[((int64_t)n * H + y) * W + xc];
+          wgt = omode == 0 ? (lp > thresh ? 1.f : 0.f) : (lp > okth ? 1.f : (lp == okth ? otie : 0.f));
+        }
+        const float inv = __builtin_amdgcn_rcpf(sm) * wgt;
 #pragma unroll
-      for (int c = 0; c < C; ++c) {
-        const float g = v[c] * inv - (c == (int)t ? 1.f : 0.f);
-        at[c] += (1.f - ly) * g;
-        ab[c] += ly * g;
+        for (int c = 0; c < C; ++c) {
+          const float g = v[c] * inv - (c == (int)t ? wgt : 0.f);
+          at[c] += (1.f - ly) * g;
+          ab[c] += ly * g;
+        }
       }
+    } else if (MODE == 1 && live) {
+      pix[((int64_t)n * H + y) * W + x] = 0.f;
     }
   }
-  flush(j, at);
-  flush(j + 1 < low.h ? j + 1 : low.h - 1, ab);
-  const double bs = block_sum256(lsum, shd);
-  const double bc = block_sum256(lcnt, shd);
-  if (threadIdx.x == 0) { atomicAdd(acc + 0, bs); atomicAdd(acc + 1, bc); }
+  if (MODE != 1) {
+    flush(j, at);
+    flush(j + 1 < low.h ? j + 1 : low.h - 1, ab);
+  }
+  if (MODE != 2) {
+    const double bs = block_sum256(lsum, shd);
+    const double bc = block_sum256(lcnt, shd);
+    if (threadIdx.x == 0) { atomicAdd(acc + 0, bs); atomicAdd(acc + 1, bc); }
+  }
 }
 
 // low-res gradient of the head's classifier: glow (+)= scale * g32   (scale = gout / n_valid, myolo_seg_ce_scale)
@@ -536,17 +558,61 @@ extern "C" int myolo_seg_upce_fwd_grad(const myolo_tensor* low, int H, int W, co
   const int64_t grid = (int64_t)low->n * ((H + TY - 1) / TY) * strips;
   if (grid > 0x7fffffff) return MYOLO_EINVAL;
   if (low->dtype == MYOLO_F16)
-    hipLaunchKernelGGL((seg_upce_kernel<half_t, 19>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index,
-                       acc, glow32);
+    hipLaunchKernelGGL((seg_upce_kernel<half_t, 19, 0>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index,
+                       acc, glow32, (float*)nullptr, (const OhemSel*)nullptr, 0.f);
   else
-    hipLaunchKernelGGL((seg_upce_kernel<float, 19>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index,
-                       acc, glow32);
+    hipLaunchKernelGGL((seg_upce_kernel<float, 19, 0>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index,
+                       acc, glow32, (float*)nullptr, (const OhemSel*)nullptr, 0.f);
   MYOLO_CHECK_LAUNCH();
   if (loss) {
     hipLaunchKernelGGL(ce_final_kernel, dim3(1), dim3(1), 0, st, acc, loss);
     MYOLO_CHECK_LAUNCH();
   }
   return 0;
+}
+
+// OhemCELoss over the LOW-resolution logits (SURVEY K15 for loss.py:303-328): pass 1 = per-pixel losses (the only full-resolution
+// tensor that exists: fp32 [n][H][W]) + valid count; myolo_ohem_select picks the hard pixels; pass 2 = their gradient, folded into the
+// low-resolution map.  The x8-upsampled logits and their gradient are never formed.
+static int seg_upce_ohem_launch(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, double* acc, float* pix,
+                                const float* sel, float thresh, float* glow32, int mode, void* stream) {
+  if (!low || !low->ptr || !target || !pix || H < 1 || W < 1) return MYOLO_EINVAL;
+  if ((low->dtype != MYOLO_F16 && low->dtype != MYOLO_F32) || low->c != 19) return MYOLO_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e;
+  if (mode == 1) {
+    if (!acc) return MYOLO_EINVAL;
+    e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
+    if (e != hipSuccess) return (int)e;
+  } else {
+    if (!sel || !glow32) return MYOLO_EINVAL;
+    e = hipMemsetAsync(glow32, 0, (size_t)low->n * low->h * low->w * low->c * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
+  int TY = 32;
+  const int strips = (W + 255) / 256;
+  while (TY > 8 && (int64_t)low->n * ((H + TY - 1) / TY) * strips < 1024) TY >>= 1;
+  const int64_t grid = (int64_t)low->n * ((H + TY - 1) / TY) * strips;
+  if (grid > 0x7fffffff) return MYOLO_EINVAL;
+  const OhemSel* os = reinterpret_cast<const OhemSel*>(sel);
+  if (low->dtype == MYOLO_F16) {
+    if (mode == 1) hipLaunchKernelGGL((seg_upce_kernel<half_t, 19, 1>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index, acc, glow32, pix, os, thresh);
+    else hipLaunchKernelGGL((seg_upce_kernel<half_t, 19, 2>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index, acc, glow32, pix, os, thresh);
+  } else {
+    if (mode == 1) hipLaunchKernelGGL((seg_upce_kernel<float, 19, 1>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index, acc, glow32, pix, os, thresh);
+    else hipLaunchKernelGGL((seg_upce_kernel<float, 19, 2>), dim3((unsigned)grid), dim3(256), 0, st, *low, H, W, sy, sx, TY, target, ignore_index, acc, glow32, pix, os, thresh);
+  }
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int myolo_seg_upce_ohem_pix(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, double* acc,
+                                       float* pix, void* stream) {
+  return seg_upce_ohem_launch(low, H, W, target, ignore_index, acc, pix, nullptr, 0.f, nullptr, 1, stream);
+}
+extern "C" int myolo_seg_upce_ohem_grad(const myolo_tensor* low, int H, int W, const int64_t* target, int ignore_index, const float* pix,
+                                        const float* sel, float thresh, float* glow32, void* stream) {
+  return seg_upce_ohem_launch(low, H, W, target, ignore_index, nullptr, const_cast<float*>(pix), sel, thresh, glow32, 2, stream);
 }
 
 extern "C" int myolo_seg_lowgrad_apply(const float* glow32, const myolo_tensor* glow, int accumulate, const float* scale, void* stream) {

@@ -88,7 +88,9 @@ extern "C" void* myolo_prog_create(const myolo_prog_op* ops, int n) {
   p->evs.assign(n, nullptr);
   for (int i = 0; i < n; ++i)
     if (ops[i].kind == MYOLO_OP_CALL_SIDE || ops[i].kind == MYOLO_OP_JOIN) {
-      if (hipEventCreateWithFlags(&p->evs[i], hipEventDisableTiming) != hipSuccess) {
+      // no timing, no system-scope fence: the event only orders two streams of this device (a default event's record releases to
+      // system scope: 5-8 us of main-queue idle per weight-gradient fork in the r3d trace, 79 forks per step)
+      if (hipEventCreateWithFlags(&p->evs[i], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
         for (hipEvent_t e : p->evs) if (e) (void)hipEventDestroy(e);
         delete p;
         return nullptr;

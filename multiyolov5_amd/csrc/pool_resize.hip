@@ -825,6 +825,8 @@ __device__ __forceinline__ void aap_bins(int v, int n, int k, int& b, int& nb) {
   else if (b + 1 < k && v >= ((b + 1) * n) / k) nb = b + 1;           // v >= floor((b+1)*n/k): already inside bin b+1
 }
 
+constexpr int AAP_REPL = 8;     // replicas of the global bin table: workgroup w adds into replica w % 8 (same-address fp32 atomics retire
+                                // at ~110 ns each: 256 workgroups on the 128 addresses of a global-average bin were 28 us of nothing else)
 template <typename T>
 __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapFwdMulti mp, int rows_per_wg, float* scratch) {
   constexpr int SEG = ET<T>::SEG;
@@ -836,12 +838,21 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
   for (int i = threadIdx.x; i < mp.nbins * C; i += 256) sbin[i] = 0.f;
   __syncthreads();
   const int xa = (int)(((int64_t)pl * x.w) / PL), xb = (int)(((int64_t)(pl + 1) * x.w) / PL);
-  int bA[AAP_MAXP];
+  // the (at most three) horizontal bins per pool this thread's x range can touch, as pixel intervals [lo, hi): no division per pixel
+  int bA[AAP_MAXP], lo[AAP_MAXP][3], hi[AAP_MAXP][3];
 #pragma unroll
   for (int p = 0; p < AAP_MAXP; ++p) {
     int b = 0, nb = -1;
-    if (p < mp.np && xa < xb) aap_bins(xa, x.w, mp.k[p], b, nb);
-    bA[p] = (nb >= 0 && nb < b) ? nb : b;                             // lowest bin this thread's range can touch
+    const int k = p < mp.np ? mp.k[p] : 1;
+    if (p < mp.np && xa < xb) aap_bins(xa, x.w, k, b, nb);
+    bA[p] = (nb >= 0 && nb < b) ? nb : b;                             // lowest bin the range can touch
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int bb = bA[p] + j;
+      const bool ok = p < mp.np && bb < k;
+      lo[p][j] = ok ? (bb * x.w) / k : 0x7fffffff;
+      hi[p][j] = ok ? ((bb + 1) * x.w + k - 1) / k : 0;
+    }
   }
   for (int y = r0; y < r1; ++y) {
     float acc[AAP_MAXP][3][SEG];
@@ -855,17 +866,13 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
       float f[SEG];
       Vec<T>::unpack(ldg16(vptr<T>(x, n, y, xx) + cg * SEG), f);
 #pragma unroll
-      for (int p = 0; p < AAP_MAXP; ++p) {
-        if (p >= mp.np) continue;
-        int b, nb;
-        aap_bins(xx, x.w, mp.k[p], b, nb);
+      for (int p = 0; p < AAP_MAXP; ++p)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-          const float m = (b == bA[p] + j || nb == bA[p] + j) ? 1.f : 0.f;
+          const float m = (xx >= lo[p][j] && xx < hi[p][j]) ? 1.f : 0.f;
 #pragma unroll
           for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
         }
-      }
     }
 #pragma unroll
     for (int p = 0; p < AAP_MAXP; ++p) {
@@ -876,20 +883,21 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const int bx = bA[p] + j;
-        if (bx >= k) continue;
+        if (bx >= k || hi[p][j] <= xa || lo[p][j] >= xb) continue;     // bin not touched by this thread's range
         float* d0 = sbin + (mp.bin0[p] + by * k + bx) * C + cg * SEG;
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) if (acc[p][j][i] != 0.f) atomicAdd(d0 + i, acc[p][j][i]);
+        for (int i = 0; i < SEG; ++i) atomicAdd(d0 + i, acc[p][j][i]);
         if (nby >= 0) {
           float* d1 = sbin + (mp.bin0[p] + nby * k + bx) * C + cg * SEG;
 #pragma unroll
-          for (int i = 0; i < SEG; ++i) if (acc[p][j][i] != 0.f) atomicAdd(d1 + i, acc[p][j][i]);
+          for (int i = 0; i < SEG; ++i) atomicAdd(d1 + i, acc[p][j][i]);
         }
       }
     }
   }
   __syncthreads();
-  float* dst = scratch + (int64_t)n * mp.nbins * C;
+  const int rep = (blockIdx.x + blockIdx.y) % AAP_REPL;
+  float* dst = scratch + ((int64_t)rep * gridDim.y + n) * mp.nbins * C;
   for (int i = threadIdx.x; i < mp.nbins * C; i += 256) {
     const float v = sbin[i];
     if (v != 0.f) atomicAdd(dst + i, v);
@@ -910,7 +918,10 @@ __global__ __launch_bounds__(256) void aap_finish_multi_kernel(int H, int W, int
     const int by = lb / k, bx = lb - by * k;
     const int y0 = (by * H) / k, y1 = ((by + 1) * H + k - 1) / k;
     const int x0 = (bx * W) / k, x1 = ((bx + 1) * W + k - 1) / k;
-    vptr<T>(outs.o[p], n, by, bx)[c] = (T)(scratch[i] / (float)((y1 - y0) * (x1 - x0)));
+    float sum = 0.f;
+#pragma unroll
+    for (int rp = 0; rp < AAP_REPL; ++rp) sum += scratch[(int64_t)rp * total + i];
+    vptr<T>(outs.o[p], n, by, bx)[c] = (T)(sum / (float)((y1 - y0) * (x1 - x0)));
   }
 }
 
@@ -1305,7 +1316,7 @@ extern "C" int myolo_adaptive_avgpool_fwd_multi(const myolo_tensor* x, const myo
   if ((x->w + PL - 1) / PL + 2 > x->w / kmax || x->w < PL) return MYOLO_EINVAL;
   const int smem = mp.nbins * x->c * 4;
   if (smem > 60 * 1024) return MYOLO_EINVAL;
-  int rows = (int)(((int64_t)x->h * x->n + 511) / 512);        // ~512 workgroups
+  int rows = (int)(((int64_t)x->h * x->n + 255) / 256);        // ~256 workgroups
   if (rows < 1) rows = 1;
   const int gx = (x->h + rows - 1) / rows;
   hipStream_t st = (hipStream_t)stream;

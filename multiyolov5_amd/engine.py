@@ -634,8 +634,8 @@ class AvgPoolOp(SimpleOp):
 
     def _fwd_multi(self, plan):
         """PyramidPooling: the pools of one map as ONE pass over it (myolo_adaptive_avgpool_fwd_multi) -- the conditions of that entry point"""
-        g = self.group
-        if g is None or len(g) < 2 or len(g) > 4 or os.environ.get('MYOLO_NO_AAP_MULTI', '0') == '1':
+        g = self.group if self.group is not None else [self]            # (a lone pool -- FFM's global average -- takes the same kernel)
+        if len(g) > 4 or os.environ.get('MYOLO_NO_AAP_MULTI', '0') == '1':
             return False
         s0, seg = g[0].src, SEG[plan.dtype]
         G = s0.c // seg
@@ -651,10 +651,10 @@ class AvgPoolOp(SimpleOp):
     def emit_fwd(self, plan):
         d = self.dst
         if self._fwd_multi(plan):
-            g = self.group
+            g = self.group if self.group is not None else [self]
             if self is g[0]:
                 nb = sum(o.dst.h * o.dst.w for o in g)
-                self.scratch = plan.f32_fwd_zero(d.n * nb * self.src.c)
+                self.scratch = plan.f32_fwd_zero(8 * d.n * nb * self.src.c)
                 self.fouts = (CT * len(g))(*[o.dst.desc() for o in g])
                 self.fwd_calls.append(Call('myolo_adaptive_avgpool_fwd_multi', (C.byref(self.sd), self.fouts, len(g), L.ptr(self.scratch))))
             return

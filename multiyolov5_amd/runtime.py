@@ -239,8 +239,23 @@ class PlanFn(torch.autograd.Function):
 # those parameter gradients to autograd -- whose engine runs their AccumulateGrad nodes (DDP's hooks: bucket ready -> all-reduce on
 # DDP's stream) BEFORE the next node -- then stage 1 runs the next piece of the launch list, and so on.  The stages are chained through
 # a dummy token tensor; the model inputs hang on the LAST stage (their gradient is complete when the whole list has run).
-STAGED_BWD = _os_env_flag('MYOLO_STAGED_BWD', True)
+# Used when a process group exists (stock DDP, or parallel.GradReducer with world > 1) or MYOLO_STAGED_BWD=force: every stage boundary makes
+# the main stream wait for the weight-gradient stream (the slice must be final before it is handed out) -- 2 x ~0.2 ms of main-queue idle
+# per step in the r3d trace, which only pays off when an exchange overlaps with the rest of the backward.
+import os as _os_staged
+STAGED_BWD = _os_staged.environ.get('MYOLO_STAGED_BWD', '1')
 STAGES = 3
+
+
+def _staged_wanted(holder):
+    if STAGED_BWD in ('0', False):
+        return False
+    if STAGED_BWD in ('force', True):
+        return True
+    red = holder.module.__dict__.get('_grad_reducer')
+    if red is not None:
+        return red.world > 1
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
 
 
 class StageCuts:
@@ -265,7 +280,7 @@ def _stage_plan(holder):
     """[(param index range, [flat slices], program op range)] per stage for this holder's plan, or None when the staged form does not
     apply (no native executor, a single bucket)"""
     plan = holder.plan
-    if not (STAGED_BWD and plan.training and plan.native_ok() and not plan.graphable()):
+    if not (_staged_wanted(holder) and plan.training and plan.native_ok() and not plan.graphable()):
         return None
     red = holder.module.__dict__.get('_grad_reducer')
     cuts = red if red is not None else holder.__dict__.setdefault('_stage_cuts', StageCuts())

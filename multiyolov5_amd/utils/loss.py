@@ -80,6 +80,30 @@ class _SegCE(torch.autograd.Function):
                 gs[1]['low'] = True
             elif rc != L.EINVAL:
                 L.check(rc, 'myolo_seg_upce_fwd_grad')
+        # K15 for OhemCELoss (loss.py:303-328): per-pixel losses from the low-resolution logits (the only full-resolution tensor: fp32
+        # [n,H,W]), hard-pixel selection on the device, then the selected pixels' gradient folded into the low-resolution map
+        ctx.ohem_sel = None
+        if (FUSED_UPCE and FUSED_CE and pix is not None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
+                and low is not None and g32 is not None and low.shape[3] == 19 and low.stride(3) == 1 and low.dtype == logits.dtype
+                and not gs[1].get('low', True)):
+            ld = L.Tensor(low.data_ptr(), low.shape[0], low.shape[1], low.shape[2], low.shape[3], low.stride(0), low.stride(1),
+                          low.stride(2), L.DT[low.dtype], 0)
+            rc = lib.myolo_seg_upce_ohem_pix(C.byref(ld), h, w, L.ptr(target), int(ignore_index), L.ptr(acc), L.ptr(pix), st)
+            if rc == 0:
+                sel = torch.empty(4, dtype=torch.float32, device=dev)
+                scratch = torch.empty(5, dtype=torch.float64, device=dev)
+                ws = torch.empty(2052, dtype=torch.int32, device=dev)
+                L.check(lib.myolo_ohem_select(L.ptr(pix), n * h * w, C.c_float(ohem_thresh), L.ptr(acc), L.ptr(scratch), L.ptr(ws),
+                                              L.ptr(loss), L.ptr(sel), st), 'myolo_ohem_select')
+                L.check(lib.myolo_seg_upce_ohem_grad(C.byref(ld), h, w, L.ptr(target), int(ignore_index), L.ptr(pix), L.ptr(sel),
+                                                     C.c_float(ohem_thresh), L.ptr(g32), st), 'myolo_seg_upce_ohem_grad')
+                ctx.fused, ctx.ohem_sel = gs, sel
+                gs[1]['low'] = True
+                ctx.save_for_backward(logits, target, acc)
+                ctx.pix, ctx.sel, ctx.ignore, ctx.thresh = None, None, int(ignore_index), ohem_thresh
+                return loss.view(())
+            elif rc != L.EINVAL:
+                L.check(rc, 'myolo_seg_upce_ohem_pix')
         if (ctx.fused is None and FUSED_CE and pix is None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
                 and logits.stride() == (h * w * c, 1, w * c, c) and ctx.grad_buf.stride() == logits.stride()
                 and ctx.grad_buf.dtype == logits.dtype and logits.data_ptr() % 16 == 0 and ctx.grad_buf.data_ptr() % 16 == 0):
@@ -111,7 +135,10 @@ class _SegCE(torch.autograd.Function):
         if ctx.fused is not None:
             scale, state = ctx.fused
             gout = go.detach().to(torch.float32).reshape(1).contiguous()
-            L.check(L.lib().myolo_seg_ce_scale(L.ptr(acc), L.ptr(gout), L.ptr(scale), L.stream_ptr()), 'myolo_seg_ce_scale')
+            if ctx.ohem_sel is not None:            # OHEM: the mean runs over the selected pixels (sel = mode, denom, kth, tie weight)
+                scale.copy_(gout / ctx.ohem_sel[1:2])
+            else:
+                L.check(L.lib().myolo_seg_ce_scale(L.ptr(acc), L.ptr(gout), L.ptr(scale), L.stream_ptr()), 'myolo_seg_ce_scale')
             state['fresh'] = True                   # consumed (and reset) by the plan's backward
             return grad, None, None, None
         if grad is None or grad.shape != logits.shape or grad.stride() != logits.stride() or grad.dtype != logits.dtype:

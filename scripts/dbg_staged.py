@@ -7,7 +7,7 @@ from oracle import loss_ref, synth
 from tests.util import CFG, TAGS, synth_sd
 DEV = 'cuda:0'
 def run(staged, flat, passes):
-    R.STAGED_BWD, R.FLAT_ACCUMULATE = staged, flat
+    R.STAGED_BWD, R.FLAT_ACCUMULATE = ('force' if staged else '0'), flat
     torch.manual_seed(0)
     m = Model(os.path.join(CFG, TAGS['s_psp']))
     m.load_state_dict(synth_sd('s_psp'), strict=True)

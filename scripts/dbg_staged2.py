@@ -6,7 +6,7 @@ from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
 from oracle import loss_ref, synth
 from tests.util import CFG, TAGS, synth_sd
 DEV = 'cuda:0'
-R.STAGED_BWD, R.FLAT_ACCUMULATE = True, True
+R.STAGED_BWD, R.FLAT_ACCUMULATE = 'force', True
 torch.manual_seed(0)
 m = Model(os.path.join(CFG, TAGS['s_psp']))
 m.load_state_dict(synth_sd('s_psp'), strict=True)

@@ -1,0 +1,62 @@
+"""worker of tests/test_gpu_dist.py: one rank of a 2-process data-parallel step on ONE GPU (gloo carries the device tensors).  Every rank
+runs a joint det+seg forward/backward on ITS OWN batch with parallel.GradReducer attached (3 slices of the flat gradient buffer, issued as
+the staged backward completes them), then recomputes both ranks' gradients locally without any exchange and checks
+reduced == mean over ranks, parameter by parameter."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', init_method='env://')
+    from multiyolov5_amd.models.yolo import Model
+    from multiyolov5_amd.parallel import GradReducer
+    from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
+    from oracle import loss_ref, synth
+    from tests.util import CFG, TAGS, synth_sd
+    dev = torch.device('cuda', 0)
+    hyp = loss_ref.scaled_hyp(imgsz=128, nc=10, nl=3)
+
+    def grads(seed, reducer_world):
+        m = Model(os.path.join(CFG, TAGS['s_psp']))
+        m.load_state_dict(synth_sd('s_psp'), strict=True)
+        m = m.to(dev).train()
+        m.hyp, m.gr, m.nc = hyp, 1.0, 10
+        red = GradReducer(m, reducer_world) if reducer_world > 1 else None
+        x = synth.synth_images(2, 64, 128, seed=seed).to(dev)
+        t = synth.synth_det_targets(2, 8, 10, seed=seed).to(dev)
+        mk = synth.synth_seg_targets(2, 64, 128, 19, seed=seed).to(dev)
+        det, seg = m(x)
+        loss, _ = ComputeLoss(m)(det, t)
+        (loss * 0.6 + SegmentationLosses()(seg, mk) * 2 * 0.35).backward()
+        if red is not None:
+            red.wait()
+        torch.cuda.synchronize()
+        return {k: p.grad.detach().clone() for k, p in m.named_parameters()}, m
+
+    g_red, m = grads(10 + rank, world)
+    h = [hh for hh in m.__dict__['_plans'].values() if hh.plan.training][0]
+    staged = h.__dict__.get('_stages', (None, None))[1]
+    locals_ = [grads(10 + r, 1)[0] for r in range(world)]
+    worst = 0.0
+    for k in g_red:
+        ref = sum(l[k] for l in locals_) / world
+        err = float((g_red[k] - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        worst = max(worst, err)
+    ok = worst < 5e-5 and staged is not None and len(staged) == 3
+    print(f'rank {rank}: worst relative deviation of the reduced gradient from the mean of the per-rank gradients {worst:.2e}; '
+          f'staged backward: {None if staged is None else [len(s["params"]) for s in staged]} -> {"OK" if ok else "FAIL"}', flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == '__main__':
+    main()

@@ -89,6 +89,19 @@ def _ddp_loop_body(tmp_path):
     segtargets = synth.seg_targets(B, H, W, 19, seed=2).to(DEV)
     w0 = model.module.model[1].conv.weight.detach().clone()
     model.train()
+    # stock DDP learns that a gradient is final from the parameter's AccumulateGrad hook: with the backward cut into a chain of autograd
+    # nodes (runtime.PlanStageFn) the head's hooks must fire BEFORE the launches of the last stage (the backbone) are enqueued
+    from multiyolov5_amd import runtime as _R
+    order = []
+    _orig_stage = _R.PlanStageFn.backward
+
+    def _logged(ctx, *g):
+        order.append(('stage', ctx.k))
+        return _orig_stage(ctx, *g)
+    _R.PlanStageFn.backward = staticmethod(_logged)
+    head_p, stem_p = model.module.model[25].m[0].weight, model.module.model[0].conv.conv.weight
+    head_p.register_post_accumulate_grad_hook(lambda p: order.append(('hook', 'head')))
+    stem_p.register_post_accumulate_grad_hook(lambda p: order.append(('hook', 'stem')))
     accumulate, seen = 2, []
     for ni in range(1, 5):
         with amp.autocast(enabled=True):                                              # train.py:363-370
@@ -110,6 +123,10 @@ def _ddp_loop_body(tmp_path):
             ema.update(model)
         seen.append((float(loss.detach()), float(segloss.detach())))
     assert scaler.get_scale() == 1024.0                                               # no step was skipped for inf/nan
+    first = order[:order.index(('hook', 'stem')) + 1]                                 # the first backward of the run
+    stages = [k for kind, k in first if kind == 'stage']
+    assert stages == [0, 1, 2], order[:12]
+    assert first.index(('hook', 'head')) < first.index(('stage', 1)) < first.index(('stage', 2)) < first.index(('hook', 'stem')), first
     assert float((model.module.model[1].conv.weight - w0).abs().max()) > 0
     assert seen[-1][1] < seen[0][1] and all(torch.isfinite(torch.tensor(s)).all() for s in seen)
     # ---- checkpoint block, train.py:481-499 ----

@@ -451,7 +451,7 @@ def test_adaptive_avgpool_multi_matches_torch(shape, dt):
     outs = [torch.zeros(n, k, k, c, dtype=dt, device=DEV) for k in ks]
     d = lambda t: L.Tensor(t.data_ptr(), t.shape[0], t.shape[1], t.shape[2], t.shape[3], t.stride(0), t.stride(1), t.stride(2), L.DT[dt], 0)
     arr = (L.Tensor * 4)(*[d(o) for o in outs])
-    scratch = torch.zeros(n * sum(k * k for k in ks) * c, dtype=torch.float32, device=DEV)
+    scratch = torch.zeros(8 * n * sum(k * k for k in ks) * c, dtype=torch.float32, device=DEV)
     xdesc = d(xd)
     L.check(L.lib().myolo_adaptive_avgpool_fwd_multi(C.byref(xdesc), arr, 4, L.ptr(scratch), L.stream_ptr()), 'aap_multi')
     xr = x.float().permute(0, 3, 1, 2)

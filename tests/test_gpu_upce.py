@@ -243,3 +243,32 @@ def test_graph_train_segmentation_gradients_match_eager(monkeypatch):
     for a, b in zip(g1, g0):
         den = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) / den <= 5e-4, float((a - b).abs().max()) / den
+
+
+@pytest.mark.parametrize('thresh', [0.7, 0.05], ids=['above_thresh', 'topk'])
+def test_fused_upsample_ohem_matches_the_unfused_path(monkeypatch, thresh):
+    """OhemCELoss (loss.py:303-328) over the low-resolution logits (per-pixel losses -> device selection -> gradient of the hard pixels
+    folded into the low map, no full-resolution logits) against the unfused path on the materialised logits: same loss, same gradients.
+    thresh 0.7 (train.py:287): enough pixels above -log(0.7) -> mean over those; thresh 0.05: fewer than n_min above -log(0.05) ~ 3.0 ->
+    the top-k branch (loss.py:325-326) with its tie handling"""
+    from multiyolov5_amd.utils import loss as loss_mod
+
+    def run(fused):
+        monkeypatch.setattr(loss_mod, 'FUSED_UPCE', fused)
+        mod, xs_cpu, tgt = _psp_head()
+        xs = [x.to(DEV).requires_grad_() for x in xs_cpu]
+        crit = loss_mod.OhemCELoss(thresh=thresh)
+        out = mod(xs)
+        loss = crit(out, tgt)
+        loss.backward()
+        torch.cuda.synchronize()
+        lazy_done = getattr(out, '_myolo_lazy_state', {'done': None})['done']
+        return float(loss), [x.grad.clone() for x in xs] + [p.grad.clone() for p in mod.parameters()], lazy_done
+
+    l1, g1, done1 = run(True)
+    l0, g0, done0 = run(False)
+    assert done1 is False and done0 is True            # the fused path never materialised the x8 logits, the unfused one had to
+    assert abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+    for a, b in zip(g1, g0):
+        den = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) / den <= 5e-4, float((a - b).abs().max()) / den

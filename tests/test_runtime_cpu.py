@@ -29,7 +29,8 @@ def test_training_plan_launch_list_structure():
     assert len(merged) == 9 and all(op.cout == op.weight.shape[0] + op.weight2.shape[0] for op in merged)
     # PyramidPooling: four pools / four upsamples, one backward pass each, one forward launch for the upsamples (common.py:521-537)
     assert fwd['myolo_pyramid_upsample_fwd'] == 1 and bwd['myolo_pyramid_upsample_bwd'] == 1 and bwd['myolo_adaptive_avgpool_bwd_multi'] == 1
-    assert fwd['myolo_adaptive_avgpool_fwd'] == 5 and bwd['myolo_adaptive_avgpool_bwd'] == 1          # (FFM's global pool stays alone)
+    # (8x16 maps are too narrow for the one-pass pyramid pools: four single launches; FFM's lone global pool takes the one-pass kernel)
+    assert fwd['myolo_adaptive_avgpool_fwd'] + fwd['myolo_adaptive_avgpool_fwd_multi'] == 5 and bwd['myolo_adaptive_avgpool_bwd'] == 1
     # the x8 upsample of the logits is deferred; its backward is chosen per step (full-resolution gradient | low-resolution fused CE)
     seg = [op for op in plan.ops if isinstance(op, E.SegOutOp)]
     assert len(seg) == 1 and seg[0].lazy_call is not None and fwd['myolo_seg_upsample_fwd'] == 0
