@@ -234,12 +234,15 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int hw = (TW - 1) * s + 1 + (maxdx - mindx);
   // tallest tile whose two buffer pairs fit in LDS (<= 144 KB), at most 8 rows and not taller than the map
   int th = 0, hh = 0, smem = 0, dbuf = 0, xbuf = 0;
+  // (MYOLO_WGRAD_TILE_LDS_KB: a smaller budget leaves LDS for a main-stream workgroup on the same CU -- the weight gradients run BESIDE the
+  // dgrad / BatchNorm chain; A/B knob)
+  static const int lds_cap = (getenv("MYOLO_WGRAD_TILE_LDS_KB") ? atoi(getenv("MYOLO_WGRAD_TILE_LDS_KB")) : 144) * 1024;
   for (int t = 8; t >= 1; --t) {
     if (t > d->dy.h && t > 1) continue;
     const int h2 = (t - 1) * s + 1 + (maxdy - mindy);
     const int db_ = (t * TW * PD + 15) / 16 * 16, xb_ = (h2 * hw * PX + 15) / 16 * 16;
     const int sm = 2 * (db_ + xb_);
-    if (sm <= 144 * 1024) { th = t; hh = h2; smem = sm; dbuf = db_; xbuf = xb_; break; }
+    if (sm <= lds_cap) { th = t; hh = h2; smem = sm; dbuf = db_; xbuf = xb_; break; }
   }
   if (!th) return -1;
   WgT k;

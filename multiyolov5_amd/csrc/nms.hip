@@ -232,7 +232,9 @@ __device__ __forceinline__ float box_area(const f4_t a) { return __fmul_rn(a[2] 
 // separate float products in the CPU kernel).  Disjoint boxes (in particular boxes of different classes: their offsets differ by
 // >= max_wh) have IoU exactly 0: six min/max/sub and two compares; the division only runs when SOME lane of the wave overlaps.
 __device__ __forceinline__ bool iou_gt(const f4_t a, float aa, const f4_t b, float ab, float thr) {
-  const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]), h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
+  const float w = fminf(a[2], b[2]) - fmaxf(a[0], b[0]);
+  if (!__ballot(w > 0.f)) return 0.f > thr;         // no lane overlaps along x (other classes sit >= max_wh away): done after 3 operations
+  const float h = fminf(a[3], b[3]) - fmaxf(a[1], b[1]);
   const bool ov = w > 0.f && h > 0.f;
   bool r = !ov && (0.f > thr);
   if (__ballot(ov)) {

@@ -146,22 +146,28 @@ __global__ __launch_bounds__(256) void spp_bwd_kernel(myolo_tensor g5, myolo_ten
 constexpr size_t SPP_PLANE_LDS = 64 * 1024;      // dynamic LDS available without opting in
 template <typename T, bool IDX>
 __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(myolo_tensor x, myolo_tensor o5, myolo_tensor o9, myolo_tensor o13,
-                                                            uint8_t* idx) {
+                                                            uint8_t* idx, int band_rows) {
+  // blockIdx.y = a band of `band_rows` output rows (round 3: a batch-1 32x64 plane is 32 workgroups as a whole -- 4 bands x 32 channel
+  // groups fill more of the chip); the tile holds the band plus up to 6 halo rows on each side
   constexpr int SEG = ET<T>::SEG;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int HW = x.h * x.w, W = x.w, H = x.h;
-  T* tile = reinterpret_cast<T*>(smem);                                   // [HW][SEG]
-  T* rv = tile + (size_t)HW * SEG;                                        // [3][HW][SEG] row maxima
-  uint8_t* ri = reinterpret_cast<uint8_t*>(rv + (size_t)3 * HW * SEG);    // [3][HW][SEG] dx index of the row maximum
+  const int W = x.w, H = x.h, HWfull = H * W;
+  const int yb0 = blockIdx.y * band_rows, yb1 = yb0 + band_rows < H ? yb0 + band_rows : H;     // output rows of this workgroup
+  const int ty0 = yb0 - 6 > 0 ? yb0 - 6 : 0, ty1 = yb1 + 6 < H ? yb1 + 6 : H;                  // tile rows
+  const int HW = (ty1 - ty0) * W;                                         // pixels in the tile
+  const int cap = (band_rows + 12) * W;                                   // plane pitch (host allocates for this)
+  T* tile = reinterpret_cast<T*>(smem);                                   // [cap][SEG]
+  T* rv = tile + (size_t)cap * SEG;                                       // [3][cap][SEG] row maxima
+  uint8_t* ri = reinterpret_cast<uint8_t*>(rv + (size_t)3 * cap * SEG);   // [3][cap][SEG] dx index of the row maximum (training only)
   const int G = x.c / SEG;
   const int n = blockIdx.x / G, cg = blockIdx.x - n * G;
   for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-    const int y = p / W, xx = p - y * W;
+    const int y = ty0 + p / W, xx = p % W;
     *reinterpret_cast<uint4*>(tile + (size_t)p * SEG) = ldg16(vptr<T>(x, n, y, xx) + cg * SEG);
   }
   __syncthreads();
   for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-    const int y = p / W, xx = p - y * W;
+    const int yl = p / W, xx = p - yl * W;
     float m5[SEG], m9[SEG], m13[SEG];
     int i5[SEG], i9[SEG], i13[SEG];
 #pragma unroll
@@ -171,7 +177,7 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(myolo_tensor x, myol
       const int ix = xx + dx;
       if (ix < 0 || ix >= W) continue;
       float f[SEG];
-      Vec<T>::unpack(*reinterpret_cast<const uint4*>(tile + (size_t)(y * W + ix) * SEG), f);
+      Vec<T>::unpack(*reinterpret_cast<const uint4*>(tile + (size_t)(yl * W + ix) * SEG), f);
 #pragma unroll
       for (int i = 0; i < SEG; ++i) {
         if (f[i] > m13[i]) { m13[i] = f[i]; i13[i] = dx + 6; }
@@ -179,21 +185,24 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(myolo_tensor x, myol
         if (dx >= -2 && dx <= 2 && f[i] > m5[i]) { m5[i] = f[i]; i5[i] = dx + 2; }
       }
     }
-    *reinterpret_cast<uint4*>(rv + ((size_t)0 * HW + p) * SEG) = Vec<T>::pack(m5);
-    *reinterpret_cast<uint4*>(rv + ((size_t)1 * HW + p) * SEG) = Vec<T>::pack(m9);
-    *reinterpret_cast<uint4*>(rv + ((size_t)2 * HW + p) * SEG) = Vec<T>::pack(m13);
+    *reinterpret_cast<uint4*>(rv + ((size_t)0 * cap + p) * SEG) = Vec<T>::pack(m5);
+    *reinterpret_cast<uint4*>(rv + ((size_t)1 * cap + p) * SEG) = Vec<T>::pack(m9);
+    *reinterpret_cast<uint4*>(rv + ((size_t)2 * cap + p) * SEG) = Vec<T>::pack(m13);
+    if (IDX) {                                       // (eval: no index planes -- their LDS is not even allocated)
 #pragma unroll
-    for (int i = 0; i < SEG; ++i) {
-      ri[((size_t)0 * HW + p) * SEG + i] = (uint8_t)i5[i];
-      ri[((size_t)1 * HW + p) * SEG + i] = (uint8_t)i9[i];
-      ri[((size_t)2 * HW + p) * SEG + i] = (uint8_t)i13[i];
+      for (int i = 0; i < SEG; ++i) {
+        ri[((size_t)0 * cap + p) * SEG + i] = (uint8_t)i5[i];
+        ri[((size_t)1 * cap + p) * SEG + i] = (uint8_t)i9[i];
+        ri[((size_t)2 * cap + p) * SEG + i] = (uint8_t)i13[i];
+      }
     }
   }
   __syncthreads();
-  const int64_t plane = (int64_t)x.n * HW * x.c;
-  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
-    const int y = p / W, xx = p - y * W;
-    const int64_t e = ((int64_t)n * HW + p) * x.c + cg * SEG;
+  const int64_t plane = (int64_t)x.n * HWfull * x.c;
+  const int nout = (yb1 - yb0) * W;
+  for (int p = threadIdx.x; p < nout; p += blockDim.x) {
+    const int y = yb0 + p / W, xx = p % W;
+    const int64_t e = ((int64_t)n * HWfull + (int64_t)y * W + xx) * x.c + cg * SEG;
 #pragma unroll
     for (int w = 0; w < 3; ++w) {
       const int r = 2 + 2 * w, K = 2 * r + 1;
@@ -204,12 +213,12 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(myolo_tensor x, myol
       for (int dy = -r; dy <= r; ++dy) {
         const int iy = y + dy;
         if (iy < 0 || iy >= H) continue;
-        const size_t q = (size_t)w * HW + iy * W + xx;
+        const size_t q = (size_t)w * cap + (iy - ty0) * W + xx;
         float f[SEG];
         Vec<T>::unpack(*reinterpret_cast<const uint4*>(rv + q * SEG), f);
 #pragma unroll
         for (int i = 0; i < SEG; ++i)
-          if (f[i] > m[i]) { m[i] = f[i]; id[i] = (dy + r) * K + ri[q * SEG + i]; }
+          if (f[i] > m[i]) { m[i] = f[i]; if (IDX) id[i] = (dy + r) * K + ri[q * SEG + i]; }
       }
       const myolo_tensor& o = w == 0 ? o5 : (w == 1 ? o9 : o13);
       stg16(vptr<T>(o, n, y, xx) + cg * SEG, Vec<T>::pack(m));
@@ -1169,15 +1178,25 @@ extern "C" int myolo_spp_pool_fwd(const myolo_tensor* x, const myolo_tensor* o5,
   hipStream_t st = (hipStream_t)stream;
   const int HW = x->h * x->w;
   const int es = x->dtype == MYOLO_F16 ? 2 : 4, seg = 16 / es;
-  const size_t smem = (size_t)HW * 16 * 4 + (size_t)3 * HW * seg;            // tile + 3 row-max planes (16 B/pixel) + 3 index planes
-  if (smem <= SPP_PLANE_LDS && !getenv("MYOLO_SPP_NAIVE")) {
-    const int blocks = x->n * (x->c / seg);
+  // tile + 3 row-max planes (16 B/pixel each) + (training only) 3 index planes, for a band of output rows + 12 halo rows; up to 150 KB of
+  // the CU's 160 KB.  Bands: as many as it takes to reach ~256 workgroups (batch-1 planes), each at least 4 rows (halo overhead)
+  const int blocks = x->n * (x->c / seg);
+  int nb = (256 + blocks - 1) / blocks;
+  if (nb > x->h / 4) nb = x->h / 4;
+  if (nb < 1) nb = 1;
+  int band = (x->h + nb - 1) / nb;
+  auto need = [&](int rows) { const size_t px = (size_t)(rows + 12) * x->w; return px * 16 * 4 + (idx ? px * 3 * seg : 0); };
+  while (need(band) > 150 * 1024 && band > 4) band = (band + 1) / 2;
+  nb = (x->h + band - 1) / band;
+  const size_t smem = need(band);
+  if (smem <= 150 * 1024 && !getenv("MYOLO_SPP_NAIVE")) {
+    const dim3 grid(blocks, nb);
     if (x->dtype == MYOLO_F16) {
-      if (idx) hipLaunchKernelGGL((spp_fwd_plane_kernel<half_t, true>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
-      else hipLaunchKernelGGL((spp_fwd_plane_kernel<half_t, false>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
+      if (idx) { auto kern = spp_fwd_plane_kernel<half_t, true>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
+      else { auto kern = spp_fwd_plane_kernel<half_t, false>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
     } else {
-      if (idx) hipLaunchKernelGGL((spp_fwd_plane_kernel<float, true>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
-      else hipLaunchKernelGGL((spp_fwd_plane_kernel<float, false>), dim3(blocks), dim3(256), smem, st, *x, *o5, *o9, *o13, idx);
+      if (idx) { auto kern = spp_fwd_plane_kernel<float, true>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
+      else { auto kern = spp_fwd_plane_kernel<float, false>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
     }
     MYOLO_CHECK_LAUNCH();
     return 0;
