@@ -1,6 +1,4 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for rep in 1 2; do
-for v in "X=0" "MYOLO_WGRAD_TILE_LDS_KB=96" "MYOLO_WGRAD_TILE_LDS_KB=72" "MYOLO_WGRAD_TILE_LDS_KB=48" "MYOLO_WGRAD_TILE_WG=64" "MYOLO_WGRAD_TILE_WG=256" "MYOLO_WGRAD_TILE_LDS_KB=72 MYOLO_WGRAD_TILE_WG=256"; do
-echo -n "$v: "; env $v timeout 600 python bench.py --steps 40 --warmup 10 --no-infer --no-cpu-baseline --no-kernel-timing 2>&1 | tail -1 | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])"
-done; done
+timeout 900 python -m pytest tests/test_gpu_ops.py tests/test_gpu_configs.py -m gpu -q -x --timeout 600 -k "wgrad or block or layer or config" 2>&1 | tail -3 | cut -c1-200
+bash scripts/gpu_ab_lib.sh multiyolov5_amd/lib/ab/libmyolo_row1pipe.so 2>&1 | grep -v Traceback | cut -c1-125
