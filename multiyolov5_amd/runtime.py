@@ -491,7 +491,10 @@ class PlanHolder:
                 with torch.cuda.graph(g):
                     self.plan.run_fwd()
                 st['_graph'] = g
-            except Exception:                                    # noqa: BLE001 -- capture is an optimisation only
+            except Exception as e:                               # noqa: BLE001 -- capture is an optimisation only: eager launch list, loudly once
+                import warnings
+                warnings.warn(f'multiyolov5_amd: hipGraph capture of the eval forward failed ({e!r}); running the launch list eagerly '
+                              '(bench.py reports graph_replayed: false)')
                 st['_graph_failed'] = True
                 self.bind_inputs(tensors)
                 self.plan.run_fwd()

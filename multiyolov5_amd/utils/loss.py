@@ -43,6 +43,7 @@ def _check_target(t, x):
 
 class _SegCE(torch.autograd.Function):
     """mean CE over non-ignored pixels (ohem_thresh None) or OhemCELoss.forward_once (ohem_thresh = -log(p))."""
+    _warned_classes = False
 
     @staticmethod
     def forward(ctx, logits, target, ignore_index, ohem_thresh):
@@ -68,6 +69,11 @@ class _SegCE(torch.autograd.Function):
         # K15: the plan's low-resolution class logits are at hand -> upsample + CE + gradient + transposed upsample in one pass over
         # them; the full-resolution logits are not read and their gradient is never formed
         low, g32 = getattr(logits, '_myolo_low', None), getattr(logits, '_myolo_low_grad', None)
+        if low is not None and g32 is not None and low.shape[3] != 19 and FUSED_UPCE and not _SegCE._warned_classes:
+            import warnings
+            _SegCE._warned_classes = True            # (the perf cliff should be visible: +~0.3 ms per step at 16x512x1024)
+            warnings.warn(f'multiyolov5_amd: the one-pass upsample + cross-entropy kernels are built for 19 classes (Cityscapes); '
+                          f'{low.shape[3]} classes take the materialised-logits path (x8 upsample + CE + its backward as separate passes)')
         if (FUSED_UPCE and FUSED_CE and pix is None and ctx.grad_buf is not None and gs is not None and ctx.needs_input_grad[0]
                 and low is not None and g32 is not None and low.shape[3] == 19 and low.stride(3) == 1 and low.dtype == logits.dtype
                 and not gs[1].get('low', True)):
