@@ -350,7 +350,8 @@ static inline int halo_panel_pitch(int K) {                    // bytes; multipl
 
 static int g_halo_off = -1;          // -1: from the environment (MYOLO_NO_HALO)
 static int g_halo_dbg = 0;
-static int g_halo_min_tiles = -1;    // minimum number of 8x32 tiles (MYOLO_HALO_MIN_TILES, default 16)
+static int g_halo_min_tiles = -1;    // minimum number of workgroup tiles (MYOLO_HALO_MIN_TILES, default 512 = two per CU: below that the
+                                     // 64-row tiles of the LDS-tiled kernel fill the chip better -- 3x3 64->64 at 1x128x256: 23.0 vs 15.7 us, r3 A/B)
 
 int myolo_conv_halo_set(const char* name, int value) {
   if (!strcmp(name, "halo_off")) { g_halo_off = value; return 0; }
@@ -365,7 +366,7 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   using namespace halo;
   *bnb_done = 0;
   if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
-  if (g_halo_min_tiles < 0) g_halo_min_tiles = getenv("MYOLO_HALO_MIN_TILES") ? atoi(getenv("MYOLO_HALO_MIN_TILES")) : 16;
+  if (g_halo_min_tiles < 0) g_halo_min_tiles = getenv("MYOLO_HALO_MIN_TILES") ? atoi(getenv("MYOLO_HALO_MIN_TILES")) : 512;
   if (g_halo_off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
   if (d->ntaps < 2 || d->stride != 1 || d->up_shift != 0 || d->cin_pad % KCH) return -1;
   if (d->x.h != d->y.h || d->x.w != d->y.w) return -1;
@@ -485,6 +486,10 @@ static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream, int* bnb_
   const int nvec = hh * hw * 4;
   if (nvec > 6 * THREADS) return -1;
   const int K = d0->wtaps * d0->cin_pad;
+  // K = 2304 (256 gradient channels): only a 32-wide N tile of the panel fits, dy is staged Cout/32 times and four LDS-tiled launches
+  // measured faster (133 vs 98 us at 16x32x64x256 -> 128, 81 vs 76 us at 16x16x32x256 -> 256; K = 1152: 86 vs 104 us the other way)
+  static const int s2_max_k = getenv("MYOLO_HALO_S2_MAX_K") ? atoi(getenv("MYOLO_HALO_S2_MAX_K")) : 1152;
+  if (K > s2_max_k) return -1;
   const int pitch = halo_panel_pitch(K);
   const int xbuf = hh * hw * 64;
   int bn = 0, smem = 0;

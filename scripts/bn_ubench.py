@@ -1,83 +1,83 @@
-"""graph-captured timing of the three BatchNorm passes (no host launch overhead) next to a plain device copy of the same bytes --
-what a streaming kernel of that size can reach on this part.  usage: python scripts/bn_ubench.py"""
+"""BatchNorm+SiLU forward / backward-reduce / backward-apply launches of the training step (batch 16, 512x1024) through the raw C ABI,
+hipGraph-timed over rotating buffers (> the 256 MB MALL): us per launch and the HBM rate each reaches (fp16: fwd 4 B/element,
+reduce 4 B, apply 6 B; +2 B with the residual / residual-gradient tensor).  usage: python scripts/bn_ubench.py [quick]"""
 import ctypes as C
-import os
 import sys
+
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+sys.path.insert(0, '.')
 from multiyolov5_amd import _lib as L
 
-dev = torch.device('cuda:0')
 lib = L.lib()
-SHAPES = [(16, 256, 512, 32), (16, 128, 256, 64), (16, 64, 128, 128), (16, 64, 128, 64), (16, 32, 64, 128), (16, 16, 32, 512), (16, 16, 32, 256)]
-NB = 6
+dev = 'cuda'
+SHAPES = [(16, 256, 512, 32), (16, 128, 256, 64), (16, 64, 128, 128), (16, 64, 128, 64), (16, 32, 64, 256), (16, 32, 64, 128), (16, 16, 32, 512),
+          (16, 16, 32, 256), (16, 16, 32, 128)]
+if len(sys.argv) > 1 and sys.argv[1] == 'quick':
+    SHAPES = SHAPES[1::3]
 
 
-def view(t):
+def td(t):
     n, h, w, c = t.shape
-    return L.Tensor(L.ptr(t), n, h, w, c, h * w * c, w * c, c, L.DT[t.dtype], 0)
+    return L.Tensor(t.data_ptr(), n, h, w, c, h * w * c, w * c, c, L.F16, 0)
 
 
-def graph_time(fn, iters=24):
-    fn(0)
+def timeit(fn, nbuf, iters=24):
+    sp = L.stream_ptr()
+    for i in range(min(2, nbuf)):
+        fn(i, sp)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
+        spc = L.stream_ptr()
         for i in range(iters):
-            fn(i)
+            fn(i % nbuf, spc)
     g.replay()
     torch.cuda.synchronize()
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    a.record()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     for _ in range(3):
         g.replay()
-    b.record()
+    e1.record()
     torch.cuda.synchronize()
-    return a.elapsed_time(b) * 1e3 / (3 * iters)
+    return e0.elapsed_time(e1) * 1e3 / (3 * iters)
 
 
-print('shape                 MB/tensor |  copy(2 passes)   fwd(2)   fwd-noprologue   reduce(2)   apply(3)  apply-noprologue  [us, GB/s]')
+tot = [0.0, 0.0, 0.0, 0.0]
+print(f'{"shape":22s} {"MB":>7s} | {"fwd us":>7s} {"TB/s":>5s} | {"fwd+res":>7s} {"TB/s":>5s} | {"reduce":>7s} {"TB/s":>5s} | {"apply":>7s} {"TB/s":>5s}')
 for (n, h, w, c) in SHAPES:
-    ys = [(torch.randn(n, h, w, c, device=dev) * 0.5).half() for _ in range(NB)]
-    gs = [(torch.randn(n, h, w, c, device=dev) * 0.1).half() for _ in range(NB)]
-    os_ = [torch.empty_like(ys[0]) for _ in range(NB)]
-    stats = torch.rand(L.STAT_COPIES * 2 * c, device=dev) + 1.0
-    gamma, beta = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
-    saved = torch.cat([torch.randn(c, device=dev) * 0.1, torch.rand(c, device=dev) + 0.5])
-    dsum = torch.zeros(L.STAT_COPIES * 2 * c, device=dev)
-    dgam, dbet = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
-    null = L.Tensor()
-    yd, gd, od = [view(t) for t in ys], [view(t) for t in gs], [view(t) for t in os_]
+    torch.manual_seed(0)
+    by = n * h * w * c * 2
+    nbuf = max(3, min(24, int(600e6 // (3 * by)) + 1))
+    ys = [(torch.randn(n, h, w, c, device=dev) * 1.5 + 0.3).half() for _ in range(nbuf)]
+    gs = [(torch.randn(n, h, w, c, device=dev) * 0.01).half() for _ in range(nbuf)]
+    outs = [torch.empty(n, h, w, c, device=dev, dtype=torch.float16) for _ in range(nbuf)]
+    M = n * h * w
+    stats = torch.zeros(L.STAT_COPIES, 2, c, device=dev)
+    yf = ys[0].float().view(-1, c)
+    stats[0, 0], stats[0, 1] = yf.sum(0), (yf * yf).sum(0)
+    gam, bet = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.1
+    rm, rv, nbt = torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros(1, device=dev, dtype=torch.int64)
+    saved = torch.zeros(2, c, device=dev)
+    dsum = torch.zeros(L.STAT_COPIES, 2, c, device=dev)
+    dg, db = torch.zeros(c, device=dev), torch.zeros(c, device=dev)
+    yd, gd, od = [td(t) for t in ys], [td(t) for t in gs], [td(t) for t in outs]
+    null = L.Tensor(None, 0, 0, 0, 0, 0, 0, 0, 0, 0)
 
-    def cp(i):
-        os_[i % NB].copy_(ys[i % NB])
+    def fwd(i, sp, res=False):
+        L.check(lib.myolo_bn_act_fwd(C.byref(yd[i]), L.ptr(stats), L.ptr(gam), L.ptr(bet), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(saved),
+                                     1e-3, 0.03, L.ACT_SILU, C.byref(gd[i]) if res else C.byref(null), C.byref(od[i]), sp))
 
-    def fwd(i):
-        k = i % NB
-        L.check(lib.myolo_bn_act_fwd(C.byref(yd[k]), L.ptr(stats), L.ptr(gamma), L.ptr(beta), None, None, None, L.ptr(saved),
-                                     C.c_float(1e-3), C.c_float(0.03), 1, C.byref(null), C.byref(od[k]), L.stream_ptr()), 'fwd')
+    def red(i, sp):
+        L.check(lib.myolo_bn_act_bwd_reduce(C.byref(gd[i]), C.byref(yd[i]), L.ptr(saved), L.ptr(gam), L.ptr(bet), L.ACT_SILU, L.ptr(dsum), sp))
 
-    def red(i):
-        k = i % NB
-        L.check(lib.myolo_bn_act_bwd_reduce(C.byref(gd[k]), C.byref(yd[k]), L.ptr(saved), L.ptr(gamma), L.ptr(beta), 1, L.ptr(dsum),
-                                            L.stream_ptr()), 'red')
+    def app(i, sp):
+        L.check(lib.myolo_bn_act_bwd_apply(C.byref(gd[i]), C.byref(yd[i]), L.ptr(saved), L.ptr(gam), L.ptr(bet), L.ACT_SILU, L.ptr(dsum), L.ptr(dg),
+                                           L.ptr(db), C.byref(od[i]), C.byref(null), 0, sp))
 
-    def app(i):
-        k = i % NB
-        L.check(lib.myolo_bn_act_bwd_apply(C.byref(gd[k]), C.byref(yd[k]), L.ptr(saved), L.ptr(gamma), L.ptr(beta), 1, L.ptr(dsum),
-                                           L.ptr(dgam), L.ptr(dbet), C.byref(od[k]), C.byref(null), 0, L.stream_ptr()), 'app')
-    def fwd0(i):           # gamma = NULL: activation only, no statistics prologue -> the floor of the streaming part
-        k = i % NB
-        L.check(lib.myolo_bn_act_fwd(C.byref(yd[k]), None, None, None, None, None, None, None, C.c_float(0), C.c_float(0), 1,
-                                     C.byref(null), C.byref(od[k]), L.stream_ptr()), 'fwd0')
-
-    def app0(i):
-        k = i % NB
-        L.check(lib.myolo_bn_act_bwd_apply(C.byref(gd[k]), C.byref(yd[k]), None, None, None, 1, None, None, None, C.byref(od[k]),
-                                           C.byref(null), 0, L.stream_ptr()), 'app0')
-    e = n * h * w * c * 2
-    out = []
-    for f, units in ((cp, 2), (fwd, 2), (fwd0, 2), (red, 2), (app, 3), (app0, 3)):
-        t = graph_time(f)
-        out.append(f'{t:6.1f} {e * units / t / 1e3:5.0f}')
-    print(f'{str((n, h, w, c)):22s} {e / 1e6:6.1f}   | ' + '   '.join(out), flush=True)
+    t = [timeit(fwd, nbuf), timeit(lambda i, sp: fwd(i, sp, True), nbuf), timeit(red, nbuf), timeit(app, nbuf)]
+    bts = [2 * by, 3 * by, 2 * by, 3 * by]
+    for k in range(4):
+        tot[k] += t[k]
+    print(f'{n}x{h}x{w}x{c:<10d} {by / 1e6:7.1f} | ' + ' | '.join(f'{t[k]:7.1f} {bts[k] / t[k] / 1e6:5.2f}' for k in range(4)))
+print('sum us: fwd %.1f fwd+res %.1f reduce %.1f apply %.1f' % tuple(tot))

@@ -138,7 +138,7 @@ def force_halo_kernel():
     from multiyolov5_amd import _lib
     _lib.check(_lib.lib().myolo_set_option(b'halo_min_tiles', 1))
     yield
-    _lib.check(_lib.lib().myolo_set_option(b'halo_min_tiles', 16))
+    _lib.check(_lib.lib().myolo_set_option(b'halo_min_tiles', 512))
 
 
 @pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
