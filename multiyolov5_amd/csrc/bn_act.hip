@@ -34,9 +34,11 @@ __device__ __forceinline__ T* pptr(const myolo_tensor& t, bool dense, const PixD
   return vptr<T>(t, n, yy, xx);
 }
 
-// Thread layout shared by the three passes: a workgroup is G*PPB threads (G = C/SEG channel groups, PPB = 256/G pixels);
-// thread (cg = tid % G, pl = tid / G) always owns channel group cg, so its per-channel constants live in registers and
-// the pixel index advances by a fixed stride -- no division and no table read per 16-byte vector.
+// Thread layout shared by the three passes: a workgroup is G*PPB threads over a SLICE of CW = G*SEG channels (blockIdx.y; CW = C below
+// 128 channels, else 64 = one 128-byte line per pixel) and PPB = 256/G pixels; thread (cg = tid % G, pl = tid / G) always owns channel
+// group cg of the slice, so its per-channel constants live in registers and the pixel index advances by a fixed stride -- no division
+// and no table read per 16-byte vector.  The slice bounds the per-workgroup prologue (2*MYOLO_STAT_COPIES partial sums per channel:
+// 128 loads per thread at C = 512 unsliced, 12.0 us for an 8 MB tensor against 8.0 us at C = 128; r3 bn_ubench).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const float* __restrict__ stats,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -44,10 +46,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
                                                          float mom, int act, myolo_tensor res, myolo_tensor out, int G, int PPB,
                                                          BnSplit sp) {
   constexpr int SEG = ET<T>::SEG;
-  extern __shared__ float tab[];  // [2*C]: scale, shift
-  const int C = y.c;
+  extern __shared__ float tab[];  // [2*CW]: scale, shift of the slice
+  const int C = y.c, CW = G * SEG, c0 = blockIdx.y * CW;
   const int64_t M = (int64_t)y.n * y.h * y.w;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int cl = threadIdx.x; cl < CW; cl += blockDim.x) {
+    const int c = c0 + cl;
     float sc = 1.f, sh = 0.f;
     if (gamma) {
       // the copies are combined and E[x^2] - mean^2 is formed in fp64: the fp32 partial sums are exact to ~1e-7 each, the
@@ -76,16 +79,17 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
         }
       }
     }
-    tab[c] = sc;
-    tab[C + c] = sh;
+    tab[cl] = sc;
+    tab[CW + cl] = sh;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt && gamma) *nbt += 1;
-  if (blockIdx.x == 0 && threadIdx.x == 1 && sp.nbt2 && gamma && sp.cs < C) *sp.nbt2 += 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt && gamma) *nbt += 1;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 1 && sp.nbt2 && gamma && sp.cs < C) *sp.nbt2 += 1;
   __syncthreads();
   const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  const int co = c0 + cg * SEG;          // first channel of this thread's 16-byte vector
   float sc[SEG], sh[SEG];
 #pragma unroll
-  for (int i = 0; i < SEG; ++i) { sc[i] = tab[cg * SEG + i]; sh[i] = tab[C + cg * SEG + i]; }
+  for (int i = 0; i < SEG; ++i) { sc[i] = tab[cg * SEG + i]; sh[i] = tab[CW + cg * SEG + i]; }
   const PixDec pd(y);
   const bool dense = pix_dense(y) && pix_dense(out) && (!res.ptr || pix_dense(res));
   const int64_t stride = (int64_t)gridDim.x * PPB;
@@ -93,9 +97,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
     const int64_t pix2 = pix + stride;
     const bool has2 = pix2 < M;
     const int64_t q = has2 ? pix2 : pix;
-    const uint4 r1 = ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), r2 = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG);
+    const uint4 r1 = ldg16(pptr<T>(y, dense, pd, pix) + co), r2 = ldg16(pptr<T>(y, dense, pd, q) + co);
     uint4 a1 = uint4{0u, 0u, 0u, 0u}, a2 = a1;
-    if (res.ptr) { a1 = ldg16(pptr<T>(res, dense, pd, pix) + cg * SEG); a2 = ldg16(pptr<T>(res, dense, pd, q) + cg * SEG); }
+    if (res.ptr) { a1 = ldg16(pptr<T>(res, dense, pd, pix) + co); a2 = ldg16(pptr<T>(res, dense, pd, q) + co); }
     float f[SEG], f2[SEG];
     Vec<T>::unpack(r1, f); Vec<T>::unpack(r2, f2);
 #pragma unroll
@@ -106,8 +110,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
 #pragma unroll
       for (int i = 0; i < SEG; ++i) { f[i] += g[i]; f2[i] += g2[i]; }
     }
-    stg16(pptr<T>(out, dense, pd, pix) + cg * SEG, Vec<T>::pack(f));
-    if (has2) stg16(pptr<T>(out, dense, pd, pix2) + cg * SEG, Vec<T>::pack(f2));
+    stg16(pptr<T>(out, dense, pd, pix) + co, Vec<T>::pack(f));
+    if (has2) stg16(pptr<T>(out, dense, pd, pix2) + co, Vec<T>::pack(f2));
   }
 }
 
@@ -122,13 +126,14 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
                                                                 int G, int PPB, BnSplit sp) {
   constexpr int SEG = ET<T>::SEG;
   extern __shared__ float red[];  // [PPB][G*SEG*2]
-  const int C = y.c;
+  const int C = y.c, c0 = blockIdx.y * (G * SEG);
   const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  const int co = c0 + cg * SEG;
   const int64_t M = (int64_t)y.n * y.h * y.w;
   float sc[SEG], sh[SEG], mean[SEG], istd[SEG], s0[SEG], s1[SEG];
 #pragma unroll
   for (int i = 0; i < SEG; ++i) {
-    const int c = cg * SEG + i;
+    const int c = co + i;
     mean[i] = saved[c]; istd[i] = saved[C + c];
     const bool lo = c < sp.cs;
     const int cc = lo ? c : c - sp.cs;
@@ -147,8 +152,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
       const int64_t pk = pix + k * stride;
       const int64_t q = pk < M ? pk : pix;                    // clamped: the loads stay unconditional, the weight masks
       wk[k] = pk < M ? 1.f : 0.f;
-      ry[k] = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG);
-      rg[k] = ldg16(pptr<T>(gout, dense, pd, q) + cg * SEG);
+      ry[k] = ldg16(pptr<T>(y, dense, pd, q) + co);
+      rg[k] = ldg16(pptr<T>(gout, dense, pd, q) + co);
     }
 #pragma unroll
     for (int k = 0; k < NPF; ++k) {
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_reduce_kernel(myolo_tensor gou
   for (int j = threadIdx.x; j < G * SEG * 2; j += blockDim.x) {
     float a = 0.f;
     for (int q = 0; q < PPB; ++q) a += red[(size_t)q * (G * SEG * 2) + j];
-    const int c = j >> 1;
+    const int c = c0 + (j >> 1);
     atomicAdd(dsum + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * C + ((j & 1) ? C + c : c), a);
   }
 }
@@ -185,10 +190,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
   constexpr int SEG = ET<T>::SEG;
   // dx = sc*(dz - k0 - xhat*k1), dz = gout*act'(y*sc + sh), xhat = (y - mean)*invstd, k = dsum/M
   //    = sc*dz + cb*y + cd   with cb = -sc*k1*invstd, cd = -sc*k0 - cb*mean
-  extern __shared__ float tab[];  // [4*C]: sc, sh, cb, cd
-  const int C = y.c;
+  extern __shared__ float tab[];  // [4*CW]: sc, sh, cb, cd of the slice
+  const int C = y.c, CW = G * SEG, c0 = blockIdx.y * CW;
   const int64_t M = (int64_t)y.n * y.h * y.w;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  for (int cl = threadIdx.x; cl < CW; cl += blockDim.x) {
+    const int c = c0 + cl;
     if (gamma) {
       const float mean = saved[c], istd = saved[C + c];
       const bool lo = c < sp.cs;
@@ -199,23 +205,24 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
       for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { d0 += dsum[k * 2 * C + c]; d1 += dsum[k * 2 * C + C + c]; }
       const float k0 = d0 / (float)M, k1 = d1 / (float)M;
       const float cb = -sc * k1 * istd;
-      tab[c] = sc; tab[C + c] = (lo ? beta : sp.beta2)[cc] - mean * sc; tab[2 * C + c] = cb; tab[3 * C + c] = -sc * k0 - cb * mean;
+      tab[cl] = sc; tab[CW + cl] = (lo ? beta : sp.beta2)[cc] - mean * sc; tab[2 * CW + cl] = cb; tab[3 * CW + cl] = -sc * k0 - cb * mean;
       if (blockIdx.x == 0) {
         float* dgp = lo ? dgamma : sp.dgamma2; float* dbp = lo ? dbeta : sp.dbeta2;
         if (dgp) dgp[cc] += d1;
         if (dbp) dbp[cc] += d0;
       }
     } else {
-      tab[c] = 1.f; tab[C + c] = 0.f; tab[2 * C + c] = 0.f; tab[3 * C + c] = 0.f;
+      tab[cl] = 1.f; tab[CW + cl] = 0.f; tab[2 * CW + cl] = 0.f; tab[3 * CW + cl] = 0.f;
     }
   }
   __syncthreads();
   const int cg = threadIdx.x % G, pl = threadIdx.x / G;
+  const int co = c0 + cg * SEG;
   float sc[SEG], sh[SEG], cb[SEG], cd[SEG];
 #pragma unroll
   for (int i = 0; i < SEG; ++i) {
     const int c = cg * SEG + i;
-    sc[i] = tab[c]; sh[i] = tab[C + c]; cb[i] = tab[2 * C + c]; cd[i] = tab[3 * C + c];
+    sc[i] = tab[c]; sh[i] = tab[CW + c]; cb[i] = tab[2 * CW + c]; cd[i] = tab[3 * CW + c];
   }
   const PixDec pd(y);
   const bool dense = pix_dense(y) && pix_dense(gout) && pix_dense(dy) && (!gres.ptr || pix_dense(gres));
@@ -224,10 +231,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
     const int64_t pix2 = pix + stride;
     const bool has2 = pix2 < M;
     const int64_t q = has2 ? pix2 : pix;
-    const uint4 ry = ldg16(pptr<T>(y, dense, pd, pix) + cg * SEG), rg = ldg16(pptr<T>(gout, dense, pd, pix) + cg * SEG);
-    const uint4 ry2 = ldg16(pptr<T>(y, dense, pd, q) + cg * SEG), rg2 = ldg16(pptr<T>(gout, dense, pd, q) + cg * SEG);
+    const uint4 ry = ldg16(pptr<T>(y, dense, pd, pix) + co), rg = ldg16(pptr<T>(gout, dense, pd, pix) + co);
+    const uint4 ry2 = ldg16(pptr<T>(y, dense, pd, q) + co), rg2 = ldg16(pptr<T>(gout, dense, pd, q) + co);
     uint4 ra = uint4{0u, 0u, 0u, 0u}, ra2 = ra;
-    if (gres.ptr && gres_acc) { ra = ldg16(pptr<T>(gres, dense, pd, pix) + cg * SEG); ra2 = ldg16(pptr<T>(gres, dense, pd, q) + cg * SEG); }
+    if (gres.ptr && gres_acc) { ra = ldg16(pptr<T>(gres, dense, pd, pix) + co); ra2 = ldg16(pptr<T>(gres, dense, pd, q) + co); }
     float fy[SEG], fg[SEG], fy2[SEG], fg2[SEG], o[SEG], o2[SEG];
     Vec<T>::unpack(ry, fy); Vec<T>::unpack(rg, fg); Vec<T>::unpack(ry2, fy2); Vec<T>::unpack(rg2, fg2);
 #pragma unroll
@@ -237,8 +244,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
       o[i] = fmaf(sc[i], dz, fmaf(cb[i], fy[i], cd[i]));
       o2[i] = fmaf(sc[i], dz2, fmaf(cb[i], fy2[i], cd[i]));
     }
-    stg16(pptr<T>(dy, dense, pd, pix) + cg * SEG, Vec<T>::pack(o));
-    if (has2) stg16(pptr<T>(dy, dense, pd, pix2) + cg * SEG, Vec<T>::pack(o2));
+    stg16(pptr<T>(dy, dense, pd, pix) + co, Vec<T>::pack(o));
+    if (has2) stg16(pptr<T>(dy, dense, pd, pix2) + co, Vec<T>::pack(o2));
     if (gres.ptr) {
       if (gres_acc) {
         float a[SEG], a2[SEG];
@@ -246,8 +253,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
 #pragma unroll
         for (int i = 0; i < SEG; ++i) { fg[i] += a[i]; fg2[i] += a2[i]; }
       }
-      stg16(pptr<T>(gres, dense, pd, pix) + cg * SEG, Vec<T>::pack(fg));
-      if (has2) stg16(pptr<T>(gres, dense, pd, pix2) + cg * SEG, Vec<T>::pack(fg2));
+      stg16(pptr<T>(gres, dense, pd, pix) + co, Vec<T>::pack(fg));
+      if (has2) stg16(pptr<T>(gres, dense, pd, pix2) + co, Vec<T>::pack(fg2));
     }
   }
 }
@@ -278,6 +285,20 @@ inline BnSplit mk_split(const myolo_bn_split* sp, int C) {
   return b;
 }
 
+
+// channel slice per workgroup (see the thread-layout note above): G vector groups x PPB pixels, ny slices
+struct BnGeom { int G, PPB, ny; };
+inline bool bn_geom(int C, int seg, BnGeom* g) {
+  static const int slice = getenv("MYOLO_BN_SLICE") ? atoi(getenv("MYOLO_BN_SLICE")) : 64;      // 0: never slice
+  int cw = C;
+  if (slice > 0 && slice % seg == 0 && C >= 2 * slice && C % slice == 0) cw = slice;
+  g->G = cw / seg;
+  if (g->G < 1 || g->G > 256) return false;
+  g->PPB = 256 / g->G;
+  g->ny = C / cw;
+  return true;
+}
+
 }  // namespace
 
 extern "C" int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
@@ -291,19 +312,21 @@ extern "C" int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats,
   myolo_tensor r{};
   if (res && res->ptr) { if (!vec_ok(res) || !same_shape(res, y)) return MYOLO_EINVAL; r = *res; }
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
-  const int G = y->c / seg;
-  if (G > 256) return MYOLO_EINVAL;
-  const int PPB = 256 / G;
+  BnGeom gm;
+  if (!bn_geom(y->c, seg, &gm)) return MYOLO_EINVAL;
+  const int G = gm.G, PPB = gm.PPB;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int grid = grid_for(M, PPB * 2, y->c >= 512 ? 256 : 1024);   // two pixels per thread and pass; <= 4 workgroups per CU (1 for wide layers): each one's
-                                                         // prologue sums the MYOLO_STAT_COPIES partial statistics of every channel
-  const size_t smem = (size_t)2 * y->c * sizeof(float);
+  // two pixels per thread and pass; <= 4 workgroups per CU in total (1 for wide UNSLICED layers: each workgroup's prologue sums the
+  // MYOLO_STAT_COPIES partial statistics of every channel it covers)
+  const int cap = (gm.ny == 1 && y->c >= 512) ? 256 : 1024 / gm.ny;
+  const dim3 grid(grid_for(M, PPB * 2, cap > 1 ? cap : 1), gm.ny);
+  const size_t smem = (size_t)2 * G * seg * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
-    hipLaunchKernelGGL(bn_act_fwd_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_act_fwd_kernel<half_t>, grid, dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
                        running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB, bs);
   else
-    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
+    hipLaunchKernelGGL(bn_act_fwd_kernel<float>, grid, dim3(G * PPB), smem, st, *y, stats, gamma, beta, running_mean,
                        running_var, nbt, saved, eps, momentum, act, r, *out, G, PPB, bs);
   MYOLO_CHECK_LAUNCH();
   return 0;
@@ -325,21 +348,24 @@ extern "C" int myolo_bn_act_bwd_reduce_split(const myolo_tensor* gout, const myo
   if (!split_ok(split, y->c, y->dtype == MYOLO_F16 ? 8 : 4, true)) return MYOLO_EINVAL;
   const BnSplit bs = mk_split(split, y->c);
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
-  const int G = y->c / seg;
-  if (G > 256) return MYOLO_EINVAL;
-  const int PPB = 256 / G;
+  BnGeom gm;
+  if (!bn_geom(y->c, seg, &gm)) return MYOLO_EINVAL;
+  const int G = gm.G, PPB = gm.PPB;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  int grid = (int)((M + PPB * 4 - 1) / (PPB * 4));   // >= 4 pixels per thread (one pass of the 4-deep load pipeline)
-  const int cap = y->c >= 512 ? 256 : 512;   // few, long-lived workgroups: the final per-channel atomics (2*C per workgroup) are same-address
-  if (grid > cap) grid = cap;
-  if (grid < 1) grid = 1;
+  int gx = (int)((M + PPB * 4 - 1) / (PPB * 4));   // >= 4 pixels per thread (one pass of the 4-deep load pipeline)
+  // few, long-lived workgroups: the final per-channel atomics (2 per channel of the slice and workgroup) are same-address
+  int cap = ((gm.ny == 1 && y->c >= 512) ? 256 : 512) / gm.ny;
+  if (cap < 1) cap = 1;
+  if (gx > cap) gx = cap;
+  if (gx < 1) gx = 1;
+  const dim3 grid(gx, gm.ny);
   const size_t smem = (size_t)PPB * G * seg * 2 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<half_t>, grid, dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
                        beta, act, dsum, G, PPB, bs);
   else
-    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
+    hipLaunchKernelGGL(bn_act_bwd_reduce_kernel<float>, grid, dim3(G * PPB), smem, st, *gout, *y, saved, gamma,
                        beta, act, dsum, G, PPB, bs);
   MYOLO_CHECK_LAUNCH();
   return 0;
@@ -362,18 +388,19 @@ extern "C" int myolo_bn_act_bwd_apply_split(const myolo_tensor* gout, const myol
   myolo_tensor r{};
   if (gres && gres->ptr) { if (!vec_ok(gres) || !same_shape(gres, y)) return MYOLO_EINVAL; r = *gres; }
   const int seg = y->dtype == MYOLO_F16 ? 8 : 4;
-  const int G = y->c / seg;
-  if (G > 256) return MYOLO_EINVAL;
-  const int PPB = 256 / G;
+  BnGeom gm;
+  if (!bn_geom(y->c, seg, &gm)) return MYOLO_EINVAL;
+  const int G = gm.G, PPB = gm.PPB;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int grid = grid_for(M, PPB * 2, y->c >= 512 ? 256 : 1024);
-  const size_t smem = (size_t)4 * y->c * sizeof(float);
+  const int cap = (gm.ny == 1 && y->c >= 512) ? 256 : 1024 / gm.ny;
+  const dim3 grid(grid_for(M, PPB * 2, cap > 1 ? cap : 1), gm.ny);
+  const size_t smem = (size_t)4 * G * seg * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   if (y->dtype == MYOLO_F16)
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<half_t>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<half_t>, grid, dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
                        act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB, bs);
   else
-    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3(grid), dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
+    hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, grid, dim3(G * PPB), smem, st, *gout, *y, saved, gamma, beta,
                        act, dsum, dgamma, dbeta, *dy, r, gres_accumulate, G, PPB, bs);
   MYOLO_CHECK_LAUNCH();
   return 0;
