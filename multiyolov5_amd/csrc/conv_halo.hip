@@ -9,8 +9,9 @@
 //       ds_read_b128 at (pixel + tap offset); halo pixels are 64-byte rows whose 16-byte segment index is XOR-ed with
 //       2*bit2(pixel), which is conflict-free for the ds_read_b128 lane groups at EVERY pixel alignment (the +-1 / +-d tap shifts);
 //     * keeps the whole weight panel of its N tile ([BN][taps*cin_pad]) in LDS for the life of the (persistent) workgroup;
-//     * issues the MFMA as D^T = W . X^T (lane = pixel, 4 consecutive channels per lane): 8-byte NHWC stores from registers,
-//       BatchNorm statistics accumulated per lane and flushed once per workgroup.
+//     * issues the MFMA as D^T = W . X^T over a row-permuted weight panel (panel_chan, myolo_dev.h: lane = pixel, 8 consecutive
+//       channels per lane across a fragment pair): 16-byte NHWC stores from registers, BatchNorm statistics accumulated per lane and
+//       flushed once per workgroup.
 //   Out-of-image halo pixels and padded channels are masked by the buffer-resource bounds check (no branches, no zero page).
 //   Tiles are dealt in XCD-contiguous ranges (neighbouring tiles share halo rows in one L2).
 //
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
   else for (int t = tid; t < p.ntaps; t += THREADS) sTap[t] = p.tap_off[t];
 
   constexpr int OOB = 0x7fff0000;
+  const bool half_tail = (p.Cout & 4) != 0;      // wave-uniform: the last 8-channel group of the layer is half a group
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.y_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.res ? p.res : p.y), 0, p.res ? p.r_bytes : 0, 0x00020000);
@@ -187,50 +189,46 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
       const int yoff = (n * (int)p.y_sn + oy * (int)p.y_sh + ox * (int)p.y_sw) * 2;
       const int roff = EXTRA ? (n * (int)p.r_sn + oy * (int)p.r_sh + ox * (int)p.r_sw) * 2 : 0;
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) {
-        const int cl = nf * 16 + 4 * lq;
+      for (int q = 0; q < NF / 2; ++q) {
+        // permuted weight-panel rows (panel_chan, myolo_dev.h): fragments 2q, 2q+1 hold channels cl .. cl+7 of this lane's pixel
+        const int cl = q * 32 + 8 * lq;
         const int c0 = tn * BN + cl;
-        float v[4];
+        float v[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v0 = acc[mf][nf][r];
-          acc[mf][nf][r] = 0.f;
-          if (EPI == 0) { v[r] = v0; if (mok && !BNS) { st_s[nf][r] += v0; st_q[nf][r] += v0 * v0; } }
-          else v[r] = act_f(v0 * sT[cl + r] + sT[BN + cl + r], p.act);
-        }
-        const bool ok = mok && c0 < p.Cout;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v0 = acc[mf][2 * q + h][r];
+            acc[mf][2 * q + h][r] = 0.f;
+            if (EPI == 0) { v[4 * h + r] = v0; if (mok && !BNS) { st_s[2 * q + h][r] += v0; st_q[2 * q + h][r] += v0 * v0; } }
+            else v[4 * h + r] = act_f(v0 * sT[cl + 4 * h + r] + sT[BN + cl + 4 * h + r], p.act);
+          }
+        const bool ok8 = mok && c0 + 8 <= p.Cout, ok4 = mok && !ok8 && c0 + 4 <= p.Cout;     // Cout % 4 == 0 (host)
         if (EXTRA) {
-          if (p.res) {
-            const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(rr, ok ? roff + c0 * 2 : OOB, 0, 0);
-            const h4_t gh = *reinterpret_cast<const h4_t*>(&g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)gh[r];
-          }
-          if (p.accumulate) {
-            const u32x2_t g = __builtin_amdgcn_raw_buffer_load_b64(ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
-            const h4_t gh = *reinterpret_cast<const h4_t*>(&g);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)gh[r];
-          }
+          if (p.res) add_h8(v, buf_load_h8(rr, roff + c0 * 2, ok8, ok4, half_tail));
+          if (p.accumulate) add_h8(v, buf_load_h8(ry, yoff + c0 * 2, ok8, ok4, half_tail));
         }
-        h4_t o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-        __builtin_amdgcn_raw_buffer_store_b64(*reinterpret_cast<const u32x2_t*>(&o), ry, ok ? yoff + c0 * 2 : OOB, 0, 0);
+        const u32x4_t o = pack_h8(v);
+        __builtin_amdgcn_raw_buffer_store_b128(o, ry, ok8 ? yoff + c0 * 2 : OOB, 0, 0);
+        if (half_tail) __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{o.x, o.y}, ry, ok4 ? yoff + c0 * 2 : OOB, 0, 0);
         if (BNS) {
           if (sgi >= 0) {                // (wave-uniform) dz = gout * act'(z) of the normalised layer, from its raw output at this pixel
             const BnbSeg& sg = p.bnb.seg[sgi];
-            const bool okb = ok && c0 < sg.c1;
+            const bool okb = ok8 && c0 < sg.c1;                    // segments start and end on N-tile boundaries (bnb_aligned)
             const char* yp = okb ? sg.y + ((int64_t)n * sg.y_sn + (int64_t)oy * sg.y_sh + (int64_t)ox * sg.y_sw + (c0 - sg.c0)) * 2 : zero_page();
-            const u32x2_t yr = ldg8(yp);
-            const h4_t yh = *reinterpret_cast<const h4_t*>(&yr);
+            const uint4 yr = ldg16(yp);
+            const half_t* yh = reinterpret_cast<const half_t*>(&yr);
+            const half_t* oh = reinterpret_cast<const half_t*>(&o);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const float yv = (float)yh[r], g = okb ? (float)o[r] : 0.f;
-              const float dz = g * act_grad_f(fmaf(yv, sT[2 * BN + cl + r], sT[3 * BN + cl + r]), sg.act);
-              st_s[nf][r] += dz;
-              st_q[nf][r] += dz * (yv - sT[cl + r]) * sT[BN + cl + r];
-            }
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const int e = 4 * h + r;
+                const float yv = (float)yh[e], g = okb ? (float)oh[e] : 0.f;
+                const float dz = g * act_grad_f(fmaf(yv, sT[2 * BN + cl + e], sT[3 * BN + cl + e]), sg.act);
+                st_s[2 * q + h][r] += dz;
+                st_q[2 * q + h][r] += dz * (yv - sT[cl + e]) * sT[BN + cl + e];
+              }
           }
         }
       }
@@ -260,7 +258,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
     decode_issue();
     issue();                             // the first halo chunk is in flight while the weight panel is staged
   }
-  if (!(p.dbg & 8)) stage_weight_panel<BN, THREADS>(sB, p.w, tn, p.pitchB, p.cin_pad, p.ntaps, p.wtaps, p.tap_w, tid);
+  if (!(p.dbg & 8)) stage_weight_panel<BN, THREADS, true>(sB, p.w, tn, p.pitchB, p.cin_pad, p.ntaps, p.wtaps, p.tap_w, tid);
   if (nsteps > 0) commit(0);
   __syncthreads();                       // weight panel, tables and the first halo chunk are in LDS
   for (int s = 0; s < nsteps; ++s) {
@@ -297,7 +295,7 @@ __global__ __launch_bounds__(THREADS) void conv_halo_kernel(const ConvH p) {
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o, 64); q2 += __shfl_xor(q2, o, 64); }
         if (l15 == 0) {
-          const int cl = nf * 16 + 4 * lq + r;
+          const int cl = panel_chan(nf * 16 + 4 * lq + r);
           red[wave * 2 * BN + cl] = s;
           red[wave * 2 * BN + BN + cl] = q2;
         }

@@ -149,9 +149,14 @@ static inline int grid_for(int64_t work_items, int threads, int max_blocks = 204
 // weight panel [BN][ntaps*cin_pad] of one N tile -> LDS (64-byte blocks, 16-byte segment XOR-ed with H[(row>>2)&3], H = {0,2,3,1}; row
 // pitch = odd number of 64-byte blocks): U independent 16-byte loads are in flight per thread before the first LDS store (a
 // load -> store loop serialises on one L2 round trip per iteration: ~1 us x 18 iterations for a 3x3 64->64 panel)
-template <int BN, int NT>
+// PERM: panel row R = nf*16 + j holds output channel panel_chan(R) of the N tile instead of channel R.  With D^T = W . X^T a lane holds
+// rows 4*lq .. 4*lq+3 of every 16-row fragment; under this order the rows it holds in fragments 2q and 2q+1 are the 8 CONSECUTIVE
+// channels 32q + 8*lq .. + 7 of its pixel (16-byte stores).  BN must be a multiple of 32.
+__host__ __device__ __forceinline__ int panel_chan(int R) { return (R >> 5) * 32 + 8 * ((R & 15) >> 2) + 4 * ((R >> 4) & 1) + (R & 3); }
+template <int BN, int NT, bool PERM = false>
 __device__ __forceinline__ void stage_weight_panel(char* sB, const char* w, int tn, int pitchB, int cin_pad, int ntaps, int wtaps,
                                                    const int* tap_w, int tid) {
+  static_assert(!PERM || BN % 32 == 0, "permuted panels pair 16-row fragments");
   constexpr int U = 8;
   const int vec_per_tap = cin_pad / 8;
   const int vec_per_row = ntaps * vec_per_tap;
@@ -166,7 +171,7 @@ __device__ __forceinline__ void stage_weight_panel(char* sB, const char* w, int 
       const int vv = ok ? v : 0;
       const int r = vv / vec_per_row; const int q = vv - r * vec_per_row;
       const int t = q / vec_per_tap; const int s2 = q - t * vec_per_tap;
-      tmp[u] = ldg16(w + ((int64_t)((tn * BN + r) * wtaps + tap_w[t]) * cin_pad + s2 * 8) * 2);
+      tmp[u] = ldg16(w + ((int64_t)((tn * BN + (PERM ? panel_chan(r) : r)) * wtaps + tap_w[t]) * cin_pad + s2 * 8) * 2);
       const int g = t * vec_per_tap + s2;
       const int sw = (0x78 >> (((r >> 2) & 3) * 2)) & 3;
       dst[u] = ok ? r * pitchB + (g >> 2) * 64 + (((g & 3) ^ sw) << 4) : -1;
@@ -175,6 +180,34 @@ __device__ __forceinline__ void stage_weight_panel(char* sB, const char* w, int 
     for (int u = 0; u < U; ++u)
       if (dst[u] >= 0) *reinterpret_cast<uint4*>(sB + dst[u]) = tmp[u];
   }
+}
+
+// ---- 8 consecutive fp16 channels of one pixel (the epilogues of the D^T = W . X^T kernels) ----
+__device__ __forceinline__ u32x4_t pack_h8(const float* v) {
+  typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+  u32x4_t o;
+  uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h2v hv; hv.x = (_Float16)v[2 * i]; hv.y = (_Float16)v[2 * i + 1];
+    ow[i] = *reinterpret_cast<const uint32_t*>(&hv);
+  }
+  return o;
+}
+__device__ __forceinline__ void add_h8(float* v, const u32x4_t& g) {
+  const _Float16* gh = reinterpret_cast<const _Float16*>(&g);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] += (float)gh[i];
+}
+// buffer load of a lane's 8 channels: whole (ok8), the first four only (ok4; issued only when the layer has such a group), or zeros
+__device__ __forceinline__ u32x4_t buf_load_h8(__amdgpu_buffer_rsrc_t rs, int off, bool ok8, bool ok4, bool half_tail) {
+  constexpr int OOB_ = 0x7fff0000;
+  u32x4_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, ok8 ? off : OOB_, 0, 0);
+  if (half_tail) {
+    const u32x2_t g2 = __builtin_amdgcn_raw_buffer_load_b64(rs, ok4 ? off : OOB_, 0, 0);
+    g.x |= g2.x; g.y |= g2.y;
+  }
+  return g;
 }
 
 // ---- BatchNorm-backward statistics in a dgrad epilogue (myolo_conv_desc.bnb) ----

@@ -47,12 +47,14 @@ def _oracle_params(sd):
 def _grad_tol(k, tag):
     # parameters upstream of a max-pool (backbone up to SPP.cv1; the Base head's C3SPP.cv1) see ~1e5 pool windows at this resolution,
     # a handful with top-2 values inside the rounding noise of two summation orders: the arg-max of those flips (measured ~2e-3 of the
-    # gradient energy, tests/test_gpu_model.py) -- everything else is held to 1e-3
+    # gradient energy, tests/test_gpu_model.py) -- everything else is held to 1e-3.  WHICH windows flip changes from run to run (the
+    # BatchNorm statistics are fp32 atomics: their last bits depend on the arrival order): 12 runs of config 1 gave 1.2e-3 .. 1.2e-2 on
+    # the worst of these parameters, hence 2.5e-2 here
     upstream = any(k.startswith(f'model.{i}.') for i in range(8)) or k.startswith('model.8.cv1.')
     if tag == 's_base':
         upstream = upstream or any(k.startswith(f'model.{i}.') for i in range(8, 17)) or k.startswith('model.24.m.0.') or \
             k.startswith('model.24.m.1.cv1.') or k.startswith('model.24.m.1.cv2.') or k.startswith('model.24.m.1.m.cv1.')
-    return 1e-2 if upstream else 1e-3
+    return 2.5e-2 if upstream else 1e-3
 
 
 def test_config1_s_base_full_resolution_joint_step_with_dropout_replay():
