@@ -21,6 +21,7 @@
 // Replaces: nn.Conv2d+BatchNorm2d+SiLU (reference models/common.py:34-46, 481-490), Detect.m (yolo.py:211-214),
 // and their dgrad (transposed weights, flipped taps, stride-2 by output parity).
 #include "myolo_dev.h"
+#include <string.h>
 
 namespace {
 
@@ -407,6 +408,14 @@ int launch_conv(const ConvK& k, int grid_x, int ntile_n, hipStream_t st) {
 
 }  // namespace
 
+static int g_ig_bm = 0, g_ig_bn = 0, g_ig_wgs = 0;      // 0: the rules below
+int myolo_conv_igemm_set(const char* name, int value) {
+  if (!strcmp(name, "igemm_bm")) { g_ig_bm = value; return 0; }
+  if (!strcmp(name, "igemm_bn")) { g_ig_bn = value; return 0; }
+  if (!strcmp(name, "igemm_wgs")) { g_ig_wgs = value; return 0; }
+  return MYOLO_EINVAL;
+}
+
 extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   if (!d || !d->x.ptr || !d->y.ptr || !d->w) return MYOLO_EINVAL;
   const int dt = d->x.dtype;
@@ -453,13 +462,22 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   const int64_t M = (int64_t)k.N * k.Ho * k.Wo;
   if (M <= 0 || M > 0x7fffffff) return MYOLO_EINVAL;
   k.M = (int)M;
-  const int bn = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
+  // Tile shape from the number of tiles against the 768-1024 workgroups the chip holds at once (r3 tile sweep, batch-16 layers):
+  //   * <= 256 tiles of 64 x 128 (one per CU or fewer): split N, 64 x 64 tiles (256 -> 256 at 8192 pixels: 11.6 -> 9.9 us);
+  //   * 769 .. 1536 tiles of 64 rows would run a second, one-third-full round: 128-row tiles, one round (256 -> 256 at 32768 pixels:
+  //     26.7 -> 22.4 us; 512 -> 256: 33.3 -> 27.5 us);
+  //   * in between 64-row tiles (twice the workgroups of the 128-row ones on small maps), beyond it 128-row tiles.
+  int bn = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
+  const int64_t mt64 = (M + 63) / 64;
+  if (bn == 128 && mt64 * (d->cout_pad / 128) <= 256) bn = 64;
+  if (g_ig_bn && bn > g_ig_bn && d->cout_pad % g_ig_bn == 0) bn = g_ig_bn;
   const int ntile_n = d->cout_pad / bn;
-  k.bm = ((M + 127) / 128) * ntile_n < 768 ? 64 : 128;      // small maps: 64-row tiles = twice the workgroups
+  k.bm = mt64 * ntile_n > 768 ? 128 : 64;
+  if (g_ig_bm) k.bm = g_ig_bm;
   k.ntile_m = (int)((M + k.bm - 1) / k.bm);
   k.tiles_per_xcd = (k.ntile_m + 7) / 8;
   // persistent grid: ~3 workgroups per CU in total, multiple of 8 (one slot range per XCD)
-  int per_xcd = (768 / ntile_n + 7) / 8;
+  int per_xcd = ((g_ig_wgs ? g_ig_wgs : 768) / ntile_n + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
   const int grid_x = per_xcd * 8;

@@ -238,6 +238,7 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
 // conv_halo.hip: LDS-staged input tiles for k x k stride-1 convolutions; -1 = layer does not qualify
 int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 int myolo_conv_halo_set(const char* name, int value);
+int myolo_conv_igemm_set(const char* name, int value);   // conv_igemm.hip: "igemm_bm", "igemm_bn", "igemm_wgs" (tile-shape experiments)
 // conv_small.hip: split-K kernel for small maps (eval epilogues); -1 = layer does not qualify
 int myolo_conv_small_try(const myolo_conv_desc* d, void* stream);
 int myolo_conv_small_set(const char* name, int value);

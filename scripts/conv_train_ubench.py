@@ -71,6 +71,30 @@ def run(cin, cout, k, s, d, H, W, iters=16, stats_on=True):
     return e0.elapsed_time(e1) * 1e3 / (3 * iters)
 
 
+if os.environ.get('PROBE') == 'igemm':
+    # LDS-tiled kernel on the mid-size layers: tile shape / grid experiments
+    for shp in [(256, 256, 1, 1, 1, 32, 64), (128, 128, 1, 1, 1, 32, 64), (256, 128, 1, 1, 1, 32, 64), (512, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 16, 32),
+                (256, 256, 1, 1, 1, 16, 32), (1024, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 32, 64), (128, 128, 3, 1, 1, 32, 64), (256, 256, 3, 1, 1, 16, 32)]:
+        row = []
+        for bm, bn, wgs in [(0, 0, 0), (64, 0, 0), (128, 0, 0), (64, 64, 0), (128, 64, 0), (64, 0, 1024), (64, 64, 1536), (128, 0, 512)]:
+            for kk, vv in (('igemm_bm', bm), ('igemm_bn', bn), ('igemm_wgs', wgs)):
+                lib.myolo_set_option(kk.encode(), vv)
+            row.append(f'{bm}/{bn}/{wgs}: {run(*shp):.1f}')
+        for kk in ('igemm_bm', 'igemm_bn', 'igemm_wgs'):
+            lib.myolo_set_option(kk.encode(), 0)
+        print(shp, ' | '.join(row), flush=True)
+    sys.exit(0)
+if os.environ.get('PROBE') == 'mintiles':
+    # mid-size layers: LDS-tiled kernel (stream_min_tiles 2048) against the streaming kernel (stream_min_tiles 1)
+    for shp in [(256, 256, 1, 1, 1, 32, 64), (128, 128, 1, 1, 1, 32, 64), (256, 128, 1, 1, 1, 32, 64), (512, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 16, 32),
+                (256, 256, 1, 1, 1, 16, 32), (1024, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 32, 64), (128, 128, 3, 1, 1, 32, 64), (256, 256, 3, 1, 1, 16, 32)]:
+        row = []
+        for mt in (2048, 1):
+            lib.myolo_set_option(b'stream_min_tiles', mt)
+            row.append(f'min_tiles {mt}: {run(*shp):.1f}')
+        lib.myolo_set_option(b'stream_min_tiles', 2048)
+        print(shp, ' | '.join(row), flush=True)
+    sys.exit(0)
 if os.environ.get('PROBE') == 'dbg':
     # streaming kernel with its profiling switches: 1 = no stores, 2 = no activation loads, 3 = neither
     for shp in [(256, 256, 1, 1, 1, 32, 64), (128, 128, 1, 1, 1, 64, 128), (64, 64, 1, 1, 1, 128, 256), (512, 512, 1, 1, 1, 16, 32)]:

@@ -1,12 +1,12 @@
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-for sl in 0 64 0 64 0 64 0 64 0 64; do
-rm -f gpurun_out/parity_log.jsonl
-MYOLO_BN_SLICE=$sl timeout 300 python -m pytest tests/test_gpu_configs.py -x -q -k config1 2>&1 | tail -1 | tr '\n' ' '
-python - <<'PY'
-import json
-rows=[json.loads(l) for l in open('gpurun_out/parity_log.jsonl')]
-c=[r['rel_l2'] for r in rows if r['name'].startswith('cfg1/grad') and r['tol']==1e-2]
-print(' max %.2e' % max(c))
-PY
+cp multiyolov5_amd/lib/libmyolo.so /tmp/new.so
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q 2>&1 | tail -3
+for rep in 1 2; do
+for v in "igemm_old" "X=1"; do
+echo -n "$v: "; env $( [ "$v" = igemm_old ] && echo MYOLO_LIB=$GRAFT_REPO_ROOT/multiyolov5_amd/lib/libmyolo_prev.so || echo X=1) timeout 300 python bench.py --steps 40 --warmup 10 --no-infer --no-cpu-baseline --no-kernel-timing 2>&1 | tail -1 | python -c "import sys,json; print('step ms', json.loads(sys.stdin.read())['ms_per_step'])"
+done; done
+for v in "X=1" ; do
+echo -n "infer $v: "; env $v timeout 300 python bench.py --stage infer --no-cpu-baseline --steps 100 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['value'],1), round(j['stage_ms']['forward'],4))"
+echo -n "infer1024 $v: "; env $v timeout 300 python bench.py --stage infer --infer-size 512 1024 --no-cpu-baseline --steps 100 2>&1 | tail -1 | python -c "import sys,json; j=json.loads(sys.stdin.read()); print(round(j['value'],1), round(j['stage_ms']['forward'],4))"
 done
