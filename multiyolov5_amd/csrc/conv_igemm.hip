@@ -22,6 +22,7 @@
 // and their dgrad (transposed weights, flipped taps, stride-2 by output parity).
 #include "myolo_dev.h"
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int r = 0; r < BROWS; ++r) {
           int brow = lrow + r * 64;
-          if (BN < 64) brow &= (BN - 1);               // BN = 32: the upper half of the threads reloads a valid row (unused)
+          if (BN % 64) brow = brow < BN ? brow : brow - 32;   // BN = 32 / 96: the threads past the last row reload a valid row (unused)
           db[ks * BROWS + r] = ldg16(wbase + ((int64_t)(brow * p.wtaps + wt) * p.cin_pad + c0) * ES);
         }
       }
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(THREADS) void conv_igemm_kernel(const ConvK p) {
 #pragma unroll
         for (int r = 0; r < BROWS; ++r) {
           const int brow = lrow + r * 64;
-          if (BN >= 64 || brow < BN)
+          if (BN % 64 == 0 || brow < BN)
             *reinterpret_cast<uint4*>(sB + buf * B_BYTES + ks * B_PLANE + lds_off2(brow, lseg)) = sb[ks * BROWS + r];
         }
       }
@@ -468,6 +469,9 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   //     26.7 -> 22.4 us; 512 -> 256: 33.3 -> 27.5 us);
   //   * in between 64-row tiles (twice the workgroups of the 128-row ones on small maps), beyond it 128-row tiles.
   int bn = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
+  // 96-wide N tile (fp16): the 96-channel layers of yolov5m are ONE N tile instead of three 32-wide ones that each re-stage the input
+  static const int no96 = getenv("MYOLO_NO_BN96") != nullptr;
+  if (bn == 32 && d->cout_pad % 96 == 0 && dt == MYOLO_F16 && !no96) bn = 96;
   const int64_t mt64 = (M + 63) / 64;
   if (bn == 128 && mt64 * (d->cout_pad / 128) <= 256) bn = 64;
   if (g_ig_bn && bn > g_ig_bn && d->cout_pad % g_ig_bn == 0) bn = g_ig_bn;
@@ -482,11 +486,13 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
   const int grid_x = per_xcd * 8;
   hipStream_t st = (hipStream_t)stream;
-  const bool fold = want_bnb && !d->stats && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && bnb_aligned(d, bn);
+  // (the folded BatchNorm-backward sums need a fixed channel vector per thread: 256 % (BN/8) == 0, not the 96-wide tile)
+  const bool fold = want_bnb && !d->stats && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && bn != 96 && bnb_aligned(d, bn);
   if (fold) bnb_fill(&k.bnb, d);
   int r;
   if (dt == MYOLO_F16) {
     if (bn == 128) r = launch_conv<half_t, 128>(k, grid_x, ntile_n, st);
+    else if (bn == 96) r = launch_conv<half_t, 96>(k, grid_x, ntile_n, st);
     else if (bn == 64) r = launch_conv<half_t, 64>(k, grid_x, ntile_n, st);
     else r = launch_conv<half_t, 32>(k, grid_x, ntile_n, st);
   } else {

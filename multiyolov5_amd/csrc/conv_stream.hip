@@ -381,10 +381,14 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
   // N tile: the weight panel [BN][ntaps*cin_pad] (+16 B row padding) must fit beside the 8 wave-private staging areas
   const int K = d->ntaps * d->cin_pad;
   int bn = 0;
-  const int cands[2] = {64, 32};               // BN = 128 needs > 200 VGPRs with the per-channel statistics: two N tiles instead
-  for (int i = 0; i < 2; ++i) {
+  // BN = 128 needs > 200 VGPRs with the per-channel statistics: two N tiles instead.  96 (yolov5m: 96 / 192 / 384 / 768 channels)
+  // where it means fewer N tiles than 64: every N tile re-streams the activations
+  static const int no96 = getenv("MYOLO_NO_BN96") != nullptr;
+  const int cands[3] = {96, 64, 32};
+  for (int i = 0; i < 3; ++i) {
     const int b = cands[i];
     if (d->cout_pad % b) continue;
+    if (b == 96 && (no96 || (d->cout_pad % 64 == 0 && d->cout_pad / 64 <= d->cout_pad / 96))) continue;
     if (b * panel_pitch(K) + 4 * b * 4 + 256 <= 144 * 1024) { bn = b; break; }
   }
   if (!bn) return -1;
@@ -448,6 +452,7 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
   const int grid_x = per_xcd * 8;
   hipStream_t st = (hipStream_t)stream;
   const bool kb2 = (d->cin_pad % 64) == 0;
+  if (bn == 96) return kb2 ? launch<96, 2>(k, grid_x, ntile_n, smem, st) : launch<96, 1>(k, grid_x, ntile_n, smem, st);
   if (bn == 64) return kb2 ? launch<64, 2>(k, grid_x, ntile_n, smem, st) : launch<64, 1>(k, grid_x, ntile_n, smem, st);
   return kb2 ? launch<32, 2>(k, grid_x, ntile_n, smem, st) : launch<32, 1>(k, grid_x, ntile_n, smem, st);
 }

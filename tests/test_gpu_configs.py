@@ -204,6 +204,12 @@ LAYERS = [
     (64, 64, 3, 1, 3, 64, 128, '24.out.0.branch2.0 (dilation 3)'),
     (64, 32, 1, 1, 1, 128, 256, '2.cv1'),
     (32, 32, 3, 1, 1, 128, 256, '2.m.0.cv2'),
+    # yolov5m widths (48 / 96 / 192 / 384): the 96-wide N tile of the LDS-tiled and streaming kernels
+    (48, 96, 3, 2, 1, 256, 512, 'm.1.conv (96 outputs: one 96-wide N tile)'),
+    (96, 96, 1, 1, 1, 128, 256, 'm.2.cv3'),
+    (96, 96, 3, 1, 1, 64, 128, 'm.4.m.0.cv2 (K=864)'),
+    (192, 192, 1, 1, 1, 64, 128, 'm.4.cv3 (two 96-wide tiles)'),
+    (384, 96, 1, 1, 1, 64, 128, 'm.lab.reduce'),
 ]
 
 
