@@ -21,6 +21,7 @@ from ._lib import Tensor as CT
 GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '0') != '0'
 PACK_TILED = os.environ.get('MYOLO_PACK_TILED', '1') != '0'        # per-forward weight repack through LDS tiles (coalesced OIHW reads)
 LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
+LAZY_SEG_EVAL = os.environ.get('MYOLO_LAZY_SEG_EVAL', '1') != '0'  # eval: same (detect.py's resize + argmax reads the low-resolution logits)
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
@@ -816,7 +817,10 @@ class SegOutOp(Op):
         # training: the full-resolution logits (318 MB at 16x19x512x1024) are consumed by the fused loss from the LOW-resolution map
         # (K15) and nothing reads them -- the upsample is deferred until something other than that loss touches the tensor
         # (runtime.LazySegLogits).  Captured training graphs keep the eager launch.
-        self.lazy_call = up if (plan.training and LAZY_SEG and not GRAPH_TRAIN) else None
+        # eval (detect.py:191-193): utils.general.seg_argmax takes resize + argmax from the low-resolution logits, the 80 MB a 1024x2048
+        # frame's upsample writes are read by nobody (25 us of a 1.19 ms forward); any other consumer triggers the launch as in training
+        lazy = LAZY_SEG and ((plan.training and not GRAPH_TRAIN) or (not plan.training and LAZY_SEG_EVAL))
+        self.lazy_call = up if lazy else None
         if self.lazy_call is None:
             self.fwd_calls.append(up)
         else:

@@ -611,10 +611,12 @@ class PlannedModule(nn.Module):
                     tok = PlanStageFn.apply(h, k, n, 1, tok, *[params[i] for i in stages[k]['params']])
                 outs = PlanStageFn.apply(h, 0, n, 1, tok, *[params[i] for i in stages[0]['params']])
         elif not self.training and GRAPH_EVAL:
-            outs = h.run_graphed(tensors)
+            outs = self._eval_outputs(h, h.run_graphed(tensors))
         else:
             h.bind_inputs(tensors)
             h.plan.run_fwd()
+            if not self.training:
+                return _OutSpec.rebuild(h.out_spec, list(self._eval_outputs(h, h.output_tensors())))
             if self.training:
                 # train mode without autograd (`with torch.no_grad(): model(x)`: BatchNorm recalibration, train-mode validation): the
                 # deferred x8 upsample of the logits has no LazySegLogits wrapper to trigger it -- run it now
@@ -626,6 +628,16 @@ class PlannedModule(nn.Module):
                 h.generation += 1
             outs = h.output_tensors()
         return _OutSpec.rebuild(h.out_spec, list(outs))
+
+    @staticmethod
+    def _eval_outputs(h, outs):
+        """eval forward: an output whose last launch is deferred (the x8 upsample of the class logits, engine.SegOutOp) goes out as a
+        LazySegLogits of THIS forward -- detect.py's resize + argmax (utils.general.seg_argmax) never needs the full-resolution values,
+        anything else materialises them on first use"""
+        if not any(o.__dict__.get('_myolo_lazy') is not None for o in outs):
+            return outs
+        h.generation += 1
+        return PlanFn._wrap_outputs(h)
 
     def invalidate_plans(self):
         self.__dict__.pop('_plans', None)

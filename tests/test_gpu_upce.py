@@ -195,6 +195,39 @@ def test_training_logits_are_materialised_only_on_demand(monkeypatch):
     assert float((ref - vals).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
+def test_eval_logits_are_materialised_only_on_demand(monkeypatch):
+    """eval (detect.py:144-193): the x8 upsample of the logits is deferred -- seg_argmax labels come from the low-resolution logits and
+    equal the argmax of the materialised tensor, which equals the eager path's values bit for bit; an older frame's logits raise"""
+    from multiyolov5_amd import _lib as L, engine as E, runtime as R
+    from multiyolov5_amd.utils.general import seg_argmax
+    mod, xs_cpu, _ = _psp_head()
+    mod.eval()
+    for _ in range(4):                                            # eager warm-up runs, capture, replay: every path returns a lazy tensor
+        with torch.no_grad():
+            out = mod([x.to(DEV) for x in xs_cpu])
+        assert isinstance(out, R.LazySegLogits) and out._myolo_lazy_state['done'] is False
+    lab = seg_argmax(out)
+    assert out._myolo_lazy_state['done'] is False                 # labels without the full-resolution tensor
+    vals = out.float().cpu()                                      # any other use materialises
+    assert out._myolo_lazy_state['done'] is True
+    from tests.test_gpu_model import assert_argmax_exact_or_near_tie
+    assert_argmax_exact_or_near_tie('eval lazy logits', lab.cpu(), vals.argmax(1), vals, 1e-6)
+    with torch.no_grad():
+        out_b = mod([(x * 0.5).to(DEV) for x in xs_cpu])          # never read ...
+        out_c = mod([(x * 0.25).to(DEV) for x in xs_cpu])
+    with pytest.raises(L.MyoloError):
+        out_b.sum()                                               # ... until the plan has moved on to the next frame: no stale data is served
+    assert torch.isfinite(out_c.float()).all()
+    monkeypatch.setattr(E, 'LAZY_SEG_EVAL', False)
+    mod2, _, _ = _psp_head()
+    mod2.eval()
+    with torch.no_grad():
+        ref = mod2([x.to(DEV) for x in xs_cpu])
+    assert not isinstance(ref, R.LazySegLogits)
+    refv = ref.float().cpu()                                      # (the pyramid's average pools sum through fp32 atomics: last-bit differences)
+    assert float((refv - vals).abs().max()) <= 2e-5 * float(refv.abs().max())
+
+
 def test_train_mode_without_autograd_returns_real_logits(monkeypatch):
     """`model.train(); with torch.no_grad(): model(x)` (BatchNorm recalibration, train-mode validation): no LazySegLogits wrapper is
     there to trigger the deferred x8 upsample, so the forward itself must run it -- the logits equal the eager path's"""

@@ -43,11 +43,17 @@ def test_training_plan_launch_list_structure():
     assert plan._pack_call is not None and plan._pack_call.args[3] == 0
 
 
-def test_eval_plan_keeps_the_eager_upsample_and_merges_too():
+def test_eval_plan_defers_the_logit_upsample_and_merges_too(monkeypatch):
     from multiyolov5_amd import engine as E
     plan = _plan(training=False)
     fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
-    assert fwd['myolo_seg_upsample_fwd'] == 1 and fwd['myolo_pyramid_upsample_fwd'] == 1
+    seg = [op for op in plan.ops if isinstance(op, E.SegOutOp)]
+    # detect.py's resize + argmax reads the low-resolution logits (utils.general.seg_argmax): the x8 upsample is deferred in eval too
+    assert fwd['myolo_seg_upsample_fwd'] == 0 and seg[0].lazy_call is not None and fwd['myolo_pyramid_upsample_fwd'] == 1
+    monkeypatch.setattr(E, 'LAZY_SEG_EVAL', False)
+    plan = _plan(training=False)
+    fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
+    assert fwd['myolo_seg_upsample_fwd'] == 1 and all(op.lazy_call is None for op in plan.ops if isinstance(op, E.SegOutOp))
     assert sum(1 for op in plan.ops if isinstance(op, E.ConvOp) and op.weight2 is not None) == 9
     assert not any(op.bwd_calls for op in plan.ops)
 
