@@ -22,6 +22,7 @@ GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '0') != '0'
 PACK_TILED = os.environ.get('MYOLO_PACK_TILED', '1') != '0'        # per-forward weight repack through LDS tiles (coalesced OIHW reads)
 LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
 LAZY_SEG_EVAL = os.environ.get('MYOLO_LAZY_SEG_EVAL', '1') != '0'  # eval: same (detect.py's resize + argmax reads the low-resolution logits)
+EVAL_BRANCH = os.environ.get('MYOLO_EVAL_BRANCH', '1') != '0'      # eval: the segmentation head runs on the side stream beside neck + Detect
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
@@ -1006,6 +1007,7 @@ class Plan:
         return b
 
     def add(self, op):
+        op.branch = getattr(self, 'cur_branch', None)       # set by the model while it emits an independent branch (models/yolo.py)
         self.ops.append(op)
         return op
 
@@ -1130,6 +1132,16 @@ class Plan:
             self._building = i
             op.build(self)
         self._building = None
+        # eval: the launches of a tagged branch go to the side stream (CALL_SIDE: behind everything issued on the main stream so far);
+        # the main stream joins before the first op added after the module's own (the output ops read the branch's results)
+        self._fwd_side = False
+        if not self.training:
+            for op in self.ops:
+                if getattr(op, 'branch', None):
+                    for c in op.fwd_calls:
+                        if isinstance(c, Call):
+                            c.side = True
+                            self._fwd_side = True
         self._build_pack_table()
         self.built = True
         if torch.device(self.device).type == 'cuda':     # a CPU-device plan is a dry build (shape/launch-list checks only)
@@ -1217,8 +1229,14 @@ class Plan:
                 items.append(('memset', self._arena[0], self._used[0] * 4))
             if self._pack_call is not None:
                 items.append(self._pack_call)
-            for op in self.ops:
+            joined = not self._fwd_side
+            for i, op in enumerate(self.ops):
+                if not joined and i >= getattr(self, 'n_emit_ops', len(self.ops)):
+                    items.append(('join',))
+                    joined = True
                 items += list(op.fwd_calls)
+            if not joined:
+                items.append(('join',))
             try:
                 np_ = NativeProg(items, list(self.in_ptr) + list(getattr(self, 'mutable_cells', ())))
             except KeyError:
@@ -1232,7 +1250,7 @@ class Plan:
         if not self.graphable():
             np_ = self._native_fwd() if self.native_ok() else None
             if np_ is not None:
-                np_.run()
+                np_.run(side=self._side_stream().cuda_stream if (self._fwd_side and self.use_side_stream) else None)
             else:
                 self._fwd_body(st, self.ops)
             return

@@ -237,13 +237,27 @@ class Model(PlannedModule):
 
     # ---- graph ------------------------------------------------------------------------------------------
     def _emit_graph(self, plan, x):
-        ys = []
-        for m in self.model:                                   # forward_once (yolo.py:293-316)
-            if m.f != -1:
-                x = ys[m.f] if isinstance(m.f, int) else [x if j == -1 else ys[j] for j in m.f]
-            x = _emit_layer(plan, m, x)
-            ys.append(x if m.i in self.save else None)
-        return x, ys[-2]
+        """forward_once (yolo.py:293-316) as plan ops.  Eval plans issue the segmentation head (the layer before Detect, yolo.py:253;
+        read by nobody but the model output) as soon as its inputs exist and tag its ops for the plan's side stream: it then runs
+        beside the rest of the neck and Detect instead of behind them (detect.py frames are batch 1: most launches of both chains
+        fill a fraction of the chip).  Training plans keep the reference's order."""
+        n = len(self.model)
+        order, seg_i = list(range(n)), n - 2
+        f = self.model[seg_i].f if n >= 3 else None
+        branch = (not plan.training) and E.EVAL_BRANCH and isinstance(f, (list, tuple)) and all(0 <= j < seg_i for j in f) and \
+            not any(seg_i in (g if isinstance(g, (list, tuple)) else [g]) for g in (m.f for m in self.model[seg_i + 1:]))
+        if branch:
+            hoist = max(f)
+            order = list(range(hoist + 1)) + [seg_i] + [i for i in range(hoist + 1, n) if i != seg_i]
+        outs = {-1: x}
+        for i in order:
+            m = self.model[i]
+            at = lambda j: outs[i + j] if j < 0 else outs[j]   # noqa: E731 -- negative `from` indices are relative to the layer (yolo.py:296)
+            xin = at(m.f) if isinstance(m.f, int) else [at(j) for j in m.f]
+            plan.cur_branch = 'seg' if (branch and i == seg_i) else None
+            outs[i] = _emit_layer(plan, m, xin)
+        plan.cur_branch = None
+        return outs[n - 1], outs[n - 2]
 
     def emit(self, plan, x):
         det, seg = self._emit_graph(plan, x)

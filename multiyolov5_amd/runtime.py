@@ -454,6 +454,7 @@ class PlanHolder:
                 plan.add(E.ImportOp(plan, slot, tv))
                 handles.append(tv)
         y = module.emit(plan, _unflatten(spec, handles))
+        plan.n_emit_ops = len(plan.ops)              # ops from here on export the outputs (they may read a side-stream branch)
         self.ospec = _OutSpec(plan)
         self.out_spec = self.ospec.register(y)
         plan.register_params([p for p in module.parameters()])
