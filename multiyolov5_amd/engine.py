@@ -23,6 +23,7 @@ PACK_TILED = os.environ.get('MYOLO_PACK_TILED', '1') != '0'        # per-forward
 LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
 LAZY_SEG_EVAL = os.environ.get('MYOLO_LAZY_SEG_EVAL', '1') != '0'  # eval: same (detect.py's resize + argmax reads the low-resolution logits)
 EVAL_BRANCH = os.environ.get('MYOLO_EVAL_BRANCH', '1') != '0'      # eval: the segmentation head runs on the side stream beside neck + Detect
+TRAIN_BRANCH = os.environ.get('MYOLO_TRAIN_BRANCH', '0') != '0'    # training forward: same (the backward keeps one chain)
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
@@ -1135,7 +1136,7 @@ class Plan:
         # eval: the launches of a tagged branch go to the side stream (CALL_SIDE: behind everything issued on the main stream so far);
         # the main stream joins before the first op added after the module's own (the output ops read the branch's results)
         self._fwd_side = False
-        if not self.training:
+        if not self.training or TRAIN_BRANCH:
             for op in self.ops:
                 if getattr(op, 'branch', None):
                     for c in op.fwd_calls:

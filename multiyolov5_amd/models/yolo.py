@@ -244,7 +244,7 @@ class Model(PlannedModule):
         n = len(self.model)
         order, seg_i = list(range(n)), n - 2
         f = self.model[seg_i].f if n >= 3 else None
-        branch = (not plan.training) and E.EVAL_BRANCH and isinstance(f, (list, tuple)) and all(0 <= j < seg_i for j in f) and \
+        branch = (E.TRAIN_BRANCH if plan.training else E.EVAL_BRANCH) and isinstance(f, (list, tuple)) and all(0 <= j < seg_i for j in f) and \
             not any(seg_i in (g if isinstance(g, (list, tuple)) else [g]) for g in (m.f for m in self.model[seg_i + 1:]))
         if branch:
             hoist = max(f)
