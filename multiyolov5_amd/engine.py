@@ -1245,6 +1245,41 @@ class Plan:
             self._nprog_fwd = np_
         return np_ or None
 
+    def eval_split_progs(self):
+        """eval plan with a side-stream branch (models/yolo.py: the segmentation head): (main program, index of the fork in it, branch
+        program) so that the caller can run the branch WITHOUT joining it back -- detect.py's NMS then runs on the main stream while the
+        head is still busy on the side stream.  None when the plan has no branch, or when something after the module's own ops reads the
+        branch (only Detect's decode launches may follow; the deferred logit upsample has no launch)."""
+        if self.training or not getattr(self, '_fwd_side', False) or not self.native_ok() or not self.use_side_stream:
+            return None
+        n_emit = getattr(self, 'n_emit_ops', len(self.ops))
+        if any(op.fwd_calls and not isinstance(op, DecodeOp) for op in self.ops[n_emit:]):
+            return None
+        cached = self.__dict__.get('_split_progs')
+        if cached is None:
+            main, side = [], []
+            if self._used[0]:
+                main.append(('memset', self._arena[0], self._used[0] * 4))
+            if self._pack_call is not None:
+                main.append(self._pack_call)
+            forked = False
+            for op in self.ops:
+                if getattr(op, 'branch', None) and op.fwd_calls:
+                    if not forked:
+                        main.append(('mark', 'fork'))
+                        forked = True
+                    side += list(op.fwd_calls)          # (their `side` flag falls back to the launch stream: run() gets no side stream)
+                else:
+                    main += list(op.fwd_calls)
+            try:
+                cells = list(self.in_ptr) + list(getattr(self, 'mutable_cells', ()))
+                pm, ps = NativeProg(main, cells), NativeProg(side, cells)
+                cached = (pm, pm.marks['fork'], ps) if forked else False
+            except KeyError:
+                cached = False
+            self._split_progs = cached
+        return cached or None
+
     def run_fwd(self):
         st = L.stream_ptr()
         self._check_pack_table()

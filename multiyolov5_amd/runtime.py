@@ -124,6 +124,7 @@ def materialize(t):
     if st is None or st['done']:
         return t
     holder, op = st['holder'], st['op']
+    holder.wait_branch()
     if holder.generation != st['generation']:
         raise L.MyoloError('segmentation logits of an earlier forward were read after a newer forward of the same module overwrote '
                            "the plan's activations (they are materialised on first use; read them before the next forward, or set "
@@ -428,6 +429,7 @@ def _accumulate_in_place(holder, plan):
 # MYOLO_GRAPH=0 disables it; any capture failure falls back to the eager launch list.
 import os as _os
 GRAPH_EVAL = _os.environ.get('MYOLO_GRAPH', '1') != '0'
+SPLIT_EVAL = _os.environ.get('MYOLO_SPLIT_EVAL', '1') != '0'      # eval graphs: the side-stream branch is not joined inside the forward
 
 
 class PlanHolder:
@@ -488,9 +490,27 @@ class PlanHolder:
                     s_.copy_(t)
                 self.bind_inputs(self._static_in)
                 torch.cuda.synchronize()
+                split = self.plan.eval_split_progs() if SPLIT_EVAL else None
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self.plan.run_fwd()
+                if split is None:
+                    with torch.cuda.graph(g):
+                        self.plan.run_fwd()
+                else:
+                    # three graphs: main chain up to the fork | rest of the main chain (neck tail, Detect) | the branch (segmentation head),
+                    # replayed on the plan's side stream behind the fork and NOT joined: what the caller enqueues next on the main stream
+                    # (detect.py: non_max_suppression) runs beside the head; the head's consumers wait for `_branch_done`
+                    pm, fork, ps = split
+                    side = self.plan._side_stream()
+                    gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        pm.run(0, fork)
+                    with torch.cuda.graph(gb):
+                        pm.run(fork, pm.n)
+                    with torch.cuda.graph(gc, stream=side):
+                        ps.run()
+                    st['_graph_b'], st['_graph_c'] = gb, gc
+                    st['_fork_ev'], st['_branch_done'] = torch.cuda.Event(), torch.cuda.Event()
+                    st['_branch_pending'] = False
                 st['_graph'] = g
             except Exception as e:                               # noqa: BLE001 -- capture is an optimisation only: eager launch list, loudly once
                 import warnings
@@ -500,11 +520,34 @@ class PlanHolder:
                 self.bind_inputs(tensors)
                 self.plan.run_fwd()
                 return self.output_tensors()
+        if st.get('_graph_c') is not None:
+            main, side = torch.cuda.current_stream(), self.plan._side_stream()
+            if st['_branch_pending']:
+                main.wait_event(st['_branch_done'])      # the previous frame's head may still be reading the neck features
+            for s_, t in zip(self._static_in, tensors):
+                if s_.data_ptr() != t.data_ptr():
+                    s_.copy_(t)
+            st['_graph'].replay()
+            st['_fork_ev'].record(main)
+            side.wait_event(st['_fork_ev'])
+            with torch.cuda.stream(side):
+                st['_graph_c'].replay()
+                st['_branch_done'].record(side)
+            st['_branch_pending'] = True
+            st['_graph_b'].replay()
+            return self.output_tensors()
         for s_, t in zip(self._static_in, tensors):
             if s_.data_ptr() != t.data_ptr():
                 s_.copy_(t)
         st['_graph'].replay()
         return self.output_tensors()
+
+    def wait_branch(self):
+        """the main stream waits for the un-joined branch of the last eval forward (no-op without one)"""
+        st = self.__dict__
+        if st.get('_branch_pending'):
+            torch.cuda.current_stream().wait_event(st['_branch_done'])
+            st['_branch_pending'] = False
 
     def bind_inputs(self, tensors):
         for i, t in enumerate(tensors):
@@ -636,9 +679,14 @@ class PlannedModule(nn.Module):
         LazySegLogits of THIS forward -- detect.py's resize + argmax (utils.general.seg_argmax) never needs the full-resolution values,
         anything else materialises them on first use"""
         if not any(o.__dict__.get('_myolo_lazy') is not None for o in outs):
+            h.wait_branch()
             return outs
         h.generation += 1
-        return PlanFn._wrap_outputs(h)
+        outs = PlanFn._wrap_outputs(h)
+        for o in outs:
+            if isinstance(o, LazySegLogits):
+                o._myolo_holder = h                      # utils.general.seg_argmax: wait for the un-joined head before reading its logits
+        return outs
 
     def invalidate_plans(self):
         self.__dict__.pop('_plans', None)

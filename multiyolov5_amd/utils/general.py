@@ -104,6 +104,9 @@ def seg_argmax(seg, h0=None, w0=None, out_dtype=torch.int64):
     n, c, H, W = seg.shape
     h0, w0 = int(h0 or H), int(w0 or W)
     low = getattr(seg, '_myolo_low', None)
+    holder = getattr(seg, '_myolo_holder', None)
+    if holder is not None:
+        holder.wait_branch()                                      # eval: the segmentation head may still be running on the plan's side stream
     if low is not None and (h0, w0) == (H, W):
         src = low                                                 # [N,h,w,C] view of the plan's NHWC buffer
     else:

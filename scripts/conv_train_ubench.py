@@ -71,6 +71,11 @@ def run(cin, cout, k, s, d, H, W, iters=16, stats_on=True):
     return e0.elapsed_time(e1) * 1e3 / (3 * iters)
 
 
+if os.environ.get('PROBE') == 'one':
+    # one shape given as PROBE_SHAPE="cin,cout,k,s,d,H,W"
+    shp = tuple(int(v) for v in os.environ['PROBE_SHAPE'].split(','))
+    print(shp, f'{run(*shp):.1f} us with stats, {run(*shp, stats_on=False):.1f} without', flush=True)
+    sys.exit(0)
 if os.environ.get('PROBE') == 'igemm':
     # LDS-tiled kernel on the mid-size layers: tile shape / grid experiments
     for shp in [(256, 256, 1, 1, 1, 32, 64), (128, 128, 1, 1, 1, 32, 64), (256, 128, 1, 1, 1, 32, 64), (512, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 16, 32),

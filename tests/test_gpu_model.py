@@ -66,6 +66,40 @@ def test_eval_fused_fp32_matches_reference_golden(tag):
                                     rseg, eps=1e-4)
 
 
+def test_eval_frames_with_the_unjoined_head_match_the_joined_forward(monkeypatch):
+    """detect.py loop (forward -> NMS -> resize + argmax) over several different frames through the captured eval graphs: with the
+    segmentation head left running on the side stream (three graphs, NMS beside the head) and with everything on one stream --
+    decoded predictions identical, label maps identical (the head's pyramid pools sum through atomics: a near-tie pixel may differ);
+    the cross-frame hazards (next frame's neck overwriting what the previous head still reads) would show as differences"""
+    from multiyolov5_amd import engine as E, runtime as R
+    from multiyolov5_amd.utils.general import non_max_suppression, seg_argmax
+    frames = [synth.synth_images(1, H, W, seed=s).to(DEV, torch.float16) for s in (1, 2, 3, 4, 5, 6)]
+
+    def run(split, branch):
+        monkeypatch.setattr(R, 'SPLIT_EVAL', split)
+        monkeypatch.setattr(E, 'EVAL_BRANCH', branch)
+        m, _ = build('s_psp')
+        m.half().fuse().eval()
+        outs = []
+        with torch.no_grad():
+            for x in frames + frames[:2]:                           # (warm-up runs, capture, then replays)
+                (pred, _raw), seg = m(x)
+                det = non_max_suppression(pred, 0.001, 0.6)
+                lab = seg_argmax(seg, H, W)
+                outs.append((pred.float().cpu().clone(), [d.float().cpu().clone() for d in det], lab.cpu().clone()))
+        holders = list(m.__dict__['_plans'].values())
+        return outs, holders
+
+    a, ha = run(True, True)
+    assert all(h.__dict__.get('_graph_c') is not None for h in ha)                # the three-graph path really ran
+    b, hb = run(False, False)
+    assert all(h.__dict__.get('_graph') is not None and h.__dict__.get('_graph_c') is None for h in hb)
+    for i, ((pa, da, la), (pb, db, lb)) in enumerate(zip(a, b)):
+        assert torch.equal(pa, pb), f'frame {i}: decoded predictions differ'
+        assert len(da) == len(db) and all(torch.equal(u, v) for u, v in zip(da, db)), f'frame {i}: NMS rows differ'
+        assert int((la != lb).sum()) <= 1e-4 * la.numel(), f'frame {i}: {int((la != lb).sum())} label pixels differ'
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16], ids=['f32', 'f16'])
 @pytest.mark.parametrize('tag', ['s_psp', 's_lab', 's_bise', 's_base', 'm_lab'])
 def test_train_forward_backward_vs_oracle(tag, dtype):

@@ -61,8 +61,8 @@ def test_eval_plan_defers_the_logit_upsample_and_merges_too(monkeypatch):
 def test_lazy_logits_materialise_on_first_real_use_only():
     from multiyolov5_amd import _lib as L
     from multiyolov5_amd import runtime as R
-    launches = []
-    holder = SimpleNamespace(generation=3)
+    launches, joins = [], []
+    holder = SimpleNamespace(generation=3, wait_branch=lambda: joins.append(len(launches)))   # (eval: the un-joined head is waited for first)
     op = SimpleNamespace(lazy_call=lambda st: launches.append(st))
     base = torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4)
     t = base.detach().as_subclass(R.LazySegLogits)
@@ -74,6 +74,7 @@ def test_lazy_logits_materialise_on_first_real_use_only():
         assert t.numel() == 24 and t.is_contiguous() and not t.requires_grad and t.device.type == 'cpu'
         assert launches == []                                         # metadata only: nothing launched
         s = t.sum()
+        assert joins == [0]                                           # ... after the branch was joined, before the launch
         assert launches == ['stream'] and type(s) is torch.Tensor and float(s) == float(base.sum())
         (t * 2).float()
         assert launches == ['stream']                                 # once
