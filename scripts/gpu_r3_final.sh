@@ -1,6 +1,6 @@
 # round-3 measurement run: full parity suite, smoke, the bench line, rocprofv3 stats + the two PMC passes of the same command, inference
 # profiles at both sizes, 2 ranks on one GPU.  usage: bash scripts/gpu_r3_final.sh <tag>
-TAG=${1:-r3g}
+TAG=${1:-r3h}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
