@@ -318,7 +318,8 @@ extern "C" int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats,
   const int64_t M = (int64_t)y->n * y->h * y->w;
   // two pixels per thread and pass; <= 4 workgroups per CU in total (1 for wide UNSLICED layers: each workgroup's prologue sums the
   // MYOLO_STAT_COPIES partial statistics of every channel it covers)
-  const int cap = (gm.ny == 1 && y->c >= 512) ? 256 : 1024 / gm.ny;
+  static const int wgs = getenv("MYOLO_BN_WGS_FWD") ? atoi(getenv("MYOLO_BN_WGS_FWD")) : 1024;
+  const int cap = (gm.ny == 1 && y->c >= 512) ? 256 : wgs / gm.ny;
   const dim3 grid(grid_for(M, PPB * 2, cap > 1 ? cap : 1), gm.ny);
   const size_t smem = (size_t)2 * G * seg * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
@@ -354,7 +355,8 @@ extern "C" int myolo_bn_act_bwd_reduce_split(const myolo_tensor* gout, const myo
   const int64_t M = (int64_t)y->n * y->h * y->w;
   int gx = (int)((M + PPB * 4 - 1) / (PPB * 4));   // >= 4 pixels per thread (one pass of the 4-deep load pipeline)
   // few, long-lived workgroups: the final per-channel atomics (2 per channel of the slice and workgroup) are same-address
-  int cap = ((gm.ny == 1 && y->c >= 512) ? 256 : 512) / gm.ny;
+  static const int wgs = getenv("MYOLO_BN_WGS_REDUCE") ? atoi(getenv("MYOLO_BN_WGS_REDUCE")) : 512;
+  int cap = ((gm.ny == 1 && y->c >= 512) ? 256 : wgs) / gm.ny;
   if (cap < 1) cap = 1;
   if (gx > cap) gx = cap;
   if (gx < 1) gx = 1;
@@ -392,7 +394,8 @@ extern "C" int myolo_bn_act_bwd_apply_split(const myolo_tensor* gout, const myol
   if (!bn_geom(y->c, seg, &gm)) return MYOLO_EINVAL;
   const int G = gm.G, PPB = gm.PPB;
   const int64_t M = (int64_t)y->n * y->h * y->w;
-  const int cap = (gm.ny == 1 && y->c >= 512) ? 256 : 1024 / gm.ny;
+  static const int wgs = getenv("MYOLO_BN_WGS_APPLY") ? atoi(getenv("MYOLO_BN_WGS_APPLY")) : 1024;
+  const int cap = (gm.ny == 1 && y->c >= 512) ? 256 : wgs / gm.ny;
   const dim3 grid(grid_for(M, PPB * 2, cap > 1 ? cap : 1), gm.ny);
   const size_t smem = (size_t)4 * G * seg * sizeof(float);
   hipStream_t st = (hipStream_t)stream;

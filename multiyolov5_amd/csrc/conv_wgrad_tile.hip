@@ -33,12 +33,18 @@ struct WgT {
   int tiles_co, tiles_ci, cout_w, cin_w;
   int x_bytes, d_bytes;
   int dbuf_bytes, xbuf_bytes;        // bytes of one dy / x LDS buffer
+  int pd, px;                        // LDS pixel-row pitches (bytes) of the dy / x tiles
 };
 
 template <int NT, int COF, int CIF>
 __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
   constexpr int CO_T = 32 * COF, CI_T = 32 * CIF;
-  constexpr int PD = CO_T * 2 + 16, PX = CI_T * 2 + 16;       // LDS pixel-row pitches (bytes)
+  // LDS pixel-row pitches (bytes): an ODD number of 32-byte units per pixel step (dy and stride-1 x: row + 32; stride-2 x: row + 16, the
+  // step is two rows).  A 32-lane group of a transpose read fetches 32-byte pieces of EIGHT CONSECUTIVE pixel steps (K index
+  // 8g + 4h + k' <-> pixel 4g + k' + 16h, the same bijection for both operands): 8 x odd x 32 B covers the 64 banks exactly once at
+  // every base alignment (the tap shifts).  With pixels 8g + k' + 4h and pitch row + 16 the group read pixels {0-3, 8-11} whose
+  // pieces overlapped pairwise: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.33 (1x1) .. 0.50 (3x3), r3 PMC pass.
+  const int PD = p.pd, PX = p.px;
   constexpr int DV = CO_T / 8, XV = CI_T / 8;                  // 16-byte vectors per pixel
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sD = smem;                                  // [2][TH*32][PD]
@@ -119,11 +125,11 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
     for (int i = 0; i < COF; ++i)
 #pragma unroll
       for (int j = 0; j < CIF; ++j) acc[t][i][j] = f4_t{0.f, 0.f, 0.f, 0.f};
-  // transpose-read lane map (see conv_wgrad.hip): within a 16-lane group lane (4*k'+q) supplies the address of pixel (8g + k') (+4h),
+  // transpose-read lane map (see conv_wgrad.hip): within a 16-lane group lane (4*k'+q) supplies the address of pixel (4g + k') (+16h),
   // channels base+4q..4q+3, and receives the 4 consecutive pixels of channel base + (lane&15)
   const int g = lane >> 4, kq = (lane & 15) >> 2, q = lane & 3;
-  const int dlane = (8 * g + kq) * PD + (wr * 16 * COF + q * 4) * 2;
-  const int xlane = (8 * g + kq) * p.stride * PX + (wc * 16 * CIF + q * 4) * 2;
+  const int dlane = (4 * g + kq) * PD + (wr * 16 * COF + q * 4) * 2;
+  const int xlane = (4 * g + kq) * p.stride * PX + (wc * 16 * CIF + q * 4) * 2;
   __syncthreads();                                    // first tile staged
   for (int i = 0; i < ntl; ++i) {
     const char* bD = sD + (i & 1) * p.dbuf_bytes + dlane;
@@ -135,7 +141,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const fp16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-              (__attribute__((address_space(3))) fp16x4_t*)(bD + (r * TW + 4 * h) * PD + f * 32));
+              (__attribute__((address_space(3))) fp16x4_t*)(bD + (r * TW + 16 * h) * PD + f * 32));
 #pragma unroll
           for (int e = 0; e < 4; ++e) fa[f][4 * h + e] = (half_t)va[e];
         }
@@ -149,7 +155,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
-                (__attribute__((address_space(3))) fp16x4_t*)(bX + poff + 4 * h * p.stride * PX + f * 32));
+                (__attribute__((address_space(3))) fp16x4_t*)(bX + poff + 16 * h * p.stride * PX + f * 32));
 #pragma unroll
             for (int e = 0; e < 4; ++e) fb[f][4 * h + e] = (half_t)vb[e];
           }
@@ -230,7 +236,7 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int big = d->ntaps == 1 ? 4 : 2;          // widest block per workgroup: 128 channels for 1x1, 64 for 3x3 (9 accumulator sets)
   const int cof = cout_w > 64 ? big : (cout_w > 32 ? 2 : 1), cif = cin_w > 64 ? big : (cin_w > 32 ? 2 : 1);
   const int CO_T = 32 * cof, CI_T = 32 * cif;
-  const int PD = CO_T * 2 + 16, PX = CI_T * 2 + 16;
+  const int PD = CO_T * 2 + 32, PX = CI_T * 2 + (s == 1 ? 32 : 16);      // odd 32-byte units per pixel STEP (kernel comment)
   const int hw = (TW - 1) * s + 1 + (maxdx - mindx);
   // tallest tile whose two buffer pairs fit in LDS (<= 144 KB), at most 8 rows and not taller than the map
   int th = 0, hh = 0, smem = 0, dbuf = 0, xbuf = 0;
@@ -265,7 +271,7 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int64_t xb = span(d->x), db = span(d->dy);
   if (xb >= 0x3ffe0000LL || db >= 0x3ffe0000LL) return -1;
   k.x_bytes = (int)xb; k.d_bytes = (int)db;
-  k.dbuf_bytes = dbuf; k.xbuf_bytes = xbuf;
+  k.dbuf_bytes = dbuf; k.xbuf_bytes = xbuf; k.pd = PD; k.px = PX;
   // split-K over tiles: one workgroup per CU at most (the buffers take > 80 KB), at least ~6 tiles per workgroup
   static const int tgt = getenv("MYOLO_WGRAD_TILE_WG") ? atoi(getenv("MYOLO_WGRAD_TILE_WG")) : 128;
   const int want = d->wg_hint > 0 ? d->wg_hint : tgt;
