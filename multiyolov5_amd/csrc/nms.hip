@@ -5,6 +5,7 @@
 //                wave-aggregated compaction into per-image candidate lists
 //   nms_rank   : (lists longer than 8192 only) descending-score rank of every candidate (ties broken by the original row for
 //                determinism); candidates are scattered to their sorted slot, truncated to max_nms (487-488)
+//   (short lists: rank2 / scatter / mask / mscan / merge, class by class on the whole device -- see "SHORT lists" below)
 //   nms_scan   : one workgroup per image; sorts short lists itself (bitonic network over 64-bit keys in LDS), then walks the sorted
 //                list in chunks of 64 against the keep list (see the kernel).  IoU is taken on the class-offset boxes
 //                (box + cls*max_wh, 491-492) with torchvision's formula inter/(a+b-inter), strict '>'; stops once max_det boxes
@@ -13,6 +14,25 @@
 
 namespace {
 
+// ---- per-image side data of the matrix path (short lists): written by the filter, the segment table by nms_rank2's first workgroup ----
+constexpr int NMS_MAXC = 128;                 // classes the segment table distinguishes (class byte of the key & 127 .. nc <= 128 checked on the host)
+constexpr int NMS_COPIES = 32;                // the filter's workgroups add into copy (workgroup % 32): same-address atomics retire at ~110 ns each,
+                                              // 504 workgroups on ONE counter per class made the filter 51 us instead of 11
+constexpr int NMS_AUX_HIST = 0;               // [NMS_COPIES][NMS_MAXC] candidates per class
+constexpr int NMS_AUX_HI = NMS_COPIES * NMS_MAXC;     // [NMS_COPIES] max(x2, y2) over the candidates, order-preserving unsigned encoding (0 = -inf)
+constexpr int NMS_AUX_NLO = NMS_AUX_HI + NMS_COPIES;  // [NMS_COPIES] max(-x1, -y1)
+constexpr int NMS_AUX_KCOUNT = NMS_AUX_NLO + NMS_COPIES;      // boxes kept so far (all segments)
+constexpr int NMS_AUX_OK = NMS_AUX_KCOUNT + 1;        // 1: the matrix path owns this image (else the lazy scan kernel does)
+constexpr int NMS_AUX_NSEG = NMS_AUX_KCOUNT + 2;
+constexpr int NMS_AUX_SEG = NMS_AUX_KCOUNT + 8;       // [NMS_MAXC][2] segment s: first sorted slot (64-aligned), candidates
+constexpr int NMS_AUX_CSEG = NMS_AUX_SEG + 2 * NMS_MAXC;    // [NMS_MAXC][2] class c: its segment, candidates of the classes sorted before it
+constexpr int NMS_AUX_INTS = NMS_AUX_CSEG + 2 * NMS_MAXC;
+__device__ __forceinline__ unsigned int ford(float f) {           // monotonic float -> unsigned
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float funord(unsigned int u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+
 __device__ __forceinline__ float ldp(const void* p, int64_t i, int dt) {
   return dt == MYOLO_F16 ? (float)((const half_t*)p)[i] : ((const float*)p)[i];
 }
@@ -20,7 +40,7 @@ __device__ __forceinline__ float ldp(const void* p, int64_t i, int dt) {
 // class_mask: bit j set = class j passes the `classes=` filter of general.py:476-477 (0 = no filter)
 __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int dt, int A, int no, float conf, int multi,
                                                          int cap, int* counts, float* cand, int* cand_idx, uint64_t class_mask,
-                                                         unsigned long long* keys, int* rank, int64_t pred_bytes) {
+                                                         unsigned long long* keys, int* rank, int64_t pred_bytes, int* aux, int keymode) {
   const int b = blockIdx.y;
   const int nc = no - 5;
   // fp16 predictions (detect.py --half): the reference's `x[:, 5:] *= x[:, 4:5]`, `xywh2xyxy` and threshold compares run in the input
@@ -34,6 +54,13 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
   // 2048x1024 frame): wave ballots meet in LDS, thread 0 reserves the workgroup's slots, every lane takes its rank.  Called uniformly by
   // all four waves (two barriers per call; the LDS cells alternate between calls so a fast wave cannot overwrite a slow wave's input).
   __shared__ int s_wc[2][4], s_base[2];
+  // matrix path (keys != nullptr): per-class candidate counts and the range of the un-offset coordinates of this image (NmsAux)
+  __shared__ int s_hist[NMS_MAXC];
+  if (aux) {
+    for (int c = threadIdx.x; c < NMS_MAXC; c += 256) s_hist[c] = 0;
+    __syncthreads();
+  }
+  float t_hi = -INFINITY, t_nlo = -INFINITY;
   int call_parity = 0;
   auto append = [&](bool pass, float x1, float y1, float x2, float y2, float sc, int cls, int idx) {
     const unsigned long long m = __ballot(pass);
@@ -54,8 +81,17 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
         float* c = cand + ((int64_t)b * cap + slot) * 6;
         c[0] = x1; c[1] = y1; c[2] = x2; c[3] = y2; c[4] = sc; c[5] = (float)cls;
         cand_idx[(int64_t)b * cap + slot] = idx;
-        // descending order = descending key: score bits (positive floats order like integers), ties broken by the LOWER original row
-        if (keys) keys[(int64_t)b * cap + slot] = ((unsigned long long)__float_as_uint(sc) << 32) | (0xffffffffu - (unsigned)idx);
+        // descending order = descending key: score bits (positive floats order like integers), ties broken by the LOWER original row;
+        // keymode 1: the class on top (class-major order: classes are suppressed independently, see nms_segs below)
+        if (keys)
+          keys[(int64_t)b * cap + slot] = keymode
+              ? ((unsigned long long)(unsigned)cls << 56) | ((unsigned long long)__float_as_uint(sc) << 24) | (unsigned long long)(0xffffffu - (unsigned)idx)
+              : ((unsigned long long)__float_as_uint(sc) << 32) | (0xffffffffu - (unsigned)idx);
+        if (aux) {
+          atomicAdd(&s_hist[cls & (NMS_MAXC - 1)], 1);
+          t_hi = fmaxf(t_hi, fmaxf(x2, y2));
+          t_nlo = fmaxf(t_nlo, fmaxf(-x1, -y1));
+        }
       }
     }
   };
@@ -100,6 +136,26 @@ __global__ __launch_bounds__(256) void nms_filter_kernel(const void* pred, int d
         if (s > best) { best = s; bj = j; }                        // first maximum (torch.max)
       }
       append(live && best > conf && (!class_mask || ((class_mask >> bj) & 1ull)), x1, y1, x2, y2, best, bj, a);
+    }
+  }
+  if (aux) {
+    __syncthreads();
+    int* ax = aux + (int64_t)b * NMS_AUX_INTS;
+    const int copy = blockIdx.x % NMS_COPIES;
+    for (int c = threadIdx.x; c < NMS_MAXC; c += 256)
+      if (s_hist[c]) atomicAdd(ax + NMS_AUX_HIST + copy * NMS_MAXC + c, s_hist[c]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { t_hi = fmaxf(t_hi, __shfl_xor(t_hi, o, 64)); t_nlo = fmaxf(t_nlo, __shfl_xor(t_nlo, o, 64)); }
+    __shared__ float s_rng[2][4];
+    if (lane == 0) { s_rng[0][threadIdx.x >> 6] = t_hi; s_rng[1][threadIdx.x >> 6] = t_nlo; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float hi = fmaxf(fmaxf(s_rng[0][0], s_rng[0][1]), fmaxf(s_rng[0][2], s_rng[0][3]));
+      const float nlo = fmaxf(fmaxf(s_rng[1][0], s_rng[1][1]), fmaxf(s_rng[1][2], s_rng[1][3]));
+      if (hi > -INFINITY) {
+        atomicMax(reinterpret_cast<unsigned int*>(ax + NMS_AUX_HI + copy), ford(hi));
+        atomicMax(reinterpret_cast<unsigned int*>(ax + NMS_AUX_NLO + copy), ford(nlo));
+      }
     }
   }
 }
@@ -271,7 +327,7 @@ struct KeptBox { f4_t box; float area; int next; int pos; int pad; };     // 32 
 //    (checked here over all candidates; otherwise every box goes to bucket 0 and the walk is exhaustive, like the reference's arithmetic).
 __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* counts, const float* cand, const int* cand_idx,
                                                                 float* sorted, int cap, int max_nms, int max_det, float iou_thr,
-                                                                float max_wh, int agnostic, int lds_sort, float* out, int* nkeep, int dbg, int skip_short) {
+                                                                float max_wh, int agnostic, int lds_sort, float* out, int* nkeep, int dbg, const int* aux) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   f4_t* lbox = reinterpret_cast<f4_t*>(smem);                                              // [LDS_BOXES] offset boxes (after the sort)
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);                  // [SORT_MAX]  (before)
@@ -285,7 +341,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
   const int b = blockIdx.x;
   int m = counts[b];
   if (m > cap) m = cap;
-  if (skip_short && m <= SORT_MAX) return;                          // (the matrix path has this image)
+  if (aux && aux[(int64_t)b * NMS_AUX_INTS + NMS_AUX_OK]) return;   // (the matrix path has this image)
   const bool sort_here = lds_sort && m <= SORT_MAX;
   const float* cb = cand + (int64_t)b * cap * 6;
   float* sb = sorted + (int64_t)b * max_nms * 6;
@@ -454,25 +510,74 @@ __global__ __launch_bounds__(SCAN_THREADS) void nms_scan_kernel(const int* count
 
 // ---- SHORT lists (detect.py: <= 8192 candidates): the pair tests leave the sequential walk altogether ---------------------------
 //   rank2   : descending rank of every candidate, the whole device: [i block] x [j slice] workgroups count keys greater than their own
-//             (keys are unique), partial counts meet in one atomicAdd per (candidate, slice)
-//   scatter : candidates to their sorted slot (general.py:487-488 truncation) + the class-offset boxes (491-492)
-//   mask    : the suppression bit matrix, upper triangle, one 64 x 64 tile per wave and pass: bit j of word (row, cc) = IoU(row, cc*64+j) > thr
-//             -- n^2/2 pair tests spread over all CUs (7.5 k candidates: 28 M tests, ~5 us) instead of ~250 k per 64-box chunk on one CU
-//   mscan   : ONE wave per image walks the chunks with bit operations only and no barrier.  Chunk c needs (1) the OR over all kept rows
-//             of their word c: every lane gathers the words of up to MS_KR kept rows, issued MS_P chunks ahead for the keep list as it stood
-//             then; (2) the contribution of boxes kept during the last MS_P chunks: those chunks' own rows were loaded as a BAND of MS_P+1
-//             words (diagonal + the next MS_P), so a survivor's later words are readlane'd into MS_P scalar accumulators the moment it is
-//             kept; (3) the diagonal words of its own 64 rows (the band's first word).  All loads are address-predictable MS_P chunks
-//             ahead: the dependent chain per chunk is a cross-lane OR, a find-first-set loop and a few readlanes.
+//             (keys are unique), partial counts meet in one atomicAdd per (candidate, slice).  Its first workgroup per image also builds
+//             the SEGMENT TABLE: with the class on top of the key the order is class-major, and classes are suppressed independently
+//             of each other -- box + cls*max_wh (general.py:491-492) cannot overlap across classes as long as the un-offset
+//             coordinates span less than max_wh (checked over all candidates; otherwise, and for lists whose padded length does not
+//             fit, the image is left to the lazy scan kernel).  A segment = one class, its sorted slots start on a multiple of 64
+//   scatter : candidates to their (segment-aligned) sorted slot + the class-offset boxes + the score part of the key
+//   mask    : the suppression bit matrix, upper triangle, one 64 x 64 tile per wave and pass, ONLY tiles inside a segment: with ten classes
+//             a tenth of the n^2/2 pair tests (7.5 k candidates: 46 -> ~8 us)
+//   mscan   : ONE wave per (image, segment) walks the segment's chunks with bit operations only and no barrier (see below); the
+//             segments of an image run side by side (one 7.5 k list: 117 sequential chunks at 0.65 us -> ~12 per class); each appends its
+//             kept slots and their score keys to the image's kept list
+//   merge   : the kept boxes of all classes back into descending-score order (rank by counting among the kept), the first max_det of
+//             them are the output (general.py:494-495) -- a class cannot contribute more than max_det, so each scan stops there
+//   Chunk c of a scan needs (1) the OR over all kept rows of their word c: every lane gathers the words of up to MS_KR kept rows, issued
+//   MS_P chunks ahead for the keep list as it stood then; (2) the contribution of boxes kept during the last MS_P chunks: those chunks'
+//   own rows were loaded as a BAND of MS_P+1 words (diagonal + the next MS_P), so a survivor's later words are readlane'd into MS_P scalar
+//   accumulators the moment it is kept; (3) the diagonal words of its own 64 rows (the band's first word).  All loads are
+//   address-predictable MS_P chunks ahead: the dependent chain per chunk is a cross-lane OR, a find-first-set loop and a few readlanes.
 constexpr int MS_P = 4;
 constexpr int MS_KR = 5;                       // kept rows gathered per lane: max_det <= 64 * MS_KR = 320 (general.py:434 uses 300)
 constexpr int MS_RS = SORT_MAX / 64 + 8;       // mask row stride in 64-bit words (the band may read MS_P words past the last chunk)
+constexpr unsigned long long KEY56 = 0x00ffffffffffffffull;      // score | inverted row: the key without its class byte
 
-__global__ __launch_bounds__(256) void nms_rank2_kernel(const int* counts, const unsigned long long* keys, int cap, int* rank) {
+__global__ __launch_bounds__(256) void nms_rank2_kernel(const int* counts, const unsigned long long* keys, int cap, int* rank, int* aux,
+                                                        int keymode, float max_wh) {
   __shared__ unsigned long long sk[256];
   const int b = blockIdx.z;
   int n = counts[b];
   if (n > cap) n = cap;
+  if (blockIdx.x == 0 && blockIdx.y == 0) {                              // the image's segment table (read by the kernels behind this one)
+    int* ax = aux + (int64_t)b * NMS_AUX_INTS;
+    __shared__ int sh[NMS_MAXC];
+    __shared__ unsigned int srng[2];
+    if (threadIdx.x < NMS_MAXC) {
+      int h = 0;
+#pragma unroll 8
+      for (int k = 0; k < NMS_COPIES; ++k) h += ax[NMS_AUX_HIST + k * NMS_MAXC + threadIdx.x];
+      sh[threadIdx.x] = h;
+    } else if (threadIdx.x < NMS_MAXC + 2) {
+      unsigned int m = 0;
+      for (int k = 0; k < NMS_COPIES; ++k) { const unsigned int v = (unsigned int)ax[(threadIdx.x == NMS_MAXC ? NMS_AUX_HI : NMS_AUX_NLO) + k]; m = v > m ? v : m; }
+      srng[threadIdx.x - NMS_MAXC] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < NMS_MAXC) {
+      // descending key order = descending class: class c sits behind every class above it (each thread sums the classes above its own)
+      const int c = threadIdx.x, h = sh[c];
+      int before = 0, slot = 0, sg = 0;
+      for (int c2 = c + 1; c2 < NMS_MAXC; ++c2) { const int h2 = sh[c2]; before += h2; slot += (h2 + 63) & ~63; sg += h2 > 0 ? 1 : 0; }
+      if (keymode && h > 0) {
+        ax[NMS_AUX_SEG + 2 * sg] = slot; ax[NMS_AUX_SEG + 2 * sg + 1] = h;
+        ax[NMS_AUX_CSEG + 2 * c] = sg; ax[NMS_AUX_CSEG + 2 * c + 1] = before;
+      }
+      if (c == 0) {
+        const float span = funord(srng[0]) + funord(srng[1]);             // max(x2,y2) - min(x1,y1) over the candidates
+        bool ok = n <= SORT_MAX;
+        int nseg = 1;
+        if (keymode && n > 0) {
+          nseg = sg + (h > 0 ? 1 : 0);
+          ok = ok && span < max_wh && slot + ((h + 63) & ~63) <= SORT_MAX && before + h == n;
+        } else if (ok) {                                                  // one segment: plain score order (agnostic / keys without class /
+          ax[NMS_AUX_SEG] = 0; ax[NMS_AUX_SEG + 1] = n;                   // empty list); class -> segment 0, nothing before: the zeroed table
+        }
+        ax[NMS_AUX_NSEG] = ok ? nseg : 0;
+        ax[NMS_AUX_OK] = ok ? 1 : 0;
+      }
+    }
+  }
   if (n > SORT_MAX || (int)blockIdx.x * 256 >= n) return;
   const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
   const unsigned long long* kb = keys + (int64_t)b * cap;
@@ -490,24 +595,31 @@ __global__ __launch_bounds__(256) void nms_rank2_kernel(const int* counts, const
   if (i < n && cnt) atomicAdd(rank + (int64_t)b * cap + i, cnt);
 }
 
-__global__ __launch_bounds__(256) void nms_scatter_kernel(const int* counts, const float* cand, const int* rank, int cap, int max_nms,
-                                                          float max_wh, int agnostic, float* sorted, f4_t* obx) {
+__global__ __launch_bounds__(256) void nms_scatter_kernel(const int* counts, const float* cand, const int* rank, const unsigned long long* keys,
+                                                          int cap, int max_nms, float max_wh, int agnostic, int keymode, const int* aux,
+                                                          float* sorted, f4_t* obx, unsigned long long* skey) {
   const int b = blockIdx.y;
+  const int* ax = aux + (int64_t)b * NMS_AUX_INTS;
+  if (!ax[NMS_AUX_OK]) return;
   int n = counts[b];
   if (n > cap) n = cap;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (n > SORT_MAX || i >= n) return;
-  const int r = rank[(int64_t)b * cap + i];
-  if (r >= max_nms) return;
+  if (i >= n) return;
   const float* c = cand + ((int64_t)b * cap + i) * 6;
   float v[6];
 #pragma unroll
   for (int e = 0; e < 6; ++e) v[e] = c[e];
+  const int cls = (int)v[5] & (NMS_MAXC - 1);
+  const int sg = keymode ? ax[NMS_AUX_CSEG + 2 * cls] : 0, before = keymode ? ax[NMS_AUX_CSEG + 2 * cls + 1] : 0;
+  const int r = ax[NMS_AUX_SEG + 2 * sg] + (rank[(int64_t)b * cap + i] - before);        // slot: segment start + rank inside the class
+  if (r >= max_nms || r >= SORT_MAX) return;
   float* d = sorted + ((int64_t)b * max_nms + r) * 6;
 #pragma unroll
   for (int e = 0; e < 6; ++e) d[e] = v[e];
   const float o = v[5] * (agnostic ? 0.f : max_wh);               // class offset (general.py:491-492), fp32 like the reference
   obx[(int64_t)b * SORT_MAX + r] = f4_t{v[0] + o, v[1] + o, v[2] + o, v[3] + o};
+  const unsigned long long k = keys[(int64_t)b * cap + i];
+  skey[(int64_t)b * SORT_MAX + r] = keymode ? (k & KEY56) : k;
 }
 
 __device__ __forceinline__ float rl_f(float v, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)); }
@@ -516,14 +628,23 @@ __device__ __forceinline__ unsigned long long rl_u64(unsigned long long v, int i
          (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, i);
 }
 
-__global__ __launch_bounds__(256) void nms_mask_kernel(const int* counts, const f4_t* obx, unsigned long long* mask, int cap, int max_nms,
-                                                       float thr) {
+__global__ __launch_bounds__(256) void nms_mask_kernel(const int* aux, const f4_t* obx, unsigned long long* mask, float thr) {
+  __shared__ short wseg[MS_RS];                                     // segment of every 64-slot word (-1: past the last segment)
+  __shared__ int send[NMS_MAXC];                                    // one past the last candidate slot of every segment
   const int b = blockIdx.y;
-  int m = counts[b];
-  if (m > cap) m = cap;
-  if (m > SORT_MAX) return;
-  if (m > max_nms) m = max_nms;
-  const int words = (m + 63) >> 6;
+  const int* ax = aux + (int64_t)b * NMS_AUX_INTS;
+  if (!ax[NMS_AUX_OK]) return;
+  const int nseg = ax[NMS_AUX_NSEG];
+  for (int w = threadIdx.x; w < MS_RS; w += 256) wseg[w] = -1;
+  __syncthreads();
+  for (int sg = threadIdx.x; sg < nseg; sg += 256) {
+    const int s0 = ax[NMS_AUX_SEG + 2 * sg], h = ax[NMS_AUX_SEG + 2 * sg + 1];
+    send[sg] = s0 + h;
+    for (int w = s0 >> 6; w < (s0 + h + 63) >> 6; ++w) wseg[w] = (short)sg;
+  }
+  __syncthreads();
+  const int lastseg = nseg - 1;
+  const int words = nseg > 0 ? (ax[NMS_AUX_SEG + 2 * lastseg] + ax[NMS_AUX_SEG + 2 * lastseg + 1] + 63) >> 6 : 0;
   const int lane = threadIdx.x & 63;
   const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)), nw = gridDim.x * 4;
   const f4_t* ob = obx + (int64_t)b * SORT_MAX;
@@ -531,7 +652,8 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(const int* counts, const 
   const f4_t zero = f4_t{0.f, 0.f, 0.f, 0.f};
   for (int t = gw; t < words * words; t += nw) {
     const int rc = t / words, cc = t - rc * words;
-    if (cc < rc) continue;                                          // upper triangle: later boxes only
+    if (cc < rc || wseg[rc] != wseg[cc]) continue;                  // upper triangle (later boxes only), inside one segment
+    const int m = send[wseg[rc]];
     const int row = rc * 64 + lane, col = cc * 64 + lane;
     const f4_t bi = row < m ? ob[row] : zero;
     const f4_t bc = col < m ? ob[col] : zero;                       // lane j holds column box j (a zero box overlaps nothing)
@@ -568,17 +690,16 @@ __device__ __forceinline__ unsigned long long wave_or64(unsigned long long v) {
 typedef __attribute__((address_space(1))) unsigned long long g_u64_t;
 __device__ __forceinline__ unsigned long long ldg_u64(const unsigned long long* p) { return *(const g_u64_t*)p; }
 
-__global__ __launch_bounds__(64) void nms_mscan_kernel(const int* counts, const float* sorted, const unsigned long long* mask, int cap,
-                                                       int max_nms, int max_det, float* out, int* nkeep) {
+__global__ __launch_bounds__(64) void nms_mscan_kernel(int* aux, const unsigned long long* mask, const unsigned long long* skey, int max_det,
+                                                       int* kpos_out, unsigned long long* kkey_out) {
   __shared__ int kpos[MS_KR * 64];
-  const int b = blockIdx.x, lane = threadIdx.x;
-  int m = counts[b];
-  if (m > cap) m = cap;
-  if (m > SORT_MAX) return;                                         // the lazy kernel owns longer lists
-  if (m > max_nms) m = max_nms;
+  const int b = blockIdx.x, sg = blockIdx.y, lane = threadIdx.x;
+  int* ax = aux + (int64_t)b * NMS_AUX_INTS;
+  if (!ax[NMS_AUX_OK] || sg >= ax[NMS_AUX_NSEG]) return;
+  const int s0 = ax[NMS_AUX_SEG + 2 * sg];
+  const int m = s0 + ax[NMS_AUX_SEG + 2 * sg + 1];                   // one past the segment's last candidate slot
   const unsigned long long* M = mask + (int64_t)b * SORT_MAX * MS_RS;
-  const float* sb = sorted + (int64_t)b * max_nms * 6;
-  const int words = (m + 63) >> 6;
+  const int w0 = s0 >> 6, words = (m + 63) >> 6;                     // the segment's chunks: [w0, words)
   unsigned long long G[MS_P][MS_KR], B[MS_P][MS_P + 1], near[MS_P];
   int total = 0;
   auto issue = [&](int c, unsigned long long* g, unsigned long long* bd, int tot) {
@@ -596,9 +717,9 @@ __global__ __launch_bounds__(64) void nms_mscan_kernel(const int* counts, const 
     }
   };
 #pragma unroll
-  for (int s = 0; s < MS_P; ++s) { issue(s, G[s], B[s], 0); near[s] = 0ull; }
+  for (int s = 0; s < MS_P; ++s) { issue(w0 + s, G[s], B[s], 0); near[s] = 0ull; }
   bool done = false;
-  for (int c0 = 0; c0 < words && !done; c0 += MS_P) {
+  for (int c0 = w0; c0 < words && !done; c0 += MS_P) {
 #pragma unroll
     for (int s = 0; s < MS_P; ++s) {
       const int c = c0 + s;
@@ -632,12 +753,45 @@ __global__ __launch_bounds__(64) void nms_mscan_kernel(const int* counts, const 
       issue(c + MS_P, G[s], B[s], total);
     }
   }
-  // the kept rows, in keep order (= descending score): x1, y1, x2, y2, conf, cls as the filter wrote them
-  for (int e = lane; e < total * 6; e += 64) {
-    const int k = e / 6, q = e - k * 6;
-    out[((int64_t)b * max_det + k) * 6 + q] = sb[(int64_t)kpos[k] * 6 + q];
+  // this segment's kept slots (in keep order = descending score inside the class) join the image's kept list
+  int base = 0;
+  if (lane == 0 && total > 0) base = atomicAdd(ax + NMS_AUX_KCOUNT, total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const unsigned long long* sk = skey + (int64_t)b * SORT_MAX;
+  for (int e = lane; e < total; e += 64) {
+    const int k = kpos[e];
+    kpos_out[(int64_t)b * SORT_MAX + base + e] = k;
+    kkey_out[(int64_t)b * SORT_MAX + base + e] = sk[k];
   }
-  if (lane == 0) nkeep[b] = total;
+}
+
+// the kept boxes of all segments in descending (score, lower original row) order; the first max_det are the result (general.py:494-495)
+__global__ __launch_bounds__(256) void nms_merge_kernel(const int* aux, const int* kpos, const unsigned long long* kkey, const float* sorted,
+                                                        int max_nms, int max_det, float* out, int* nkeep) {
+  __shared__ unsigned long long sk[256];
+  const int b = blockIdx.y;
+  const int* ax = aux + (int64_t)b * NMS_AUX_INTS;
+  if (!ax[NMS_AUX_OK]) return;
+  const int K = ax[NMS_AUX_KCOUNT];
+  if (blockIdx.x == 0 && threadIdx.x == 0) nkeep[b] = K < max_det ? K : max_det;
+  if ((int)blockIdx.x * 256 >= K) return;
+  const int tid = threadIdx.x, i = blockIdx.x * 256 + tid;
+  const unsigned long long* kb = kkey + (int64_t)b * SORT_MAX;
+  const unsigned long long ki = i < K ? kb[i] : ~0ull;
+  int cnt = 0;
+  for (int jt = 0; jt < K; jt += 256) {
+    sk[tid] = jt + tid < K ? kb[jt + tid] : 0ull;
+    __syncthreads();
+    const int lim = K - jt < 256 ? K - jt : 256;
+    for (int q = 0; q < lim; ++q) cnt += sk[q] > ki ? 1 : 0;
+    __syncthreads();
+  }
+  if (i < K && cnt < max_det) {
+    const float* src = sorted + ((int64_t)b * max_nms + kpos[(int64_t)b * SORT_MAX + i]) * 6;
+    float* dst = out + ((int64_t)b * max_det + cnt) * 6;
+#pragma unroll
+    for (int e = 0; e < 6; ++e) dst[e] = src[e];
+  }
 }
 
 }  // namespace
@@ -646,7 +800,9 @@ int g_nms_dbg = 0;      // myolo_set_option("nms_dbg", bits): profiling only
 
 extern "C" int64_t myolo_nms_ws_bytes(int batch, int cap) {
   if (batch < 1 || cap < 1) return 0;
-  return (int64_t)batch * ((int64_t)SORT_MAX * 16 + (int64_t)SORT_MAX * MS_RS * 8 + (int64_t)cap * 8 + (int64_t)cap * 4);
+  // class-offset boxes | bit matrix | sort keys | score keys by slot | kept keys | ranks | kept slots | per-image side data (NmsAux)
+  return (int64_t)batch * ((int64_t)SORT_MAX * 16 + (int64_t)SORT_MAX * MS_RS * 8 + (int64_t)cap * 8 + (int64_t)SORT_MAX * 16 + (int64_t)cap * 4 +
+                           (int64_t)SORT_MAX * 4 + (int64_t)NMS_AUX_INTS * 4);
 }
 
 extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres,
@@ -663,22 +819,34 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   if (e != hipSuccess) return (int)e;
   // lists of up to SORT_MAX candidates (single label, cap == A): rank / scatter / bit matrix on the whole device + the one-wave scan
   const bool matrix = !sort_ws && mws && !((uintptr_t)mws & 15) && mws_bytes >= myolo_nms_ws_bytes(batch, cap) && cap == A &&
-                      max_det <= 64 * MS_KR && !(g_nms_dbg & 16);
+                      (int64_t)cap <= (1ll << IDX_BITS) && max_det <= 64 * MS_KR && !(g_nms_dbg & 16);
   f4_t* obx = reinterpret_cast<f4_t*>(mws);
   unsigned long long* mask = matrix ? reinterpret_cast<unsigned long long*>(obx + (int64_t)batch * SORT_MAX) : nullptr;
   unsigned long long* keys = matrix ? mask + (int64_t)batch * SORT_MAX * MS_RS : nullptr;
-  int* rank = matrix ? reinterpret_cast<int*>(keys + (int64_t)batch * cap) : nullptr;
+  unsigned long long* skey = matrix ? keys + (int64_t)batch * cap : nullptr;
+  unsigned long long* kkey = matrix ? skey + (int64_t)batch * SORT_MAX : nullptr;
+  int* rank = matrix ? reinterpret_cast<int*>(kkey + (int64_t)batch * SORT_MAX) : nullptr;
+  int* kpos = matrix ? rank + (int64_t)batch * cap : nullptr;
+  int* aux = matrix ? kpos + (int64_t)batch * SORT_MAX : nullptr;
+  // class on top of the sort key (classes are then suppressed side by side): single label (cap == A), class id and row must fit the key
+  const int keymode = (matrix && !agnostic && no - 5 <= NMS_MAXC && A < (1 << 24) && !(g_nms_dbg & 32)) ? 1 : 0;
+  if (matrix) {
+    e = hipMemsetAsync(aux, 0, (size_t)batch * NMS_AUX_INTS * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int es = dtype == MYOLO_F16 ? 2 : 4;
   const int filter_smem = 256 * no * es + 32;
-  if (((uintptr_t)pred & 15) || filter_smem > 64 * 1024) return MYOLO_EINVAL;
+  if (((uintptr_t)pred & 15) || filter_smem > 150 * 1024) return MYOLO_EINVAL;      // 256 rows of the prediction in LDS (80 classes fp32: 87 KB)
+  MYOLO_ENSURE_DYN_SMEM(nms_filter_kernel, filter_smem);
   hipLaunchKernelGGL(nms_filter_kernel, dim3(grid_for(A, 256, 1024), batch), dim3(256), filter_smem, st, pred, dtype, A, no, conf_thres,
-                     multi_label, cap, counts, cand, cand_idx, class_mask, keys, rank, (int64_t)batch * A * no * es);
+                     multi_label, cap, counts, cand, cand_idx, class_mask, keys, rank, (int64_t)batch * A * no * es, aux, keymode);
   if (matrix) {
-    hipLaunchKernelGGL(nms_rank2_kernel, dim3(SORT_MAX / 256, 16, batch), dim3(256), 0, st, counts, keys, cap, rank);
-    hipLaunchKernelGGL(nms_scatter_kernel, dim3(SORT_MAX / 256, batch), dim3(256), 0, st, counts, cand, rank, cap, max_nms, max_wh,
-                       agnostic, sorted, obx);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(1024, batch), dim3(256), 0, st, counts, obx, mask, cap, max_nms, iou_thres);
-    hipLaunchKernelGGL(nms_mscan_kernel, dim3(batch), dim3(64), 0, st, counts, sorted, mask, cap, max_nms, max_det, out, nkeep);
+    hipLaunchKernelGGL(nms_rank2_kernel, dim3(SORT_MAX / 256, 16, batch), dim3(256), 0, st, counts, keys, cap, rank, aux, keymode, max_wh);
+    hipLaunchKernelGGL(nms_scatter_kernel, dim3(SORT_MAX / 256, batch), dim3(256), 0, st, counts, cand, rank, keys, cap, max_nms, max_wh,
+                       agnostic, keymode, aux, sorted, obx, skey);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(1024, batch), dim3(256), 0, st, aux, obx, mask, iou_thres);
+    hipLaunchKernelGGL(nms_mscan_kernel, dim3(batch, keymode ? NMS_MAXC : 1), dim3(64), 0, st, aux, mask, skey, max_det, kpos, kkey);
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(SORT_MAX / 256, batch), dim3(256), 0, st, aux, kpos, kkey, sorted, max_nms, max_det, out, nkeep);
   }
   // longer lists (and callers without the matrix workspace): the lazy scan; it orders lists of up to SORT_MAX candidates itself
   // (original rows must fit the key's 19 bits)
@@ -708,7 +876,7 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
     attr_set = true;
   }
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(SCAN_THREADS), scan_smem, st, counts, cand, cand_idx, sorted, cap, max_nms,
-                     max_det, iou_thres, max_wh, agnostic, lds_sort, out, nkeep, g_nms_dbg, matrix ? 1 : 0);
+                     max_det, iou_thres, max_wh, agnostic, lds_sort, out, nkeep, g_nms_dbg, matrix ? aux : (const int*)nullptr);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }

@@ -95,6 +95,44 @@ def test_nms_edge_cases():
     np.testing.assert_array_equal(o.cpu().numpy(), r)
 
 
+@pytest.mark.parametrize('case', ['agnostic', 'nc80', 'wide_span', 'one_class_many_kept', 'classes_filter'])
+def test_nms_per_class_segments_match_the_oracle(case):
+    """round 3: short lists are suppressed class by class (class on top of the sort key, one scan wave per class, merge by score).
+    Against the oracle (global greedy walk in score order, like torchvision's): agnostic mode (one segment), 80 classes (many short
+    segments), coordinates spanning more than max_wh (classes are NOT independent any more: the image must go to the lazy scan),
+    one class keeping more than max_det boxes while others keep a few, and the `classes=` filter"""
+    from multiyolov5_amd.utils.general import non_max_suppression
+    kw = dict(conf_thres=0.25, iou_thres=0.45)
+    if case == 'nc80':
+        pred = synth.synth_nms_pred(2, 6000, 80, seed=11, img_w=1024, img_h=512)
+    elif case == 'wide_span':
+        pred = synth.synth_nms_pred(2, 5000, 10, seed=12, img_w=1024, img_h=512)
+        pred[0, ::7, 0] += 5000.0                                # boxes of image 0 spread over > max_wh (4096) pixels; image 1 stays narrow
+        pred[0, 1::7, 2] = 4500.0                                # and some wider than max_wh: they overlap across the class offsets
+    elif case == 'one_class_many_kept':
+        rs = np.random.RandomState(1)
+        a = np.zeros((1, 3000, 15), np.float32)
+        a[0, :, 0] = np.arange(3000) * 37 % 2000 + 10
+        a[0, :, 1] = np.arange(3000) // 54 * 18 + 10
+        a[0, :, 2:4] = 6
+        a[0, :, 4] = 0.95
+        cls = np.where(np.arange(3000) % 5 == 0, rs.randint(1, 10, 3000), 0)      # 80 % class 0: > 300 disjoint boxes of one class
+        a[0, np.arange(3000), 5 + cls] = rs.uniform(0.4, 1.0, 3000)
+        pred = torch.from_numpy(a)
+    else:
+        pred = synth.synth_nms_pred(2, 6000, 10, seed=13, img_w=1024, img_h=512)
+    if case == 'agnostic':
+        kw['agnostic'] = True
+    if case == 'classes_filter':
+        kw['classes'] = [1, 3, 8]
+    ref = nms_ref.non_max_suppression(pred.numpy(), **kw)
+    for dt in (torch.float32,):
+        out = non_max_suppression(pred.to(DEV, dt), **kw)
+        for i in range(pred.shape[0]):
+            _same(out[i].cpu().numpy(), ref[i], f'nms/{case}/{i}')
+            assert out[i].shape[0] <= 300
+
+
 def test_seg_argmax_fused_matches_oracle_and_model_output():
     from multiyolov5_amd.models.yolo import Model
     from multiyolov5_amd.utils.general import seg_argmax
