@@ -377,8 +377,10 @@ int myolo_scaler_update(float* scale, int32_t* growth_tracker, float* found_inf,
  * (nc <= 64 when non-zero).  sort_ws (optional, device int32 [batch][3*65536 + cap]): the descending-score order is produced by a
  * counting sort instead of the O(n^2) rank kernel -- for test.py's conf 0.001 / multi_label lists (1e5 candidates per image).
  * mws (optional, device, 16-byte aligned, >= myolo_nms_ws_bytes(batch, cap) bytes; single-label calls, cap == A, max_det <= 320):
- * images with at most 8192 candidates (detect.py) take the device-wide path -- rank, scatter and the n x n suppression bit matrix on all
- * CUs, then one wave per image walks the sorted list with bit operations only; longer lists and callers without mws keep the
+ * images with at most 8192 candidates (detect.py) take the device-wide path -- rank, scatter and the suppression bit matrix on all
+ * CUs, class by class (classes cannot suppress each other once box + cls*max_wh is formed, as long as the un-offset coordinates span
+ * less than max_wh: checked per image), one wave per (image, class) walks its part of the sorted list with bit operations only, the
+ * kept boxes are merged back into score order; longer lists, images failing that check and callers without mws keep the
  * single-workgroup lazy scan.  Identical results either way. */
 int64_t myolo_nms_ws_bytes(int batch, int cap);
 int myolo_nms(const void* pred, int dtype, int batch, int A, int no, float conf_thres, float iou_thres, int multi_label,
