@@ -35,6 +35,9 @@ WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
 NATIVE_EXEC = os.environ.get('MYOLO_NATIVE_EXEC', '1') != '0'
+# MYOLO_PRUNE_BWD=0: a backward that starts from a subset of the outputs (train.py:371 / 392: the detection pass, the segmentation pass)
+# runs the whole static launch list over zero gradients instead of the sub-list that can contribute (Plan.bwd_schedule)
+PRUNE_BWD = os.environ.get('MYOLO_PRUNE_BWD', '1') != '0'
 
 SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
@@ -132,6 +135,10 @@ class Op:
     def plan_bwd(self, plan):   # decide accumulate flags; called in reverse op order before build()
         pass
 
+    def grad_io(self):
+        """(TVs whose gradient this op's backward launches READ, TVs whose gradient they WRITE) -- Plan.bwd_schedule's dataflow"""
+        return [], []
+
 
 def claim(tv, writer=None):
     """Gradient write planning for tv: returns (accumulate_flag, [zero-fill TV ranges needed first]).  `writer` (an Op whose dgrad
@@ -140,9 +147,12 @@ def claim(tv, writer=None):
     b = tv.buf
     lo, hi = tv.coff, tv.coff + tv.c
     b.gwriters.append((lo, hi, writer))
-    covered = [(a, z) for a, z in b.gwritten if a < hi and z > lo]
+    log = getattr(tv.plan, '_claim_log', None)        # (claiming op, buffer, range, accumulate flag, zero-filled gaps) in backward order:
+    covered = [(a, z) for a, z in b.gwritten if a < hi and z > lo]      # what Plan.bwd_schedule prunes a backward with
     if not covered:
         b.gwritten.append((lo, hi))
+        if log is not None:
+            log.append((tv.plan._claiming, b, lo, hi, 0, []))
         return 0, []
     # fully covered?
     pts = sorted(covered)
@@ -154,6 +164,8 @@ def claim(tv, writer=None):
     if cur < hi:
         gaps.append((cur, hi))
     b.gwritten.append((lo, hi))
+    if log is not None:
+        log.append((tv.plan._claiming, b, lo, hi, 1, list(gaps)))
     return 1, gaps
 
 
@@ -198,6 +210,9 @@ class FocusPackOp(Op):
     def __init__(self, plan, img_slot, out, mul=1.0):
         self.slot, self.out, self.mul = img_slot, out, mul
 
+    def grad_io(self):
+        return [self.out], []
+
     def build(self, plan):
         super().build(plan)
         meta = plan.in_meta[self.slot]
@@ -212,6 +227,9 @@ class ImportOp(Op):
 
     def __init__(self, plan, slot, out):
         self.slot, self.out = slot, out
+
+    def grad_io(self):
+        return [self.out], []
 
     def build(self, plan):
         super().build(plan)
@@ -258,6 +276,18 @@ class ConvOp(Op):
         self.res_acc = 0
         self.reduce_by = None        # the op whose dgrad launch produces this layer's BatchNorm-backward sums (else: own reduce launch)
         self.bnb_targets = []        # [(layer op, c0, c1)]: BatchNorm layers whose output gradient this op's dgrad completes
+
+    def grad_io(self):
+        ins = [self.x] if self.x.requires_grad else []
+        if self.res is not None and self.res.requires_grad:
+            ins.append(self.res)
+        return [self.out], ins
+
+    def bn_reduce_call(self):
+        """this layer's BatchNorm-backward reduce pass as its own launch (a pruned backward whose `reduce_by` dgrad does not run)"""
+        bn = self.bn
+        return Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias),
+                                                self.act, L.ptr(self.dsum)))
 
     def plan_bwd(self, plan):
         if self.res is not None and self.res.requires_grad:
@@ -515,6 +545,9 @@ class SimpleOp(Op):
         self.src, self.dst = src, dst
         self.acc, self.zero_first = 0, []
 
+    def grad_io(self):
+        return [self.dst], ([self.src] if self.src.requires_grad else [])
+
     def plan_bwd(self, plan):
         if self.src.requires_grad:
             self.acc, z = claim(self.src)
@@ -703,6 +736,9 @@ class AddOp(Op):
         self.acc = [0, 0]
         self.zero_first = []
 
+    def grad_io(self):
+        return [self.out], [tv for tv in (self.a, self.b) if tv.requires_grad]
+
     def plan_bwd(self, plan):
         for i, tv in enumerate((self.a, self.b)):
             if tv.requires_grad:
@@ -735,6 +771,9 @@ class SppPoolOp(Op):
     def __init__(self, plan, x, outs):
         self.x, self.outs = x, outs
         self.acc, self.zero_first = 0, []
+
+    def grad_io(self):
+        return list(self.outs), ([self.x] if self.x.requires_grad else [])
 
     def plan_bwd(self, plan):
         if self.x.requires_grad:
@@ -771,6 +810,9 @@ class GateOp(Op):
         self.fn = 'myolo_gate' if residual else 'myolo_gate_mul'
         self.acc, self.zero_first, self.acc_att = 0, [], 0
 
+    def grad_io(self):
+        return [self.out], [self.feat, self.att]
+
     def plan_bwd(self, plan):
         self.acc, z = claim(self.feat)
         self.zero_first = [(self.feat, a, b) for a, b in z]
@@ -800,6 +842,9 @@ class SegOutOp(Op):
     def __init__(self, plan, low, scale, slot):
         self.low, self.scale, self.slot = low, scale, slot
         self.acc = 0
+
+    def grad_io(self):
+        return [], [self.low]
 
     def plan_bwd(self, plan):
         self.acc, z = claim(self.low)
@@ -856,6 +901,9 @@ class ExportOp(Op):
 
     def __init__(self, plan, src, slot):
         self.src, self.slot, self.acc = src, slot, 0
+
+    def grad_io(self):
+        return [], [self.src]
 
     def plan_bwd(self, plan):
         self.acc, z = claim(self.src)
@@ -1125,8 +1173,12 @@ class Plan:
                 b.gwritten = []
             for b in self.bufs:
                 b.gwriters = []
+            self._claim_log = []
             for op in reversed(self.ops):
+                self._claiming = op
                 op.plan_bwd(self)
+            self._claiming = None
+            self._check_group_claims()
             self._plan_bn_stats()
         self._pg_first_op = {}
         for i, op in enumerate(self.ops):
@@ -1174,6 +1226,132 @@ class Plan:
                 continue
             op.reduce_by = w
             w.bnb_targets.append((op, lo - w.x.coff, hi - w.x.coff))
+
+    def _check_group_claims(self):
+        """a grouped AdaptiveAvgPool backward claims its source gradient at the LAST member's position (first in the backward) and
+        writes it -- zero fills included -- in the FIRST member's launch: nothing in between may touch that range"""
+        pos = {id(op): i for i, op in enumerate(self.ops)}
+        for op, buf, lo, hi, _, _ in self._claim_log:
+            g = getattr(op, 'group', None)
+            if not isinstance(op, AvgPoolOp) or g is None or len(g) < 2:
+                continue
+            first, last = pos[id(g[0])], pos[id(g[-1])]
+            for o2, b2, lo2, hi2, _, _ in self._claim_log:
+                if o2 is not op and b2 is buf and lo2 < hi and hi2 > lo and first <= pos[id(o2)] < last:
+                    raise L.MyoloError('grouped AdaptiveAvgPool backward: another op writes the source gradient between the group\'s '
+                                       'claim and its launch')
+
+    # ---- pruned backward ----------------------------------------------------------------------------
+    # train.py:364-392 runs a detection pass and a segmentation pass per iteration: each backward starts from ONE of the two outputs
+    # and the reference's autograd never visits the other head.  The static backward list would run that head (and every layer only it
+    # depends on) over zero gradients.  bwd_schedule() derives, per set of outputs that DID receive a gradient, the sub-list that can
+    # contribute: an op runs iff its output gradient can be non-zero; an op that does not run but was the first writer of a gradient range
+    # a running producer reads is replaced by a zero fill of that range; a running BatchNorm layer whose reduce pass rode in the
+    # epilogue of a pruned dgrad gets its own reduce launch back.  Parameter gradients of pruned ops stay at the zeros of the flat
+    # buffer's memset (= what the full list computes from a zero output gradient).
+    def _out_slot(self, op):
+        if isinstance(op, (SegOutOp, ExportOp)):
+            return op.slot
+        if isinstance(op, ConvOp) and op.det:
+            return self.__dict__.get('det_slot', {}).get(id(op))
+        return None
+
+    def bwd_liveness(self, live_slots):
+        """[does op i's backward run] when only the output slots in `live_slots` carry a gradient; None: not analysable"""
+        n = len(self.ops)
+        live, ranges = [False] * n, {}
+        for i in range(n - 1, -1, -1):
+            op = self.ops[i]
+            outs, ins = op.grad_io()
+            slot = self._out_slot(op)
+            if slot is not None:
+                live[i] = slot in live_slots
+            elif isinstance(op, ConvOp) and op.det:
+                return None                                   # a Detect level that is not a registered output
+            elif isinstance(op, ImportOp):
+                live[i] = True                                # exports the gradient of a module input: always (zeros included)
+            else:
+                live[i] = any(a < tv.coff + tv.c and z > tv.coff for tv in outs for a, z in ranges.get(id(tv.buf), ()))
+            if live[i]:
+                for tv in ins:
+                    ranges.setdefault(id(tv.buf), []).append((tv.coff, tv.coff + tv.c))
+        for op in self.ops:                                   # grouped launches live on one member: the group runs or is pruned as a whole
+            g = getattr(op, 'group', None)
+            if g and len({live[self.ops.index(o)] for o in g}) > 1:
+                return None
+        return live
+
+    def bwd_schedule(self, live_slots):
+        """the backward in execution order as [('op', i) | ('reduce', i) | ('fill', i, buf, c0, c1)] for the outputs in `live_slots`;
+        (a fill stands at the position i of the pruned op it replaces) 'full' when nothing can be pruned, None when the plan cannot be analysed (the caller runs the full list over zeros)"""
+        if not self.training or not hasattr(self, '_claim_log'):
+            return None
+        live = self.bwd_liveness(frozenset(live_slots))
+        if live is None:
+            return None
+        if all(lv for lv, op in zip(live, self.ops) if op.bwd_calls):
+            return 'full'
+        pos = {id(op): i for i, op in enumerate(self.ops)}
+        read = {}                                             # gradient ranges a running op reads (its own output gradient)
+        for i, op in enumerate(self.ops):
+            if live[i]:
+                for tv in op.grad_io()[0]:
+                    read.setdefault(id(tv.buf), []).append((tv.coff, tv.coff + tv.c))
+        claims = {}
+        for op, buf, lo, hi, acc, gaps in self._claim_log:
+            claims.setdefault(id(op), []).append((buf, lo, hi, acc, gaps))
+        sched = []
+        for i in range(len(self.ops) - 1, -1, -1):
+            op = self.ops[i]
+            if live[i]:
+                rb = getattr(op, 'reduce_by', None)
+                if rb is not None and not live[pos[id(rb)]] and op.bwd_calls:
+                    sched.append(('reduce', i))
+                sched.append(('op', i))
+                continue
+            for buf, lo, hi, acc, gaps in claims.get(id(op), ()):
+                for a, z in (gaps if acc else [(lo, hi)]):
+                    if any(ra < z and rz > a for ra, rz in read.get(id(buf), ())):
+                        sched.append(('fill', i, buf, a, z))
+        return sched
+
+    def check_bwd_schedule(self, sched):
+        """structural check of a schedule (tests): every gradient range a scheduled launch reads, or accumulates into, was written
+        earlier in the same schedule.  Returns the list of violations."""
+        done, bad = {}, []
+        claims = {}
+        for op, buf, lo, hi, acc, gaps in self._claim_log:
+            claims.setdefault(id(op), []).append((buf, lo, hi, acc, gaps))
+
+        def missing(buf, lo, hi):
+            cur = lo
+            for a, z in sorted(done.get(id(buf), ())):
+                if a > cur:
+                    break
+                cur = max(cur, z)
+            return cur < hi
+
+        for e in sched:
+            if e[0] == 'fill':
+                done.setdefault(id(e[2]), []).append((e[3], e[4]))
+                continue
+            op = self.ops[e[1]]
+            reads_out = e[0] == 'reduce' or (op.bwd_calls and self._out_slot(op) is None)
+            if reads_out:
+                for tv in op.grad_io()[0]:
+                    if tv.requires_grad and missing(tv.buf, tv.coff, tv.coff + tv.c):
+                        bad.append((e, 'reads an unwritten output gradient', tv.coff, tv.coff + tv.c))
+            if e[0] == 'reduce':
+                continue
+            for buf, lo, hi, acc, gaps in claims.get(id(op), ()):
+                if acc:
+                    cur = lo
+                    for a, z in sorted(gaps) + [(hi, hi)]:
+                        if a > cur and missing(buf, cur, a):
+                            bad.append((e, 'accumulates into an unwritten range', cur, a))
+                        cur = max(cur, z)
+                done.setdefault(id(buf), []).append((lo, hi))
+        return bad
 
     def prepare(self):
         st = L.stream_ptr()
@@ -1412,28 +1590,69 @@ class Plan:
             g['failed'] = True
             return False
 
-    def _native_bwd(self, reducer):
-        """the backward launch list as a native program, cut at the gradient-slice boundaries of `reducer`"""
+    def _sched_calls(self, sched):
+        """{op index: launches} of a pruned schedule (Plan.bwd_schedule)"""
+        per = {}
+        for e in sched:
+            calls = per.setdefault(e[1], [])
+            if e[0] == 'op':
+                calls += list(self.ops[e[1]].bwd_calls)
+            elif e[0] == 'reduce':
+                calls.append(self.ops[e[1]].bn_reduce_call())
+            else:
+                _, _, buf, a, z = e
+                tv = TV(self, buf.n, buf.h, buf.w, z - a)
+                tv.place(buf, a)
+                zd = tv.desc(grad=True)
+                calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+        return per
+
+    def _bwd_items(self, reducer, live=None):
+        """the launch items of the backward program for `reducer` (see NativeProg); `live`: frozenset of the output slots that received
+        a gradient -> the pruned list, or 'full' when there is nothing to prune / the plan cannot be analysed"""
+        per = None
+        if live is not None:
+            sched = self.bwd_schedule(live)
+            if sched is None or sched == 'full':
+                return 'full'
+            per = self._sched_calls(sched)
+        items = []
+        if self._used[1]:
+            items.append(('memset', self._arena[1], self._used[1] * 4))
+        items.append(('memset', self.flat_grad, self.flat_grad.numel() * 4))
+        for si, (hi, lo, ready) in enumerate(self._bwd_segments(reducer)):
+            for i in range(hi - 1, lo - 1, -1):
+                items += list(self.ops[i].bwd_calls) if per is None else per.get(i, [])
+            if ready:
+                items.append(('join',))
+            items.append(('mark', si))
+        items.append(('join',))
+        return items
+
+    def _native_bwd(self, reducer, live=None):
+        """the backward launch list as a native program, cut at the gradient-slice boundaries of `reducer`.  `live`: see _bwd_items
+        (the SAME program object as live=None when nothing can be pruned)"""
         cache = self.__dict__.setdefault('_nprog_bwd', {})
-        key = id(reducer)
+        key = (id(reducer), live)
         if key not in cache:
-            items = []
-            if self._used[1]:
-                items.append(('memset', self._arena[1], self._used[1] * 4))
-            items.append(('memset', self.flat_grad, self.flat_grad.numel() * 4))
-            segs = self._bwd_segments(reducer)
-            for si, (hi, lo, ready) in enumerate(segs):
-                for i in range(hi - 1, lo - 1, -1):
-                    items += list(self.ops[i].bwd_calls)
-                if ready:
-                    items.append(('join',))
-                items.append(('mark', si))
-            items.append(('join',))
-            try:
-                cache[key] = NativeProg(items)
-            except KeyError:
-                cache[key] = False
+            items = self._bwd_items(reducer, live)
+            if items == 'full':
+                cache[key] = self._native_bwd(reducer) or False
+            else:
+                try:
+                    cache[key] = NativeProg(items)
+                except KeyError:
+                    cache[key] = False
         return cache[key] or None
+
+    def pruned_bwd(self, reducer, live):
+        """the native backward program for a backward that starts from the output slots in `live` only, or None when the full list
+        runs (every output has a gradient, nothing to prune, no native executor, captured training graphs)"""
+        if not PRUNE_BWD or not live or not self.training or not self.native_ok() or self.graphable() or not self.flat_grad.is_cuda:
+            return None
+        full = self._native_bwd(reducer)
+        np_ = self._native_bwd(reducer, frozenset(live))
+        return np_ if (np_ is not None and np_ is not full) else None
 
     def _bwd_native(self, np_, reducer):
         side = self._side_stream().cuda_stream if self.use_side_stream else None
@@ -1448,11 +1667,12 @@ class Plan:
         if reducer is not None:
             reducer.finish(self.flat_grad)
 
-    def _bwd_eager(self, reducer):
+    def _bwd_eager(self, reducer, prog=None):
         """the backward launch list call by call on the CURRENT stream (also the body of the 'fork' capture): weight-gradient launches
-        are forked to the side stream behind an event each, gradient slices go to the reducer as soon as they are final"""
+        are forked to the side stream behind an event each, gradient slices go to the reducer as soon as they are final.  `prog`: a
+        pruned native program of this plan and reducer (Plan.pruned_bwd)"""
         if self.native_ok() and self.flat_grad.is_cuda and not torch.cuda.is_current_stream_capturing():
-            np_ = self._native_bwd(reducer)
+            np_ = prog if prog is not None else self._native_bwd(reducer)
             if np_ is not None:
                 self._bwd_native(np_, reducer)
                 return
@@ -1492,9 +1712,12 @@ class Plan:
         if reducer is not None:
             reducer.finish(self.flat_grad)
 
-    def run_bwd(self, reducer=None):
+    def run_bwd(self, reducer=None, prog=None):
         """backward launch list.  Weight-gradient kernels go to a side HIP stream: they only feed the optimizer, so they
         overlap with the latency-bound dgrad / BatchNorm chain on the main stream (many of those launches fill < 1 CU wave)."""
+        if prog is not None:                                  # pruned list (only handed out when the native executor runs the backward)
+            self._bwd_eager(reducer, prog)
+            return
         g = self.__dict__.get('_graphs')
         graphed = self.graphable() and g is not None and 'fwd' in g and not g.get('failed')
         if graphed and 'bwd' not in g:

@@ -57,6 +57,7 @@ class _OutSpec:
         if isinstance(y, E.DetHandle):
             s = self._slot()
             self.det_slots[s] = y.op
+            plan.__dict__.setdefault('det_slot', {})[id(y.op)] = s       # (engine.Plan.bwd_liveness: which output a Detect level is)
             return ('o', s)
         if isinstance(y, E.DecodeHandle):
             s = self._slot()
@@ -173,13 +174,18 @@ class PlanFn(torch.autograd.Function):
         if not holder.pending_bwd or ctx.generation != holder.generation:
             raise L.MyoloError('backward through a plan whose activations were overwritten by a newer forward '
                                '(one outstanding forward per module/shape; call backward before the next forward)')
-        PlanFn._take_output_grads(holder, plan, grads)
-        plan.run_bwd(holder.module.__dict__.get('_grad_reducer'))
+        red = holder.module.__dict__.get('_grad_reducer')
+        prog = PlanFn._take_output_grads(holder, plan, grads, red)
+        plan.run_bwd(red, prog)
         return PlanFn._finish_backward(holder, plan)
 
     @staticmethod
-    def _take_output_grads(holder, plan, grads):
-        """the incoming output gradients -> the plan's gradient buffers (the fused losses already wrote theirs in place)"""
+    def _take_output_grads(holder, plan, grads, cuts=None):
+        """the incoming output gradients -> the plan's gradient buffers (the fused losses already wrote theirs in place).  Returns the
+        pruned backward program when only some outputs received a gradient (train.py:371 / 392: the detection pass, the segmentation
+        pass -- engine.Plan.bwd_schedule), else None = the full launch list; `cuts`: the reducer / stage cuts the program is built for"""
+        live = [s for s, g in enumerate(grads) if g is not None]
+        prog = plan.pruned_bwd(cuts, live) if len(live) < len(grads) else None
         for s, g in enumerate(grads):
             dst = holder.output_grad_tensor(s)
             sc = plan.output_scales.get(s)
@@ -188,7 +194,8 @@ class PlanFn(torch.autograd.Function):
                 raise L.MyoloError('the segmentation logits were consumed by the fused cross-entropy AND another differentiable op: '
                                    'their gradients cannot be combined (set MYOLO_FUSED_CE=0 for that use)')
             if g is None:
-                dst.zero_()
+                if prog is None:                          # (the pruned list never reads this output's gradient buffer)
+                    dst.zero_()
                 if sc is not None:
                     sc[1]['low'] = False                  # this output's loss is not part of the backward: no low-resolution gradient either
             elif g.data_ptr() != dst.data_ptr() or g.stride() != dst.stride():
@@ -200,6 +207,7 @@ class PlanFn(torch.autograd.Function):
                 elif state['dirty']:
                     scale.fill_(1.0)
                     state['dirty'] = False
+        return prog
 
     @staticmethod
     def _finish_backward(holder, plan):
@@ -297,20 +305,22 @@ def _stage_plan(holder):
             for p in plan.params:
                 offs.append(off)
                 off += p.numel()
-            stages, first = [], 0
+            # a stage is the program range between two segment marks ('mk': mark keys, None = program start / end): the same keys
+            # address the pruned programs of this plan (engine.Plan.pruned_bwd), whose op indices differ
+            stages, first = [], None
             segs = plan._bwd_segments(cuts)
             pend = []
             for si, (hi, lo, ready) in enumerate(segs):
                 pend += ready
                 last = si == len(segs) - 1
                 if ready and not last:
-                    stages.append({'ops': (first, np_.marks[si]), 'slices': list(pend)})
-                    first, pend = np_.marks[si], []
+                    stages.append({'mk': (first, si), 'slices': list(pend)})
+                    first, pend = si, []
                 elif last:
                     if pend or not stages:
-                        stages.append({'ops': (first, np_.n), 'slices': list(pend)})
+                        stages.append({'mk': (first, None), 'slices': list(pend)})
                     else:                                  # nothing but the final join is left: it belongs to the last real stage (a stage
-                        stages[-1]['ops'] = (stages[-1]['ops'][0], np_.n)    # without parameters would be pruned by autograd)
+                        stages[-1]['mk'] = (stages[-1]['mk'][0], None)       # without parameters would be pruned by autograd)
             for sg in stages:
                 sg['params'] = [i for i, o in enumerate(offs) if any(a <= o < b for a, b in sg['slices'])]
             covered = sorted(i for sg in stages for i in sg['params'])
@@ -355,7 +365,7 @@ class PlanStageFn(torch.autograd.Function):
             if not holder.pending_bwd or ctx.generation != holder.generation:
                 raise L.MyoloError('backward through a plan whose activations were overwritten by a newer forward '
                                    '(one outstanding forward per module/shape; call backward before the next forward)')
-            PlanFn._take_output_grads(holder, plan, grads)
+            holder._stage_prog_cur = PlanFn._take_output_grads(holder, plan, grads, cuts) or np_
             holder._bwd_accumulate = _accumulate_in_place(holder, plan)
             if not holder._bwd_accumulate:
                 flat = holder.__dict__.get('_accum_buf')
@@ -363,7 +373,9 @@ class PlanStageFn(torch.autograd.Function):
                     flat = torch.empty_like(plan.flat_grad)
                 holder._accum_buf = flat
         side = plan._side_stream().cuda_stream if plan.use_side_stream else None
-        np_.run(sg['ops'][0], sg['ops'][1], side)
+        np_ = holder._stage_prog_cur
+        m0, m1 = sg['mk']
+        np_.run(0 if m0 is None else np_.marks[m0], np_.n if m1 is None else np_.marks[m1], side)
         last = k == nstage - 1
         acc = holder._bwd_accumulate
         flat = holder._accum_buf

@@ -149,3 +149,81 @@ def test_native_program_serialises_every_launch_of_a_training_plan():
     assert E._slot_value(C.byref(d), C.POINTER(L.Tensor)) == C.addressof(d)
     sw = [c for c in bwd if isinstance(c, E.SwitchCall)]
     assert len(sw) == 1 and isinstance(sw[0].cell, C.c_int32)
+
+
+@pytest.mark.parametrize('tag', ['s_psp', 's_base', 's_lab', 's_bise', 'm_lab'])
+def test_pruned_backward_schedules_are_self_consistent(tag):
+    """train.py:371 / 392 -- a backward from the detection outputs only, or from the segmentation output(s) only, runs a sub-list of the
+    static backward (engine.Plan.bwd_schedule).  Dry plan: every gradient range a scheduled launch reads or accumulates into has an
+    earlier writer in the same schedule; the checker itself is validated on the full list and on schedules with a link removed."""
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    m = Model(os.path.join(CFG, TAGS[tag])).train()
+    h = R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float16, True)
+    plan, ns = h.plan, h.ospec.nslots
+    det = frozenset(h.ospec.det_slots)
+    seg = frozenset(range(ns)) - det
+    assert len(det) == 3 and len(seg) >= 1
+    full = [('op', i) for i in range(len(plan.ops) - 1, -1, -1)]
+    assert plan.check_bwd_schedule(full) == []
+    assert plan.bwd_schedule(det | seg) == 'full'
+    nfull = sum(len(op.bwd_calls) for op in plan.ops)
+    for live in (det, seg):
+        sched = plan.bwd_schedule(live)
+        assert isinstance(sched, list) and plan.check_bwd_schedule(sched) == []
+        kept = [e[1] for e in sched if e[0] == 'op']
+        n = sum(len(plan.ops[i].bwd_calls) for i in kept)
+        assert kept == sorted(kept, reverse=True) and 0.5 * nfull < n < 0.95 * nfull      # a real sub-list, in backward order
+        # the output ops of the other head do not run, those of this head do
+        for i, op in enumerate(plan.ops):
+            s_ = plan._out_slot(op)
+            if s_ is not None:
+                assert (i in kept) == (s_ in live)
+        # every pruned launch list still writes each parameter gradient at most through launches of running ops: the weight-gradient
+        # launches kept are exactly those of the running convolutions
+        items = plan._bwd_items(None, live)
+        wg = sum(1 for it in items if getattr(it, 'name', '') == 'myolo_conv_wgrad')
+        assert wg == sum(1 for i in kept for c in plan.ops[i].bwd_calls if c.name == 'myolo_conv_wgrad')
+        # mutations: drop a zero fill / a restored reduce / a running op that feeds a running producer -> the checker objects
+        fills = [e for e in sched if e[0] == 'fill']
+        assert fills, 'a pruned op was the first writer of a range a running producer reads'
+        for e in fills:
+            assert plan.check_bwd_schedule([x for x in sched if x is not e]), e
+        stores = {id(c[0]) for c in plan._claim_log if c[4] == 0}           # ops that are the FIRST writer of a gradient range
+        mid = [e for e in sched if e[0] == 'op' and id(plan.ops[e[1]]) in stores and plan._out_slot(plan.ops[e[1]]) is None]
+        for e in mid[::7]:
+            assert plan.check_bwd_schedule([x for x in sched if x is not e]), e
+    # a BatchNorm layer whose reduce pass rides in the dgrad epilogue of a pruned convolution gets its own reduce launch back
+    from multiyolov5_amd import engine as E
+    pos = {id(op): i for i, op in enumerate(plan.ops)}
+    for live in (det, seg):
+        lv = plan.bwd_liveness(live)
+        sched = plan.bwd_schedule(live)
+        want = {i for i, op in enumerate(plan.ops) if lv[i] and getattr(op, 'reduce_by', None) is not None and not lv[pos[id(op.reduce_by)]]}
+        assert {e[1] for e in sched if e[0] == 'reduce'} == want
+        names = [it.name if hasattr(it, 'name') else it[0] for it in plan._bwd_items(None, live)]
+        assert names.count('myolo_bn_act_bwd_reduce') == sum(1 for e in sched if e[0] == 'op' for c in plan.ops[e[1]].bwd_calls
+                                                             if c.name == 'myolo_bn_act_bwd_reduce') + len(want)
+
+
+def test_staged_backward_marks_address_pruned_programs():
+    """the stock-DDP stage chain cuts the native program at segment marks: a pruned program has the same mark keys at other indices"""
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    m = Model(os.path.join(CFG, TAGS['s_psp'])).train()
+    h = R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float16, True)
+    plan = h.plan
+    cuts = R.StageCuts()
+
+    def marks(items):
+        out, n = {}, 0
+        for it in items:
+            if isinstance(it, tuple) and it[0] == 'mark':
+                out[it[1]] = n
+            else:
+                n += 2 if type(it).__name__ == 'SwitchCall' else 1
+        return out, n
+    mf, nf = marks(plan._bwd_items(cuts))
+    md, nd = marks(plan._bwd_items(cuts, frozenset(h.ospec.det_slots)))
+    assert set(mf) == set(md) and nd < nf and all(md[k] <= mf[k] for k in mf)
+    assert [md[k] for k in sorted(md)] == sorted(md[k] for k in md)
