@@ -62,7 +62,7 @@ def run_sequence(tag, seq, prune, monkeypatch, dtype=torch.float32, staged=None)
         m.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)         # same BatchNorm running stats every time
         with torch.autocast('cuda', enabled=dtype == torch.float16):
             loss = losses(m, x, targets, mask, which)
-        loss.backward()
+        (loss * (64.0 if dtype == torch.float16 else 1.0)).backward()        # (a fixed loss scale keeps fp16 gradients off the underflow edge)
         torch.cuda.synchronize()
         out.append((float(loss), grads_of(m)))
     plan = next(iter(m.__dict__['_plans'].values())).plan
