@@ -424,6 +424,7 @@ def _accumulate_in_place(holder, plan):
     if torch.distributed.is_available() and torch.distributed.is_initialized() and holder.module.__dict__.get('_grad_reducer') is None:
         return False
     base, off = buf.data_ptr(), 0
+    first = last = None
     for p in plan.params:
         n = p.numel()
         if p.requires_grad:
@@ -432,7 +433,19 @@ def _accumulate_in_place(holder, plan):
                 return False
             if p._backward_hooks or getattr(p, '_post_accumulate_grad_hooks', None):
                 return False
+            last = p
+            first = first if first is not None else p
         off += n
+    # `torch.autograd.grad(loss, params)` / `loss.backward(inputs=...)` RETURN gradients or accumulate into a subset: adding into
+    # `.grad` would be a side effect there.  Inside a backward pass, ask the engine whether it will run the parameters'
+    # AccumulateGrad nodes (first and last parameter; under autograd.grad() the query itself raises for a leaf)
+    if first is not None and torch._C._current_graph_task_id() != -1:
+        try:
+            for q in (first, last):
+                if not torch._C._will_engine_execute_node(torch.autograd.graph.get_gradient_edge(q).node):
+                    return False
+        except RuntimeError:
+            return False
     return True
 
 

@@ -106,6 +106,25 @@ def test_flat_accumulation_rule():
     assert R._accumulate_in_place(holder, plan) is False
     h.remove()
     assert R._accumulate_in_place(holder, plan) is True
+    # inside a backward pass: only when the engine will run the parameters' AccumulateGrad nodes -- not under autograd.grad(), which
+    # RETURNS gradients, nor under backward(inputs=subset)
+    seen = []
+
+    class F(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, a, b, c):
+            return a.sum() + b.sum() + c.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(R._accumulate_in_place(holder, plan))
+            return torch.ones(2, 3) * g, torch.ones(5) * g, None
+    y = F.apply(*ps)
+    y.backward(retain_graph=True)
+    ps[0].grad, ps[1].grad = buf[0:6].view(2, 3), buf[6:11].view(5)
+    torch.autograd.grad(y, ps[:2], retain_graph=True)
+    y.backward(inputs=[ps[0]], retain_graph=True)
+    assert seen == [True, False, False]
 
 
 def test_sync_batchnorm_is_rejected_loudly():
