@@ -180,8 +180,12 @@ int myolo_bn_act_bwd_apply(const myolo_tensor* gout, const myolo_tensor* y, cons
  * nbt, dgamma, dbeta) serves the low channels, `split` the high ones; stats / saved / dsum stay one array over all c channels.
  * split == NULL: identical to the plain entry points. */
 typedef struct myolo_bn_split {
-  int32_t c_split;               /* multiple of the 16-byte vector */
-  int32_t reserved;
+  int32_t c_split;               /* multiple of the 16-byte vector; == c: no second parameter set (gamma2 .. dbeta2 unused) */
+  int32_t count_scale;           /* 0 / 1: the statistics cover this tensor's n*h*w samples.  w > 1: `stats` / `dsum` hold the SUMS over w
+                                  * ranks with equally sized batches (nn.SyncBatchNorm, train.py:190-193: the caller all-reduced the
+                                  * arrays between the producing launch and this one): mean / variance / the unbiased running variance and
+                                  * the backward's mean terms use w*n*h*w samples; dgamma / dbeta receive sum / w (= the rank-local sums
+                                  * averaged over the ranks, what DistributedDataParallel makes of SyncBatchNorm's local weight gradients) */
   const float* gamma2;
   const float* beta2;
   float* running_mean2;

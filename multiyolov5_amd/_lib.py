@@ -27,7 +27,7 @@ class BnBwdSeg(C.Structure):
 
 
 class BnSplit(C.Structure):
-    _fields_ = [('c_split', C.c_int32), ('reserved', C.c_int32), ('gamma2', C.c_void_p), ('beta2', C.c_void_p),
+    _fields_ = [('c_split', C.c_int32), ('count_scale', C.c_int32), ('gamma2', C.c_void_p), ('beta2', C.c_void_p),
                 ('running_mean2', C.c_void_p), ('running_var2', C.c_void_p), ('nbt2', C.c_void_p), ('dgamma2', C.c_void_p),
                 ('dbeta2', C.c_void_p)]
 

@@ -10,6 +10,7 @@ namespace {
 // second parameter set for channels >= cs (two BatchNorm modules normalising the halves of ONE merged convolution: C3's cv2 | cv1)
 struct BnSplit {
   int cs;
+  int world;     // ranks whose statistics the arrays hold (myolo_bn_split.count_scale; 1 = this tensor only)
   const float* gamma2; const float* beta2; float* rm2; float* rv2; int64_t* nbt2; float* dgamma2; float* dbeta2;
 };
 
@@ -60,8 +61,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
       for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { sf[k & 3] += stats[k * 2 * C + c]; qf[k & 3] += stats[k * 2 * C + C + c]; }
       const double ssum = ((double)sf[0] + (double)sf[1]) + ((double)sf[2] + (double)sf[3]);
       const double qsum = ((double)qf[0] + (double)qf[1]) + ((double)qf[2] + (double)qf[3]);
-      const double meand = ssum / (double)M;
-      double vard = qsum / (double)M - meand * meand;
+      const int64_t Mg = M * sp.world;                         // samples behind the sums (SyncBatchNorm: all ranks)
+      const double meand = ssum / (double)Mg;
+      double vard = qsum / (double)Mg - meand * meand;
       const float mean = (float)meand;
       float var = vard > 0.0 ? (float)vard : 0.f;
       const float invstd = rsqrtf(var + eps);
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(myolo_tensor y, const f
         float* rmp = lo ? rm : sp.rm2; float* rvp = lo ? rv : sp.rv2;
         if (rmp) {
           rmp[cc] = (1.f - mom) * rmp[cc] + mom * mean;
-          const float unb = M > 1 ? var * (float)M / (float)(M - 1) : var;
+          const float unb = Mg > 1 ? var * (float)Mg / (float)(Mg - 1) : var;
           rvp[cc] = (1.f - mom) * rvp[cc] + mom * unb;
         }
       }
@@ -203,13 +205,15 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(myolo_tensor gout
       float d0 = 0.f, d1 = 0.f;
 #pragma unroll
       for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { d0 += dsum[k * 2 * C + c]; d1 += dsum[k * 2 * C + C + c]; }
-      const float k0 = d0 / (float)M, k1 = d1 / (float)M;
+      const float Mg = (float)M * (float)sp.world;
+      const float k0 = d0 / Mg, k1 = d1 / Mg;
       const float cb = -sc * k1 * istd;
       tab[cl] = sc; tab[CW + cl] = (lo ? beta : sp.beta2)[cc] - mean * sc; tab[2 * CW + cl] = cb; tab[3 * CW + cl] = -sc * k0 - cb * mean;
       if (blockIdx.x == 0) {
         float* dgp = lo ? dgamma : sp.dgamma2; float* dbp = lo ? dbeta : sp.dbeta2;
-        if (dgp) dgp[cc] += d1;
-        if (dbp) dbp[cc] += d0;
+        const float rw = 1.f / (float)sp.world;              // (exact for the power-of-two worlds of one node; 1 without SyncBatchNorm)
+        if (dgp) dgp[cc] += sp.world > 1 ? d1 * rw : d1;
+        if (dbp) dbp[cc] += sp.world > 1 ? d0 * rw : d0;
       }
     } else {
       tab[cl] = 1.f; tab[CW + cl] = 0.f; tab[2 * CW + cl] = 0.f; tab[3 * CW + cl] = 0.f;
@@ -271,14 +275,17 @@ inline bool vec_ok(const myolo_tensor* t) {
 // host view of myolo_bn_split -> kernel argument (no split: cs = C, every channel takes the first parameter set)
 inline bool split_ok(const myolo_bn_split* sp, int C, int seg, bool need_params) {
   if (!sp) return true;
-  if (sp->c_split <= 0 || sp->c_split >= C || sp->c_split % seg) return false;
+  if (sp->count_scale < 0 || sp->c_split <= 0 || sp->c_split > C || sp->c_split % seg) return false;
+  if (sp->c_split == C) return true;                         // no second parameter set (count_scale only)
   return !need_params || (sp->gamma2 && sp->beta2);
 }
 inline BnSplit mk_split(const myolo_bn_split* sp, int C) {
   BnSplit b{};
   b.cs = C;
+  b.world = 1;
   if (sp) {
     b.cs = sp->c_split;
+    b.world = sp->count_scale > 1 ? sp->count_scale : 1;
     b.gamma2 = sp->gamma2; b.beta2 = sp->beta2; b.rm2 = sp->running_mean2; b.rv2 = sp->running_var2; b.nbt2 = sp->nbt2;
     b.dgamma2 = sp->dgamma2; b.dbeta2 = sp->dbeta2;
   }

@@ -128,6 +128,22 @@ class SwitchCall:
         (self.b if self.state[self.key] else self.a)(st)
 
 
+class SyncPoint:
+    """a host-side step inside a launch list: all-reduce (SUM) of a plan-owned fp32 statistics array over the ranks of a process group,
+    enqueued on the current stream between two launches (nn.SyncBatchNorm, train.py:190-193: the per-channel sums of the conv epilogue
+    before BatchNorm's forward, the backward sums before its apply pass).  Behaves like a Call in the Python launch loops; the native
+    executor's program is cut at it (NativeProg.run)."""
+    __slots__ = ('t', 'group', 'name', 'side', 'args', 'keep')
+
+    def __init__(self, t, group):
+        self.t, self.group = t, group
+        self.name, self.side, self.args, self.keep = 'sync_allreduce', False, (), t
+
+    def __call__(self, st=None):
+        import torch.distributed as dist
+        dist.all_reduce(self.t, op=dist.ReduceOp.SUM, group=self.group)     # RCCL: stream-ordered behind / before the neighbouring launches
+
+
 class Op:
     def build(self, plan):      # create Calls (buffers are allocated)
         self.fwd_calls, self.bwd_calls, self.prep_calls = [], [], []
@@ -255,13 +271,18 @@ class ConvOp(Op):
                  weight2=None, bn2=None, bias2=None):
         """weight2 / bn2 / bias2: a SECOND Conv(+BN) of the same geometry on the same input, run in the same launches; its output
         channels follow the first one's (`out` holds c1out + c2out channels; C3.cv2 | C3.cv1, common.py:137)."""
-        for b_ in (bn, bn2):
-            if isinstance(b_, torch.nn.SyncBatchNorm):
-                # train.py:190-193 `--sync-bn`: convert_sync_batchnorm swaps the BatchNorm2d modules of the mirror for SyncBatchNorm.  The
-                # fused statistics kernels reduce over THIS GPU's batch only; running them under that name would silently train with
-                # per-GPU statistics.  (The cross-rank exchange of the per-channel sums is not built: SURVEY 8(e) lists it as optional.)
-                raise L.MyoloError('nn.SyncBatchNorm (train.py --sync-bn) is not supported by the gfx950 BatchNorm kernels: they use '
-                                   'per-GPU batch statistics (plain DistributedDataParallel semantics); drop --sync-bn')
+        # train.py:190-193 `--sync-bn`: convert_sync_batchnorm swaps the BatchNorm2d modules of the mirror for SyncBatchNorm.  With a process
+        # group of more than one rank the per-channel sums are all-reduced between the producing launch and the BatchNorm pass
+        # (SyncPoint) and the kernels count world x n*h*w samples (myolo_bn_split.count_scale); without one it IS BatchNorm2d, as in torch
+        self.sync_world, self.sync_group = 1, None
+        sync = [isinstance(b_, torch.nn.SyncBatchNorm) for b_ in (bn, bn2) if b_ is not None]
+        if any(sync):
+            import torch.distributed as dist
+            if not all(sync) or (bn2 is not None and bn2.process_group is not bn.process_group):
+                raise L.MyoloError('a merged convolution pair mixes BatchNorm2d and SyncBatchNorm (or two process groups)')
+            if dist.is_available() and dist.is_initialized():
+                self.sync_group = bn.process_group
+                self.sync_world = dist.get_world_size(self.sync_group)
         self.x, self.out, self.weight, self.bn, self.bias = x, out, weight, bn, bias
         self.weight2, self.bn2, self.bias2 = weight2, bn2, bias2
         self.k, self.s, self.d, self.act, self.res, self.det = k, s, d, act, res, det
@@ -343,13 +364,17 @@ class ConvOp(Op):
             self.yd, self.od = yv.desc(), self.out.desc()
             self.rd = self.res.desc() if self.res is not None else null_tensor()
             bn = self.bn
-            if has_bn and self.bn2 is not None:
+            if has_bn and (self.bn2 is not None or self.sync_world > 1):
                 b2 = self.bn2
-                assert (b2.eps, b2.momentum) == (bn.eps, bn.momentum)
                 sp = self.split = L.BnSplit()
-                sp.c_split = self.c1out
-                sp.gamma2, sp.beta2, sp.running_mean2 = b2.weight.data_ptr(), b2.bias.data_ptr(), b2.running_mean.data_ptr()
-                sp.running_var2, sp.nbt2 = b2.running_var.data_ptr(), b2.num_batches_tracked.data_ptr()
+                sp.c_split, sp.count_scale = self.cout, self.sync_world          # (c_split == c: no second parameter set)
+                if b2 is not None:
+                    assert (b2.eps, b2.momentum) == (bn.eps, bn.momentum)
+                    sp.c_split = self.c1out
+                    sp.gamma2, sp.beta2, sp.running_mean2 = b2.weight.data_ptr(), b2.bias.data_ptr(), b2.running_mean.data_ptr()
+                    sp.running_var2, sp.nbt2 = b2.running_var.data_ptr(), b2.num_batches_tracked.data_ptr()
+                if self.sync_world > 1:
+                    self.fwd_calls.append(SyncPoint(self.stats, self.sync_group))
                 self.fwd_calls.append(Call('myolo_bn_act_fwd_split', (
                     C.byref(self.yd), L.ptr(self.stats), L.ptr(bn.weight), L.ptr(bn.bias), L.ptr(bn.running_mean),
                     L.ptr(bn.running_var), L.ptr(bn.num_batches_tracked), L.ptr(self.saved), C.c_float(bn.eps),
@@ -427,20 +452,23 @@ class ConvOp(Op):
             if has_bn:
                 bn = self.bn
                 self.dsum = plan.f32_bwd_zero(L.STAT_COPIES * 2 * self.cout)
+                sync = [SyncPoint(self.dsum, self.sync_group)] if self.sync_world > 1 else []
                 if self.bn2 is not None:
                     sp = self.split
                     sp.dgamma2, sp.dbeta2 = plan.pgrad(self.bn2.weight).data_ptr(), plan.pgrad(self.bn2.bias).data_ptr()
                     calls.append(Call('myolo_bn_act_bwd_reduce_split', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
                                                                         L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum),
                                                                         C.byref(sp))))
+                elif self.reduce_by is None:     # (else the dgrad that wrote the last piece of `gout` already left the sums in dsum)
+                    calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
+                                                                  L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
+                calls += sync                    # SyncBatchNorm: the sums of all ranks, before the apply pass reads them
+                if self.bn2 is not None or self.sync_world > 1:
                     calls.append(Call('myolo_bn_act_bwd_apply_split', (
                         C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
                         L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
-                        C.byref(grd), self.res_acc, C.byref(sp))))
+                        C.byref(grd), self.res_acc, C.byref(self.split))))
                 else:
-                    if self.reduce_by is None:   # (else the dgrad that wrote the last piece of `gout` already left the sums in dsum)
-                        calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
-                                                                      L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
                     calls.append(Call('myolo_bn_act_bwd_apply', (
                         C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
                         L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
@@ -957,6 +985,7 @@ class NativeProg:
         lib = L.lib()
         recs, self.names, self.marks, self.switches, self.fixups = [], [], {}, [], []
         self.keep = []
+        self.syncs = []                   # [(program index, SyncPoint)]: host-side collectives between two records
         mut = {id(c): c for c in mutable_cells}
 
         def add_call(c, kind, cond=None, cond_val=0):
@@ -985,6 +1014,8 @@ class NativeProg:
                 add_call(it.b, L.OP_CALL, it.cell, 1)
             elif isinstance(it, Call):
                 add_call(it, L.OP_CALL_SIDE if it.side else L.OP_CALL)
+            elif isinstance(it, SyncPoint):
+                self.syncs.append((len(recs), it))
             elif it[0] == 'memset':
                 r = L.ProgOp()
                 r.kind = L.OP_MEMSET
@@ -1016,6 +1047,18 @@ class NativeProg:
             slot[0] = _slot_value(cell, t)
         last = self.n if last is None else last
         st = torch.cuda.current_stream().cuda_stream
+        pos = first
+        for idx, sp in self.syncs:        # a sync point at index i runs before record i; one that sits exactly at `last` belongs to
+            if idx < first or idx > last or (idx == last and last != self.n):      # the next range (callers walk contiguous ranges)
+                continue
+            if idx > pos:
+                self._run(pos, idx, st, side)
+            sp(None)
+            pos = idx
+        if last > pos or not self.syncs:
+            self._run(pos, last, st, side)
+
+    def _run(self, first, last, st, side):
         e = self._lib.myolo_prog_run(self.handle, first, last, st, side)
         if e:
             i = self._lib.myolo_prog_last_op(self.handle)
@@ -1188,7 +1231,7 @@ class Plan:
         # eval: the launches of a tagged branch go to the side stream (CALL_SIDE: behind everything issued on the main stream so far);
         # the main stream joins before the first op added after the module's own (the output ops read the branch's results)
         self._fwd_side = False
-        if not self.training or TRAIN_BRANCH:
+        if not self.training or (TRAIN_BRANCH and not self.has_sync()):
             for op in self.ops:
                 if getattr(op, 'branch', None):
                     for c in op.fwd_calls:
@@ -1393,8 +1436,15 @@ class Plan:
             for c in op.fwd_calls:
                 c(st)
 
+    def has_sync(self):
+        """the launch lists contain host-side collectives (SyncBatchNorm with more than one rank): no hipGraph capture, one chain"""
+        hs = self.__dict__.get('_has_sync')
+        if hs is None:
+            hs = self._has_sync = any(isinstance(c, SyncPoint) for op in self.ops for c in list(op.fwd_calls) + list(op.bwd_calls))
+        return hs
+
     def graphable(self):
-        return GRAPH_TRAIN and self.training and torch.device(self.device).type == 'cuda'
+        return GRAPH_TRAIN and self.training and torch.device(self.device).type == 'cuda' and not self.has_sync()
 
     def native_ok(self):
         return NATIVE_EXEC and torch.device(self.device).type == 'cuda' and os.environ.get('MYOLO_DBG_SKIP_WGRAD', '0') != '1'

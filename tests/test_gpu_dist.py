@@ -1,6 +1,7 @@
 """-m gpu: the N > 1 code path with real device tensors -- 2 ranks on ONE GPU over gloo, in their own processes (an in-process RCCL /
 gloo group made later tests of the same interpreter flaky): parallel.GradReducer slices issued by the staged backward, the reduced flat
-gradient equals the mean of the two single-rank gradients.  (RCCL itself needs 2 GPUs: that is the driver's SCALE run.)"""
+gradient equals the mean of the two single-rank gradients; nn.SyncBatchNorm against the whole-batch oracle.  (RCCL itself needs 2 GPUs:
+that is the driver's SCALE run.)"""
 import os
 import socket
 import subprocess
@@ -12,15 +13,25 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_two_ranks_on_one_gpu_reduce_to_the_mean_gradient():
+def _run_worker(script):
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.join(ROOT, 'tests', 'dist_worker.py')]
+           '--master-port', str(port), os.path.join(ROOT, 'tests', script)]
     r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode()
     assert r.returncode == 0, out[-3000:]
     assert out.count('-> OK') == 2, out[-3000:]
+
+
+def test_two_ranks_on_one_gpu_reduce_to_the_mean_gradient():
+    _run_worker('dist_worker.py')
+
+
+def test_sync_batchnorm_two_ranks_match_the_whole_batch_oracle():
+    """train.py:190-193 --sync-bn: torch's convert_sync_batchnorm on the mirror, 2 ranks x 2 images; the CPU oracle on all 4 images is the
+    checker (outputs, reduced gradients, running statistics)"""
+    _run_worker('dist_worker_syncbn.py')

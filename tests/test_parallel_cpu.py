@@ -70,6 +70,65 @@ def test_grad_reducer_world2_gloo():
         assert err < 1e-6 and nb == 3
 
 
+def _sync_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from multiyolov5_amd import engine as E
+        from multiyolov5_amd import runtime as R
+        from multiyolov5_amd.models.yolo import Model
+        from tests.util import CFG, TAGS
+        m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(Model(os.path.join(CFG, TAGS['s_psp']))).train()
+        plan = R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float16, True).plan            # dry build (CPU device)
+        assert plan.has_sync() and not plan.graphable()
+        nbn = sum(1 for op in plan.ops if isinstance(op, E.ConvOp) and op.bn is not None)
+        fwd = [c for op in plan.ops for c in op.fwd_calls]
+        bwd = [c for op in reversed(plan.ops) for c in op.bwd_calls]
+        for calls, before, after in ((fwd, ('myolo_conv',), ('myolo_bn_act_fwd_split',)),
+                                     (bwd, None, ('myolo_bn_act_bwd_apply_split',))):
+            idx = [i for i, c in enumerate(calls) if isinstance(c, E.SyncPoint)]
+            assert len(idx) == nbn                                            # one exchange per BatchNorm layer and direction
+            for i in idx:
+                assert calls[i + 1].name in after and (before is None or calls[i - 1].name in before)
+        # every BatchNorm pass of the plan counts the samples of both ranks
+        sp = [op.split for op in plan.ops if isinstance(op, E.ConvOp) and op.bn is not None]
+        assert all(s.count_scale == world for s in sp)
+        assert not any((c.name == 'myolo_bn_act_fwd' and c.args[1] is not None) or (c.name == 'myolo_bn_act_bwd_apply' and c.args[2] is not None)
+                       for c in fwd + bwd if isinstance(c, E.Call))               # (the plain entry points only serve activation-only layers)
+        # the exchange itself (gloo, CPU tensors): the statistics arrays hold the sums over the ranks afterwards
+        op = next(o for o in plan.ops if isinstance(o, E.ConvOp) and o.bn is not None)
+        op.stats.fill_(float(rank + 1))
+        next(c for c in op.fwd_calls if isinstance(c, E.SyncPoint))()
+        assert float(op.stats.min()) == float(op.stats.max()) == 3.0
+        # pruned one-loss backward lists keep the exchange of every layer that still runs, and the items serialise (marks aside)
+        h_det = frozenset({0, 1, 2})
+        items = plan._bwd_items(None, h_det)
+        kept = sum(1 for it in items if isinstance(it, E.SyncPoint))
+        assert 0 < kept < nbn
+        q.put((rank, 'ok', ''))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, 'fail', traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sync_batchnorm_plan_world2_gloo():
+    """nn.SyncBatchNorm (train.py --sync-bn) under a 2-rank group: the launch lists carry one all-reduce of the per-channel sums per
+    BatchNorm layer and direction, between the launch that produces them and the pass that consumes them"""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    for rank, status, err in res:
+        assert status == 'ok', err
+
+
 def test_layout_single_process():
     from multiyolov5_amd.parallel import GradReducer
 

@@ -127,47 +127,54 @@ def test_flat_accumulation_rule():
     assert seen == [True, False, False]
 
 
-def test_sync_batchnorm_is_rejected_loudly():
-    """train.py:190-193 --sync-bn converts the mirror's BatchNorm2d modules: the per-GPU statistics kernels must not run under that name"""
-    from multiyolov5_amd import _lib as L
+def test_sync_batchnorm_without_a_process_group_is_plain_batchnorm():
+    """train.py:190-193 --sync-bn converts the mirror's BatchNorm2d modules.  Like torch's SyncBatchNorm, without an initialised process
+    group (world 1) the layer IS BatchNorm2d: same launch list, no collective (the 2-rank form: tests/test_parallel_cpu.py)"""
+    from multiyolov5_amd import engine as E
     from multiyolov5_amd import runtime as R
     from multiyolov5_amd.models.yolo import Model
     m = Model(os.path.join(CFG, TAGS['s_psp']))
+    ref = _plan()
     m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m).train()
     assert any(isinstance(x, torch.nn.SyncBatchNorm) for x in m.modules())
-    with pytest.raises(L.MyoloError, match='SyncBatchNorm'):
-        R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float16, True)
+    plan = R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), torch.float16, True).plan
+    assert not plan.has_sync()
+    names = lambda pl, which: [c.name for op in pl.ops for c in getattr(op, which)]
+    assert names(plan, 'fwd_calls') == names(ref, 'fwd_calls') and names(plan, 'bwd_calls') == names(ref, 'bwd_calls')
 
 
-def test_native_program_serialises_every_launch_of_a_training_plan():
-    """csrc/plan_exec.hip: every entry point a training plan launches has a thunk, argument slots carry addresses / sign-extended integers /
-    float bit patterns, caller-bound input pointers are registered for per-run patching, the fused-loss switch becomes two conditional ops"""
-    import ctypes as C
-    import struct
-    from multiyolov5_amd import _lib as L
+def test_native_program_walks_ranges_around_sync_points():
+    """NativeProg.run cuts its record range at the host-side collectives: each runs exactly once, before the record it precedes, also
+    when callers walk the program in contiguous pieces (staged backward, gradient slices)"""
     from multiyolov5_amd import engine as E
-    plan = _plan()
-    lib = L.lib()
-    fwd = [c for op in plan.ops for c in op.fwd_calls]
-    bwd = [c for op in plan.ops for c in op.bwd_calls]
-    for c in fwd + bwd:
-        fn = lib.myolo_prog_fn_id(c.name.encode())
-        assert fn >= 0, c.name
-        nargs = len(c.a.args) if isinstance(c, E.SwitchCall) else len(c.args)
-        assert lib.myolo_prog_fn_nargs(fn) == nargs == len(L._PROTOS[c.name][1]) - 1, c.name
-    prog = E.NativeProg(fwd, plan.in_ptr)
-    assert prog.n == len(fwd) and len(prog.fixups) == 1                     # the image pointer of FocusPackOp
-    op_i, arg_i, cell, _ = prog.fixups[0]
-    assert prog.names[op_i] == 'myolo_focus_pack' and cell is plan.in_ptr[0]
-    plan.in_ptr[0].value = 0x1234560
-    assert E._slot_value(plan.in_ptr[0], C.c_void_p) == 0x1234560
-    # slot encodings
-    assert E._slot_value(C.c_float(1.5), C.c_float) == struct.unpack('<I', struct.pack('<f', 1.5))[0]
-    assert E._slot_value(-1, C.c_int) == 0xFFFFFFFFFFFFFFFF and E._slot_value(None, C.c_void_p) == 0
-    d = L.Tensor()
-    assert E._slot_value(C.byref(d), C.POINTER(L.Tensor)) == C.addressof(d)
-    sw = [c for c in bwd if isinstance(c, E.SwitchCall)]
-    assert len(sw) == 1 and isinstance(sw[0].cell, C.c_int32)
+    log = []
+    np_ = E.NativeProg.__new__(E.NativeProg)
+    np_.switches, np_.slots, np_.n, np_.handle = [], [], 10, None
+    np_._run = lambda first, last, st, side: log.append((first, last))
+    mk = lambda k: (lambda st=None: log.append(k))
+    np_.syncs = [(0, mk('a')), (4, mk('b')), (4, mk('c')), (7, mk('d')), (10, mk('e'))]
+    orig = torch.cuda.current_stream
+    torch.cuda.current_stream = lambda: SimpleNamespace(cuda_stream=0)
+    try:
+        np_.run()
+        assert log == ['a', (0, 4), 'b', 'c', (4, 7), 'd', (7, 10), 'e']
+        for cuts in ([0, 4, 10], [0, 3, 7, 10], [0, 5, 6, 10], [0, 7, 7, 10]):
+            del log[:]
+            for f, l in zip(cuts, cuts[1:]):
+                np_.run(f, l)
+            assert [x for x in log if isinstance(x, str)] == ['a', 'b', 'c', 'd', 'e'], (cuts, log)
+            recs = [x for x in log if isinstance(x, tuple)]
+            assert recs[0][0] == 0 and recs[-1][1] == 10 and all(a[1] == b[0] for a, b in zip(recs, recs[1:])), (cuts, log)
+            for k, idx in (('b', 4), ('d', 7)):            # the collective sits between the records before and after its index
+                i = log.index(k)
+                assert all(x[1] <= idx for x in log[:i] if isinstance(x, tuple)) and all(x[0] >= idx for x in log[i:] if isinstance(x, tuple))
+        np_.syncs = []
+        del log[:]
+        np_.run(2, 5)
+        assert log == [(2, 5)]
+    finally:
+        torch.cuda.current_stream = orig
+        np_.handle = None
 
 
 @pytest.mark.parametrize('tag', ['s_psp', 's_base', 's_lab', 's_bise', 'm_lab'])
