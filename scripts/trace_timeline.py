@@ -79,3 +79,12 @@ for lo, hi in bins:
         fam[r['Kernel_Name'].split('<')[0].split('(')[0].replace('void ', '')[:28]] += 1
     top = ', '.join(f'{k} x{v}' for k, v in sorted(fam.items(), key=lambda kv: -kv[1])[:5])
     print(f'  [{lo:3.0f},{hi:5.0f}): {len(rs):4d}  {sum(r["e"] - r["s"] for r in rs) / 1e3:8.1f}   {top}')
+# the end of the backward: the last kernels of every queue before the optimizer (the weight-gradient queue's exposed tail)
+opt = [i for i, r in enumerate(step) if 'mt_' in r['Kernel_Name'] or 'scaler' in r['Kernel_Name']]
+if opt:
+    first_opt = step[opt[0]]
+    print(f'end of the backward (optimizer starts at +{(first_opt["s"] - t0) / 1e3:.1f} us):')
+    for q, rs in byq.items():
+        pre = sorted([r for r in rs if r['e'] <= first_opt['s']], key=lambda r: r['s'])[-7:]
+        for r in pre:
+            print(f'  q{q} +{(r["s"] - t0) / 1e3:8.1f} .. +{(r["e"] - t0) / 1e3:8.1f} ({(r["e"] - r["s"]) / 1e3:6.1f} us)  {r["Kernel_Name"][:70]}')
