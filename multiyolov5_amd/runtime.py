@@ -455,6 +455,11 @@ def _accumulate_in_place(holder, plan):
 import os as _os
 GRAPH_EVAL = _os.environ.get('MYOLO_GRAPH', '1') != '0'
 SPLIT_EVAL = _os.environ.get('MYOLO_SPLIT_EVAL', '1') != '0'      # eval graphs: the side-stream branch is not joined inside the forward
+# how the three pieces of a split eval forward are issued (r3k trace: the main queue sat idle ~140 us between graph A's last kernel and
+# graph B's first one although B had been enqueued long before): 'g' = hipGraph replay, 'e' = the native launch program, eagerly
+EVAL_TAIL = _os.environ.get('MYOLO_EVAL_TAIL', 'g')                # graph B (neck tail + Detect, main stream)
+EVAL_HEAD = _os.environ.get('MYOLO_EVAL_HEAD', 'g')                # graph C (segmentation head, side stream)
+EVAL_ORDER = _os.environ.get('MYOLO_EVAL_ORDER', 'cb')             # host order of the two launches behind graph A
 
 
 class PlanHolder:
@@ -534,6 +539,7 @@ class PlanHolder:
                     with torch.cuda.graph(gc, stream=side):
                         ps.run()
                     st['_graph_b'], st['_graph_c'] = gb, gc
+                    st['_split'] = split
                     st['_fork_ev'], st['_branch_done'] = torch.cuda.Event(), torch.cuda.Event()
                     st['_branch_pending'] = False
                 st['_graph'] = g
@@ -554,12 +560,21 @@ class PlanHolder:
                     s_.copy_(t)
             st['_graph'].replay()
             st['_fork_ev'].record(main)
-            side.wait_event(st['_fork_ev'])
-            with torch.cuda.stream(side):
-                st['_graph_c'].replay()
-                st['_branch_done'].record(side)
-            st['_branch_pending'] = True
-            st['_graph_b'].replay()
+            pm, fork, ps = st['_split']
+            for which in EVAL_ORDER:
+                if which == 'c':
+                    side.wait_event(st['_fork_ev'])
+                    with torch.cuda.stream(side):
+                        if EVAL_HEAD == 'e':
+                            ps.run()
+                        else:
+                            st['_graph_c'].replay()
+                        st['_branch_done'].record(side)
+                    st['_branch_pending'] = True
+                elif EVAL_TAIL == 'e':
+                    pm.run(fork, pm.n)
+                else:
+                    st['_graph_b'].replay()
             return self.output_tensors()
         for s_, t in zip(self._static_in, tensors):
             if s_.data_ptr() != t.data_ptr():
