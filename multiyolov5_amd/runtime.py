@@ -631,7 +631,7 @@ class PlannedModule(nn.Module):
     forwards (accumulated predictions, one module used twice inside an Ensemble) must clone them -- models.experimental.Ensemble
     does.  A backward through activations that a newer forward has overwritten raises (forward generation counter)."""
 
-    _RUNTIME_STATE = ('_plans', '_tensor_list', '_prepared_version', '_grad_reducer')
+    _RUNTIME_STATE = ('_plans', '_tensor_list', '_prepared_version', '_grad_reducer', '_has_sync_bn')
 
     def __getstate__(self):
         """pickling / deepcopy (checkpoints, ModelEMA) carries the module, not its launch plans (device buffers, ctypes descriptors)"""
@@ -655,7 +655,7 @@ class PlannedModule(nn.Module):
         dtype = compute_dtype(tensors)
         grad = torch.is_grad_enabled() and self.training
         key = (tuple((tuple(t.shape), tuple(t.stride()), t.dtype, bool(t.requires_grad and grad)) for t in tensors),
-               str(spec), dtype, bool(self.training), grad)
+               str(spec), dtype, bool(self.training), grad, self._sync_world())
         plans = self.__dict__.setdefault('_plans', {})
         h = plans.get(key)
         sig = self._sig()
@@ -679,6 +679,17 @@ class PlannedModule(nn.Module):
 
     def _param_version(self):
         return sum(t._version for t in self._tensors())
+
+    def _sync_world(self):
+        """ranks a training plan's nn.SyncBatchNorm layers exchange statistics with (part of the plan key: a plan built before
+        init_process_group counts this GPU's samples only); 0 for models without SyncBatchNorm and for eval"""
+        has = self.__dict__.get('_has_sync_bn')
+        if has is None:
+            has = self.__dict__['_has_sync_bn'] = any(isinstance(m, nn.SyncBatchNorm) for m in self.modules())
+        if not (has and self.training and torch.distributed.is_available() and torch.distributed.is_initialized()):
+            return 0
+        g = next(m.process_group for m in self.modules() if isinstance(m, nn.SyncBatchNorm))
+        return torch.distributed.get_world_size(g)
 
     def forward(self, x):
         tensors = []
@@ -731,3 +742,4 @@ class PlannedModule(nn.Module):
     def invalidate_plans(self):
         self.__dict__.pop('_plans', None)
         self.__dict__.pop('_tensor_list', None)
+        self.__dict__.pop('_has_sync_bn', None)        # (convert_sync_batchnorm after a first forward: call this)
