@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--sync-bn', action='store_true', help='train.py --sync-bn: nn.SyncBatchNorm statistics over all ranks (N > 1)')
     return ap.parse_args()
 
 
@@ -117,6 +118,9 @@ class Trainer:
             if world > 1:
                 from multiyolov5_amd.parallel import GradReducer
                 self.reducer = GradReducer(m, world)
+            if args.sync_bn:                           # train.py:190-193 (after the optimizer's parameter groups, as there)
+                self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+                self.model.invalidate_plans()
         else:
             self.fixed = None
 
@@ -518,7 +522,7 @@ def main():
         'config': {'workload': (f'{args.cfg} bs={args.batch}/GPU {W}x{H} {args.dtype} joint train step'
                                 + (' (psp head; BASELINE configs[1])' if args.cfg == 'yolov5s_city_seg.yaml' and args.batch == 16
                                    and args.dtype == 'f16' else '')),
-                   'global_batch': args.batch * world, 'parallelism': f'dp{world}', 'stage': args.stage},
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+syncbn' if args.sync_bn else ''), 'stage': args.stage},
     }
     out['checks'] = checks
     if world > 1:
