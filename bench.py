@@ -46,22 +46,56 @@ def parse():
     ap.add_argument('--no-infer', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--sync-bn', action='store_true', help='train.py --sync-bn: nn.SyncBatchNorm statistics over all ranks (N > 1)')
+    ap.add_argument('--ddp', default='reducer', choices=['reducer', 'stock'],
+                    help="N > 1 gradient exchange: 'reducer' = parallel.GradReducer (3 flat slices on a side stream), 'stock' = the model "
+                         "wrapped in torch.nn.parallel.DistributedDataParallel exactly as train.py:243-245 does")
+    ap.add_argument('--dry-dist', action='store_true',
+                    help='dev/test only: set the process group up, check the world size against --gpus, print the header line and exit '
+                         '(no GPU needed with MYOLO_DIST_BACKEND=gloo; NOT a bench line)')
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: re-execute this command line under torch.distributed.run with
+    one rank per GPU (the form the header documents) and hand its exit code back.  Under a launcher (WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return None
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if not port:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def setup_dist(args):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to print a line whose '
+                         f'n_gpus would not be the number of GPUs asked for')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
+    elif not args.dry_dist:
+        raise SystemExit('bench.py: no GPU visible (the product path has no CPU fallback)')
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        backend = os.environ.get('MYOLO_DIST_BACKEND', 'nccl')       # 'gloo' only for single-GPU smoke tests of the N>1 path
+        backend = os.environ.get('MYOLO_DIST_BACKEND', 'nccl')       # 'gloo' only for single-GPU / CPU smoke tests of the N>1 path
         if backend == 'nccl':
             dist.init_process_group(backend='nccl', init_method='env://', device_id=torch.device('cuda', local))
         else:
             dist.init_process_group(backend=backend, init_method='env://')
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f'bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}')
     return world, rank, local
 
 
@@ -115,12 +149,19 @@ class Trainer:
             self.scaler = GradScaler(enabled=self.dtype == torch.float16)
             self.ema = ModelEMA(m) if rank == 0 else None
             self.reducer = None
-            if world > 1:
+            if world > 1 and args.ddp == 'reducer':
                 from multiyolov5_amd.parallel import GradReducer
                 self.reducer = GradReducer(m, world)
             if args.sync_bn:                           # train.py:190-193 (after the optimizer's parameter groups, as there)
                 self.model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
                 self.model.invalidate_plans()
+            self.raw_model = self.model
+            if world > 1 and args.ddp == 'stock':      # train.py:243-245
+                from torch.nn.parallel import DistributedDataParallel as DDP
+                if dev.type == 'cuda':
+                    self.model = DDP(self.model, device_ids=[dev.index], output_device=dev.index)
+                else:
+                    self.model = DDP(self.model)
         else:
             self.fixed = None
 
@@ -151,7 +192,7 @@ class Trainer:
         self.scaler.update()
         self.opt.zero_grad()
         if self.ema is not None:
-            self.ema.update(m)                                           # train.py:400-401
+            self.ema.update(self.raw_model)                              # train.py:400-401 (model.module under DDP)
         self.last = (loss, segloss)
 
 
@@ -479,7 +520,23 @@ def augment_rates(dev, n=24):
 
 def main():
     args = parse()
+    rc = spawn_ranks(args)
+    if rc is not None:
+        sys.exit(rc)
     world, rank, local = setup_dist(args)
+    if args.dry_dist:
+        n = world
+        if world > 1:
+            t = torch.ones(1)
+            dist.all_reduce(t)                           # every rank is really there
+            n = int(t.item())
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({'metric': 'DEV ONLY launch check -- not a bench line', 'n_gpus': n, 'value': None,
+                              'config': {'parallelism': f'dp{world}', 'ddp': args.ddp}}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     dev = torch.device('cuda', local if local < torch.cuda.device_count() else 0)
     from multiyolov5_amd import _lib
     _lib.lib()                                           # fail loudly if the HIP library is missing
@@ -522,8 +579,11 @@ def main():
         'config': {'workload': (f'{args.cfg} bs={args.batch}/GPU {W}x{H} {args.dtype} joint train step'
                                 + (' (psp head; BASELINE configs[1])' if args.cfg == 'yolov5s_city_seg.yaml' and args.batch == 16
                                    and args.dtype == 'f16' else '')),
-                   'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+syncbn' if args.sync_bn else ''), 'stage': args.stage},
+                   'global_batch': args.batch * world, 'parallelism': f'dp{world}' + ('+syncbn' if args.sync_bn else ''), 'stage': args.stage,
+                   'grad_exchange': None if world == 1 else ('torch DistributedDataParallel (train.py:243-245)' if args.ddp == 'stock'
+                                                              else 'parallel.GradReducer: 3 flat slices, RCCL on a side stream')},
     }
+    assert out['n_gpus'] == args.gpus, (out['n_gpus'], args.gpus)
     out['checks'] = checks
     if world > 1:
         # the main stream's wait for the RCCL slices at the end of the backward (HIP events, mean over the timed steps, this rank):
