@@ -1072,6 +1072,21 @@ class NativeProg:
             pass
 
 
+_RKEY_SERIAL = [0]
+
+
+def _rkey(reducer):
+    """cache key of a gradient-cut object (parallel.GradReducer / runtime.StageCuts): a serial number stored ON the object plus its layout
+    parameters -- an id() can be reused by a rebuilt reducer with a different bucket layout"""
+    if reducer is None:
+        return None
+    d = reducer.__dict__
+    if '_myolo_serial' not in d:
+        _RKEY_SERIAL[0] += 1
+        d['_myolo_serial'] = _RKEY_SERIAL[0]
+    return (d['_myolo_serial'], getattr(reducer, 'nbuckets', None), getattr(reducer, 'world', None))
+
+
 class Plan:
     """A built forward (+backward) launch plan for one (module, input shapes, dtype, mode)."""
 
@@ -1420,7 +1435,8 @@ class Plan:
         if self._pack_call is not None and self._pack_key != tuple((j[0].data_ptr(), j[8].data_ptr() if j[8] is not None else 0) for j in self._pack_jobs):
             self._build_pack_table()                          # a parameter was re-allocated (.to(), load): new table, new graphs
             self.__dict__.pop('_graphs', None)
-            self.__dict__.pop('_nprog_fwd', None)
+            for k in ('_nprog_fwd', '_nprog_bwd', '_split_progs'):        # every native program carries the old pointers
+                self.__dict__.pop(k, None)
 
     def _fwd_lists(self):
         """(ops reading caller tensors -> eager, every other op -> graph)"""
@@ -1550,7 +1566,7 @@ class Plan:
 
     def grad_buckets(self, reducer):
         """bucket layout of flat_grad for a parallel.GradReducer (cached per reducer)."""
-        key = id(reducer)
+        key = _rkey(reducer)
         if getattr(self, '_bucket_key', None) != key:
             sizes = [p.numel() for p in self.params]
             first = [self._pg_first_op.get(id(p), 0) for p in self.params]
@@ -1573,8 +1589,8 @@ class Plan:
         """cut points of the backward op list (descending op index): [(hi, lo, [buckets ready after op lo])] -- a bucket boundary
         always ends a segment, the rest is balanced by launch count"""
         cache = self.__dict__.setdefault('_seg_cache', {})
-        if id(reducer) in cache:
-            return cache[id(reducer)]
+        if _rkey(reducer) in cache:
+            return cache[_rkey(reducer)]
         pending = list(self.grad_buckets(reducer)) if reducer is not None else []
         n = len(self.ops)
         cuts = {0}
@@ -1597,7 +1613,7 @@ class Plan:
             ready = [(a, b) for a, b, r in pending if lo <= r < hi] if lo > 0 else [(a, b) for a, b, r in pending if r < hi]
             segs.append((hi, lo, ready))
             hi = lo
-        cache[id(reducer)] = segs
+        cache[_rkey(reducer)] = segs
         return segs
 
     def _seg_main(self, st, hi, lo, with_side):
@@ -1619,12 +1635,12 @@ class Plan:
         if not self.graphable() or g is None or 'fwd' not in g or g.get('failed'):
             return False
         use_side = self.use_side_stream
-        if g.get('bwd_key') == (id(reducer), use_side):
+        if g.get('bwd_key') == (_rkey(reducer), use_side):
             return True
         try:
             caps = []
             if GRAPH_BWD == 'fork' and reducer is None:
-                g['bwd'], g['bwd_key'] = [(self._capture(lambda s: self._bwd_eager(None)), 'fork')], (id(reducer), use_side)
+                g['bwd'], g['bwd_key'] = [(self._capture(lambda s: self._bwd_eager(None)), 'fork')], (_rkey(reducer), use_side)
                 return True
             for hi, lo, _ in self._bwd_segments(reducer):
                 gm = self._capture(lambda s, hi=hi, lo=lo: self._seg_main(s, hi, lo, use_side))
@@ -1632,7 +1648,7 @@ class Plan:
                 if use_side and any(c.side for i in range(lo, hi) for c in self.ops[i].bwd_calls):
                     gs = self._capture(lambda s, hi=hi, lo=lo: self._seg_side(s, hi, lo))
                 caps.append((gm, gs))
-            g['bwd'], g['bwd_key'] = caps, (id(reducer), use_side)
+            g['bwd'], g['bwd_key'] = caps, (_rkey(reducer), use_side)
             return True
         except Exception as e:  # noqa: BLE001 -- capture is an optimisation only
             import warnings
@@ -1683,7 +1699,7 @@ class Plan:
         """the backward launch list as a native program, cut at the gradient-slice boundaries of `reducer`.  `live`: see _bwd_items
         (the SAME program object as live=None when nothing can be pruned)"""
         cache = self.__dict__.setdefault('_nprog_bwd', {})
-        key = (id(reducer), live)
+        key = (_rkey(reducer), live)
         if key not in cache:
             items = self._bwd_items(reducer, live)
             if items == 'full':
@@ -1773,7 +1789,7 @@ class Plan:
         if graphed and 'bwd' not in g:
             graphed = self.capture_bwd(reducer)
         use_side = self.flat_grad.is_cuda and self.use_side_stream
-        if graphed and g.get('bwd_key') != (id(reducer), use_side):
+        if graphed and g.get('bwd_key') != (_rkey(reducer), use_side):
             graphed = False                                   # reducer attached / detached after the capture: eager this time
         if not graphed:
             self._bwd_eager(reducer)

@@ -293,9 +293,13 @@ def _stage_plan(holder):
         return None
     red = holder.module.__dict__.get('_grad_reducer')
     cuts = red if red is not None else holder.__dict__.setdefault('_stage_cuts', StageCuts())
-    key = id(cuts)
+    # the cut object itself is held (an id() can be reused by a rebuilt reducer with another layout) together with the parameters'
+    # requires_grad flags: a stage whose parameters are all frozen (train.py `freeze`) would never be visited by autograd
+    flags = tuple(bool(p.requires_grad) for p in plan.params)
+    key = (cuts, flags)
     st = holder.__dict__.get('_stages')
-    if st is not None and st[0] == key:
+    if st is not None and st[0][0] is cuts and st[0][1] == flags and \
+            (st[1] is None or holder.__dict__.get('_stage_prog') is plan._native_bwd(cuts)):   # (a re-packed plan has new programs)
         return st[1]
     stages = None
     if plan.flat_grad.is_cuda:
@@ -325,6 +329,10 @@ def _stage_plan(holder):
                 sg['params'] = [i for i, o in enumerate(offs) if any(a <= o < b for a, b in sg['slices'])]
             covered = sorted(i for sg in stages for i in sg['params'])
             if len(stages) < 2 or covered != [i for i in range(len(plan.params)) if plan.params[i].numel() > 0]:
+                stages = None
+            elif not all(any(flags[i] for i in sg['params']) for sg in stages):
+                # autograd only runs a stage's backward when something behind it needs a gradient; a stage of frozen
+                # parameters (and inputs that need none) would be skipped together with the final join / flat accumulation: one node
                 stages = None
             else:
                 holder._stage_prog, holder._stage_cut_obj = np_, cuts
@@ -553,8 +561,9 @@ class PlanHolder:
                 return self.output_tensors()
         if st.get('_graph_c') is not None:
             main, side = torch.cuda.current_stream(), self.plan._side_stream()
-            if st['_branch_pending']:
+            if st['_branch_pending'] or st.get('_branch_main_owes'):
                 main.wait_event(st['_branch_done'])      # the previous frame's head may still be reading the neck features
+                st['_branch_main_owes'] = False
             for s_, t in zip(self._static_in, tensors):
                 if s_.data_ptr() != t.data_ptr():
                     s_.copy_(t)
@@ -571,6 +580,7 @@ class PlanHolder:
                             st['_graph_c'].replay()
                         st['_branch_done'].record(side)
                     st['_branch_pending'] = True
+                    st['_branch_main'] = main
                 elif EVAL_TAIL == 'e':
                     pm.run(fork, pm.n)
                 else:
@@ -586,8 +596,11 @@ class PlanHolder:
         """the main stream waits for the un-joined branch of the last eval forward (no-op without one)"""
         st = self.__dict__
         if st.get('_branch_pending'):
-            torch.cuda.current_stream().wait_event(st['_branch_done'])
+            cur = torch.cuda.current_stream()
+            cur.wait_event(st['_branch_done'])
             st['_branch_pending'] = False
+            # a consumer on ANOTHER stream waited, the launch stream of the next forward has not (ADVICE r3): it still owes the wait
+            st['_branch_main_owes'] = cur != st.get('_branch_main', cur)
 
     def bind_inputs(self, tensors):
         for i, t in enumerate(tensors):

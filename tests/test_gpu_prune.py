@@ -157,3 +157,47 @@ def test_pruned_backward_fp16_amp(monkeypatch):
                 rels.append(float((ga[k] - gb[k]).norm() / gb[k].norm()))
         rels.sort()
         assert rels[len(rels) // 2] < 0.2, f'step {i}: median relative difference {rels[len(rels) // 2]:.2f}'
+
+
+def test_staged_chain_with_a_frozen_backbone(monkeypatch):
+    """ADVICE r3 (runtime._stage_plan): train.py's `freeze` list sets requires_grad = False on the early backbone layers.  With every
+    parameter of the deepest stage frozen (and images that need no gradient) autograd would never visit that stage -- the final join and
+    the flat accumulation would be skipped and ALL gradients of the pass dropped.  The chain must fall back to one node: gradients of the
+    live parameters equal the unfrozen run's, frozen ones stay None, a second backward still works."""
+    from multiyolov5_amd import engine as E, runtime as R
+    monkeypatch.setattr(R, 'STAGED_BWD', 'force')
+    m, sd, hyp = build('s_psp')
+    x, _ = tie_free_images('s_psp', 2, H, W)
+    x = x.to(DEV)
+    targets = synth.synth_det_targets(2, 8, 10, seed=1).to(DEV)
+    mask = synth.synth_seg_targets(2, H, W, 19, seed=1).to(DEV)
+
+    def one():
+        m.zero_grad(set_to_none=True)
+        m.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True)
+        losses(m, x, targets, mask, ('det', 'seg')).backward()
+        torch.cuda.synchronize()
+        return grads_of(m)
+    ref = one()
+    h = next(iter(m.__dict__['_plans'].values()))
+    stages = h.__dict__['_stages'][1]
+    assert stages and len(stages) >= 2
+    last = stages[-1]['params']
+    names = [k for k, _ in m.named_parameters()]
+    plist = list(h.plan.params)
+    frozen = {id(plist[i]) for i in last}
+    for p in m.parameters():
+        if id(p) in frozen:
+            p.requires_grad_(False)
+    for rep in range(2):
+        g = one()
+        assert h.__dict__['_stages'][1] is None, 'a stage of frozen parameters: the chain falls back to one autograd node'
+        assert not h.pending_bwd
+        bad = []
+        for (k, p) in m.named_parameters():
+            if id(p) in frozen:
+                assert g[k] is None
+            else:
+                check(f'frozen_stage/{rep}/{k}', g[k], ref[k], 1e-3, collect=bad)
+        assert not bad, '\n'.join(bad[:20])
+    assert len(names) > len(frozen) > 0
