@@ -1,0 +1,385 @@
+// Training convolutions of the mid-size / small maps (fp16, raw output + BatchNorm statistics, and their dgrads) for gfx950 (CDNA4).
+//
+//   GEMM view as in conv_igemm.hip: M = N*Ho*Wo pixels, N = Cout, K = ntaps*Cin -- for M = 8192 .. 131072, N = 64 .. 512,
+//   K = 128 .. 2304 (the 32x64 / 16x32 stages at batch 16 and the 3x3 layers of the segmentation head).  conv_igemm ran these at
+//   0.06-0.14 of their per-layer roofline (profiles/r3j_conv_layers.md): one 4-wave workgroup per CU, ONE wave per SIMD, a 64-byte K
+//   step staged global -> registers -> LDS with ~110 address instructions, 16 MFMAs and a barrier per step -- a serial chain per SIMD.
+//
+//   This kernel:
+//     * 128-byte K steps (64 halves) staged with LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no ds_write pass) into a
+//       3-stage ring; the loads of step s+2 are issued before the MFMAs of step s, waits are COUNTED (`s_waitcnt vmcnt(L)`: the next
+//       stage stays in flight across the barrier), one raw `s_barrier` per step;
+//     * 8 waves per 128 x 128 tile (two per SIMD: one wave's LDS reads sit under the other's MFMAs), 16 MFMAs per wave and step;
+//     * the per-row addresses (pixel base offset, a bit mask of the taps that fall inside the image) are computed once per tile; a
+//       K step costs two scalar table reads, one select and one add per load;
+//     * LDS rows are 128 B, the 16-byte segment XOR-ed with (row >> 1) & 7: conflict-free for the ds_read_b128 lane groups of the
+//       MFMA fragment pattern (brute-forced over all bases); the LDS-DMA image is lane-linear, so the swizzle is applied to the SOURCE
+//       address (lane l of a 1 KB piece fetches logical segment (l & 7) ^ swizzle of row l >> 3);
+//     * D^T = W . X^T over the row-permuted weight tile (panel_chan, myolo_dev.h): a lane owns 8 consecutive channels of one pixel ->
+//       16-byte NHWC stores straight from the accumulators, BatchNorm statistics reduced over the 16 pixel lanes by shuffles.
+//
+// Replaces: nn.Conv2d in training mode (reference models/common.py:34-46: the conv of Conv / Bottleneck / C3 / SPP / PSP head) and its
+// autograd dgrad.  Epilogues: raw store (+ statistics) (+ residual) (+ accumulate).  Everything else stays on conv_igemm.
+#include "myolo_dev.h"
+#include <string.h>
+#include <stdlib.h>
+
+namespace mid {
+
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+struct MidK {
+  const char* x; const char* w; char* y; const char* res; float* stats;
+  int x_sn, x_sh, x_sw;            // bytes
+  int y_sn, y_sh, y_sw;
+  int r_sn, r_sh, r_sw;
+  int Hi, Wi, Wo, HWo, M, Cout;
+  int stride, ntaps, kchunks, nsteps;
+  int wrow_bytes;                  // bytes between two output-channel rows of the packed weights (wtaps * cin_pad * 2)
+  int ntile_p, tiles_per_xcd, accumulate;
+  int dbg;                         // profiling only: 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores
+  int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
+  int tap_xoff[MYOLO_MAX_TAPS];    // (dy * x_sh + dx * x_sw) bytes
+  int tap_woff[MYOLO_MAX_TAPS];    // tap_w[t] * cin_pad * 2 bytes
+};
+
+// sum over the 16 lanes of a DPP row, valid in lane 15 of the row: four v_add_f32 with a row_shr operand (no LDS crossbar permutes)
+__device__ __forceinline__ float row_sum16(float v) {
+#define MID_SHR(n) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + (n), 0xf, 0xf, true))
+  v += MID_SHR(1); v += MID_SHR(2); v += MID_SHR(4); v += MID_SHR(8);
+#undef MID_SHR
+  return v;
+}
+
+// BM x BN output tile (pixels x channels), WP x WC waves (each (BM/WP) pixels x (BN/WC) channels), NST LDS stages
+template <int BM, int BN, int WP, int WC, int NST, bool DBG>
+__global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
+  constexpr int NT = 64 * WP * WC;
+  constexpr int PW = BM / WP, CW = BN / WC;       // wave tile
+  constexpr int PF = PW / 16, CF = CW / 16;       // 16 x 16 fragments per wave
+  static_assert(CF % 2 == 0, "channel fragments are stored in pairs (8 consecutive channels per lane)");
+  constexpr int RPI = NT / 8;                     // rows per load instruction of the workgroup (8 lanes per 128-byte row)
+  constexpr int XR = BM / RPI, WR = BN / RPI;     // loads per thread and stage
+  static_assert(XR >= 1 && WR >= 1 && BM % RPI == 0 && BN % RPI == 0, "tile rows must divide over the loader lanes");
+  constexpr int LPS = XR + WR;
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wp = wave / WC, wc = wave % WC;
+  const int lq = lane >> 4, l15 = lane & 15;
+  const int tn = blockIdx.y;
+  const int xcd = blockIdx.x & 7, bslot = blockIdx.x >> 3, bstride = gridDim.x >> 3;
+
+  // loader role: row (tid >> 3) (+ j * RPI), physical segment tid & 7 <- logical segment lsg
+  const int lrow = tid >> 3;
+  const int lsg = (tid & 7) ^ ((lrow >> 1) & 7);
+  int wbase[WR];
+#pragma unroll
+  for (int j = 0; j < WR; ++j) wbase[j] = (tn * BN + panel_chan(j * RPI + lrow)) * p.wrow_bytes + lsg * 16;
+
+  // fragment reads: row l15 of a 16-row fragment, K segment kk*4 + lq, swizzled
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)smem;
+  unsigned foff[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) foff[kk] = l15 * 128 + (((kk * 4 + lq) ^ ((l15 >> 1) & 7)) << 4);
+
+  // lane t holds tap t's (dy, dx): ONE vector read of the kernel-argument table
+  const int v_dy = p.tap_dy[lane < MYOLO_MAX_TAPS ? lane : 0], v_dx = p.tap_dx[lane < MYOLO_MAX_TAPS ? lane : 0];
+
+  float st_s[CF / 2][8], st_q[CF / 2][8];
+#pragma unroll
+  for (int q = 0; q < CF / 2; ++q)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { st_s[q][i] = 0.f; st_q[q][i] = 0.f; }
+
+  for (int tslot = bslot; tslot < p.tiles_per_xcd; tslot += bstride) {
+    const int tp = xcd * p.tiles_per_xcd + tslot;
+    if (tp >= p.ntile_p) break;
+    const int m0 = tp * BM;
+
+    int xbase[XR]; unsigned xmask[XR];
+#pragma unroll
+    for (int j = 0; j < XR; ++j) {
+      const int m = m0 + j * RPI + lrow;
+      const bool valid = m < p.M;
+      const int mm = valid ? m : 0;
+      const int n = mm / p.HWo; const int rem = mm - n * p.HWo;
+      const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+      const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+      xbase[j] = n * p.x_sn + iy0 * p.x_sh + ix0 * p.x_sw + lsg * 16;
+      unsigned mk = 0;
+      for (int t = 0; t < p.ntaps; ++t) {          // (tap offsets by readlane: a scalar table read per tap and row was a chain of ~0.25 us loads)
+        const int iy = iy0 + __builtin_amdgcn_readlane(v_dy, t), ix = ix0 + __builtin_amdgcn_readlane(v_dx, t);
+        mk |= (unsigned)(valid && iy >= 0 && iy < p.Hi && ix >= 0 && ix < p.Wi) << t;
+      }
+      xmask[j] = mk;
+    }
+
+    f4_t acc[CF][PF];
+#pragma unroll
+    for (int c = 0; c < CF; ++c)
+#pragma unroll
+      for (int q = 0; q < PF; ++q) acc[c][q] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+    int i_tap = 0, i_kc = 0;                       // issue cursor
+    // table entries of the NEXT issue: the scalar reads run a step ahead and are first touched behind the next barrier (a use inside
+    // this step would make hipcc wait lgkmcnt(0) in the middle of the fragment reads)
+    int n_xt = p.tap_xoff[0], n_wt = p.tap_woff[0];
+    const char* src[LPS];
+    auto addresses = [&]() {                       // source addresses of the next stage's LPS pieces (+ cursor advance)
+      const int t = i_tap;
+      const int xo = n_xt + i_kc * 128, wo = n_wt + i_kc * 128;
+#pragma unroll
+      for (int j = 0; j < XR; ++j)                 // per-lane select: taps outside the image / rows past M fetch the zero page; the load itself is unconditional
+        src[j] = ((xmask[j] >> t) & 1u) ? p.x + (unsigned)(xbase[j] + xo) : zero_page();
+#pragma unroll
+      for (int j = 0; j < WR; ++j) src[XR + j] = p.w + (unsigned)(wbase[j] + wo);
+      if (++i_kc == p.kchunks) { i_kc = 0; ++i_tap; }
+      const int tn_ = i_tap < p.ntaps ? i_tap : 0;
+      n_xt = p.tap_xoff[tn_]; n_wt = p.tap_woff[tn_];
+    };
+    auto piece = [&](int i, int buf) {             // one 1 KB LDS-DMA piece of this wave: 8 rows x 128 B, lane-linear in LDS
+      char* dst = smem + buf * STAGE + wave * 1024 + (i < XR ? i * RPI * 128 : BM * 128 + (i - XR) * RPI * 128);
+      __builtin_amdgcn_global_load_lds((gptr_t*)src[i], (lptr_t*)dst, 16, 0, 0);
+    };
+    // One K step.  The fragment reads and their waits are inline asm: hipcc's waitcnt pass makes every ds_read it can see wait for ALL
+    // outstanding LDS-DMA (vmcnt(0): it cannot tell the stage being read from the stages in flight), which would serialise the ring.
+    // The "+v" operands behind a wait tie the fragments to it, so the MFMAs that consume them cannot be scheduled above it.
+    // The LDS-DMA pieces of stage s + NST-1 are issued BETWEEN the MFMA groups (an LDS-DMA issue holds its wave for 60-180 cycles,
+    // MI355X_MICROARCH.md: issued in a block ahead of the reads -- both waves of a SIMD leave the barrier together -- the matrix pipe
+    // idled through it; scripts/conv_train_ubench.py PROBE=mid_dbg: loads alone 4.9 us, MFMAs alone 5.4, together 11.5 of an 18-step tile).
+    constexpr int G = 2 * CF;                      // MFMA groups (PF MFMAs each) per step
+    auto step = [&](int buf, int nb, const bool do_issue) {
+      const unsigned ax = lds0 + buf * STAGE + (wp * PW) * 128, aw = lds0 + buf * STAGE + BM * 128 + (wc * CW) * 128;
+      u32x4_t wf[2][CF], xf[2][PF];
+      if (DBG && (p.dbg & 2)) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int c = 0; c < CF; ++c) wf[kk][c] = u32x4_t{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+#pragma unroll
+          for (int q = 0; q < PF; ++q) xf[kk][q] = u32x4_t{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+          for (int c = 0; c < CF; ++c) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[kk][c]) : "v"(aw + foff[kk]), "n"(c * 2048) : "memory");
+#pragma unroll
+          for (int q = 0; q < PF; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[kk][q]) : "v"(ax + foff[kk]), "n"(q * 2048) : "memory");
+        }
+      }
+      const bool loads = do_issue && !(DBG && (p.dbg & 1));
+      if (loads) addresses();
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        __builtin_amdgcn_sched_barrier(0);         // (keeps the address arithmetic / the first half's MFMAs above the wait)
+        if (kk == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(CF + PF) : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < CF; ++c) asm volatile("" : "+v"(wf[kk][c]));
+#pragma unroll
+        for (int q = 0; q < PF; ++q) asm volatile("" : "+v"(xf[kk][q]));
+#pragma unroll
+        for (int c = 0; c < CF; ++c) {
+          if (!(DBG && (p.dbg & 4))) {
+#pragma unroll
+            for (int q = 0; q < PF; ++q)
+              acc[c][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8_t*>(&wf[kk][c]), *reinterpret_cast<const h8_t*>(&xf[kk][q]),
+                                                                 acc[c][q], 0, 0, 0);
+          }
+          const int g = kk * CF + c;
+#pragma unroll
+          for (int i = 0; i < LPS; ++i)
+            if ((i * G) / LPS == g && loads) {
+              __builtin_amdgcn_sched_barrier(0);
+              piece(i, nb);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+      }
+    };
+
+    // ring of NST stages: the loads of step s + NST-1 are issued during the MFMAs of step s.  A wait leaves the younger stages in
+    // flight; the barrier behind it says that everybody's loads of stage s have landed AND that every wave is done reading the buffer of
+    // step s-1, which this step's loads overwrite.  (nsteps >= NST-1: host)
+#pragma unroll
+    for (int j = 0; j < NST - 1; ++j) {
+      addresses();
+#pragma unroll
+      for (int i = 0; i < LPS; ++i) piece(i, j);
+    }
+    int buf = 0;
+    const int steady = p.nsteps - (NST - 1);
+    for (int s = 0; s < steady; ++s) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      int nb = buf + NST - 1; nb = nb >= NST ? nb - NST : nb;
+      step(buf, nb, true);
+      buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+#pragma unroll
+    for (int r = NST - 2; r >= 0; --r) {           // drain: no more issues, r stages stay in flight
+      if (r == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+      else if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      __builtin_amdgcn_s_barrier();
+      step(buf, 0, false);
+      buf = buf + 1 == NST ? 0 : buf + 1;
+    }
+    __builtin_amdgcn_s_barrier();                  // (the next tile's prologue overwrites buffers the slowest wave may still be reading)
+
+    // ---- epilogue: lane = pixel l15 of fragment q, channels 32*h + 8*lq .. +7 of the wave's channel range (h = fragment pair) ----
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int m = m0 + wp * PW + q * 16 + l15;
+      const bool mvalid = m < p.M;
+      const int mm = mvalid ? m : 0;
+      const int n = mm / p.HWo; const int rem = mm - n * p.HWo;
+      const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+      const unsigned yoff = (unsigned)(n * p.y_sn + oy * p.y_sh + ox * p.y_sw);
+      const unsigned roff = (unsigned)(n * p.r_sn + oy * p.r_sh + ox * p.r_sw);
+#pragma unroll
+      for (int h = 0; h < CF / 2; ++h) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { v[r] = acc[2 * h][q][r]; v[4 + r] = acc[2 * h + 1][q][r]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { st_s[h][i] += v[i]; st_q[h][i] += v[i] * v[i]; }
+        const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
+        if (mvalid && c0 < p.Cout && !(DBG && (p.dbg & 8))) {
+          if (p.res) {
+            const uint4 g = ldg16(p.res + roff + c0 * 2);
+            add_h8(v, u32x4_t{g.x, g.y, g.z, g.w});
+          }
+          char* yp = p.y + yoff + c0 * 2;
+          if (p.accumulate) {
+            const uint4 g = ldg16(yp);
+            add_h8(v, u32x4_t{g.x, g.y, g.z, g.w});
+          }
+          const u32x4_t o = pack_h8(v);
+          stg16(yp, uint4{o.x, o.y, o.z, o.w});
+        }
+      }
+    }
+  }
+
+  if (p.stats) {
+    // the 16 pixel lanes of a lane group -> one value (shuffles), pixel waves -> LDS, one atomic per channel and workgroup
+    float* red = reinterpret_cast<float*>(smem);       // [WP][2][BN]  (every tile ended with a barrier; a workgroup without tiles reads nothing)
+#pragma unroll
+    for (int h = 0; h < CF / 2; ++h)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float s = row_sum16(st_s[h][i]), q = row_sum16(st_q[h][i]);
+        if (l15 == 15) {
+          const int cl = wc * CW + 32 * h + 8 * lq + i;
+          red[(wp * 2) * BN + cl] = s; red[(wp * 2 + 1) * BN + cl] = q;
+        }
+      }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += NT) {
+      const int which = t / BN, cl = t - which * BN;
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < WP; ++k) a += red[(k * 2 + which) * BN + cl];
+      const int c = tn * BN + cl;
+      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + which * p.Cout + c, a);
+    }
+  }
+}
+
+template <int BM, int BN, int WP, int WC, int NST, bool DBG = false>
+int launch(const MidK& k, int per_cu, int ntile_c, hipStream_t st) {
+  constexpr int NT = 64 * WP * WC;
+  constexpr int SMEM = NST * (BM + BN) * 128;
+  static_assert(SMEM >= WP * 2 * BN * 4, "statistics reduction area");
+  int per_xcd = (256 * per_cu / ntile_c + 7) / 8;
+  if (per_xcd < 1) per_xcd = 1;
+  if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
+  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG>;
+  MYOLO_ENSURE_DYN_SMEM(kern, SMEM);
+  hipLaunchKernelGGL(kern, dim3(per_xcd * 8, ntile_c), dim3(NT), SMEM, st, k);
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+}  // namespace mid
+
+static int g_mid_mode = -1;        // 0 off, 1 the layers conv_igemm would run, 2 every qualifying layer (ahead of halo / stream)
+static int g_mid_var = 0;          // 0 auto, 1: 128x128 (8 waves), 2: 128x64 (4 waves), 3: 64x128 (4 waves)
+static int g_mid_dbg = 0;
+static int g_mid_min_tiles = 192;  // 128x128 tiles below this: 64-pixel tiles (twice the workgroups)
+int myolo_conv_mid_set(const char* name, int value) {
+  if (!strcmp(name, "mid_mode")) { g_mid_mode = value; return 0; }
+  if (!strcmp(name, "mid_var")) { g_mid_var = value; return 0; }
+  if (!strcmp(name, "mid_dbg")) { g_mid_dbg = value; return 0; }
+  if (!strcmp(name, "mid_min_tiles")) { g_mid_min_tiles = value; return 0; }
+  return MYOLO_EINVAL;
+}
+int myolo_conv_mid_mode() {
+  if (g_mid_mode < 0) g_mid_mode = getenv("MYOLO_CONV_MID") ? atoi(getenv("MYOLO_CONV_MID")) : 2;
+  return g_mid_mode;
+}
+
+// -1: the layer does not qualify (caller goes on to the next kernel family), else 0 / hipError_t.  The caller runs the BatchNorm-backward
+// reduce pass (myolo_conv_desc.bnb) itself: this kernel does not fold it.
+int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream) {
+  using namespace mid;
+  {   // bisecting aid: MYOLO_MID_SKIP bits exclude call classes (1 statistics, 2 no statistics, 4 accumulate, 8 residual, 16 k x k, 32 1 x 1,
+      // 64 strided output view, 128 channel-slice input, 256 bnb)
+    static const int skip = getenv("MYOLO_MID_SKIP") ? atoi(getenv("MYOLO_MID_SKIP")) : 0;
+    if (skip) {
+      if ((skip & 1) && d->stats) return -1;
+      if ((skip & 2) && !d->stats) return -1;
+      if ((skip & 4) && d->accumulate) return -1;
+      if ((skip & 8) && d->res.ptr) return -1;
+      if ((skip & 16) && d->ntaps > 1) return -1;
+      if ((skip & 32) && d->ntaps == 1) return -1;
+      if ((skip & 64) && d->y.sw != d->y.c) return -1;
+      if ((skip & 128) && d->x.sw != d->x.c) return -1;
+      if ((skip & 256) && d->bnb && d->nbnb > 0) return -1;
+    }
+  }
+  if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->scale || d->shift || d->act != MYOLO_ACT_NONE || d->up_shift != 0) return -1;
+  if (d->cin_pad % 64 || d->x.c != d->cin_pad || d->cout_pad % 64 || d->y.c % 8 || d->ntaps > 25) return -1;
+  if (d->ntaps * (d->cin_pad / 64) < 2) return -1;                  // (the ring's prologue issues two K steps)
+  if (d->res.ptr && (d->res.c < d->y.c)) return -1;
+  const int64_t M = (int64_t)d->y.n * d->y.h * d->y.w;
+  if (M < 1024 || M > (1 << 24)) return -1;
+  auto extent = [](const myolo_tensor& t) { return ((int64_t)t.n * t.sn + (int64_t)t.h * t.sh + (int64_t)t.w * t.sw + t.c) * 2; };
+  if (extent(d->x) >= (1ll << 31) || extent(d->y) >= (1ll << 31) || (d->res.ptr && extent(d->res) >= (1ll << 31))) return -1;
+  if ((int64_t)d->cout_pad * d->wtaps * d->cin_pad * 2 >= (1ll << 31)) return -1;
+  MidK k;
+  k.x = (const char*)d->x.ptr; k.w = (const char*)d->w; k.y = (char*)d->y.ptr; k.res = (const char*)d->res.ptr; k.stats = d->stats;
+  k.x_sn = (int)d->x.sn * 2; k.x_sh = (int)d->x.sh * 2; k.x_sw = (int)d->x.sw * 2;
+  k.y_sn = (int)d->y.sn * 2; k.y_sh = (int)d->y.sh * 2; k.y_sw = (int)d->y.sw * 2;
+  k.r_sn = (int)d->res.sn * 2; k.r_sh = (int)d->res.sh * 2; k.r_sw = (int)d->res.sw * 2;
+  k.Hi = d->x.h; k.Wi = d->x.w; k.Wo = d->y.w; k.HWo = d->y.h * d->y.w; k.M = (int)M; k.Cout = d->y.c;
+  k.stride = d->stride; k.ntaps = d->ntaps; k.kchunks = d->cin_pad / 64; k.nsteps = k.ntaps * k.kchunks;
+  k.wrow_bytes = d->wtaps * d->cin_pad * 2;
+  k.accumulate = d->accumulate; k.dbg = g_mid_dbg;
+  for (int t = 0; t < MYOLO_MAX_TAPS; ++t) {
+    const bool in = t < d->ntaps;
+    k.tap_dy[t] = in ? d->tap_dy[t] : 0; k.tap_dx[t] = in ? d->tap_dx[t] : 0;
+    k.tap_xoff[t] = in ? d->tap_dy[t] * k.x_sh + d->tap_dx[t] * k.x_sw : 0;
+    k.tap_woff[t] = in ? d->tap_w[t] * d->cin_pad * 2 : 0;
+  }
+  const int bn = d->cout_pad % 128 == 0 ? 128 : 64;
+  const int ntile_c = d->cout_pad / bn;
+  int var = g_mid_var;
+  if (var == 0) var = bn == 64 ? 2 : (((M + 127) / 128) * ntile_c < g_mid_min_tiles ? 3 : 1);
+  if (bn == 64) var = 2;
+  const int bm = var == 3 ? 64 : (var == 4 ? 256 : 128);
+  k.ntile_p = (int)((M + bm - 1) / bm);
+  k.tiles_per_xcd = (k.ntile_p + 7) / 8;
+  hipStream_t st = (hipStream_t)stream;
+  if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 3, true>(k, 1, ntile_c, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
+  if (var == 1) return launch<128, 128, 4, 2, 3>(k, 1, ntile_c, st);
+  if (var == 4) return launch<256, 128, 4, 2, 3>(k, 1, ntile_c, st);      // 64 x 64 wave tiles: 2/3 of the LDS and L2 bytes per MFMA
+  if (var == 5) return launch<128, 128, 4, 2, 4>(k, 1, ntile_c, st);      // four stages
+  if (var == 2) return launch<128, 64, 2, 2, 3>(k, 2, d->cout_pad / 64, st);
+  return launch<64, 128, 1, 4, 3>(k, 2, ntile_c, st);
+}

@@ -242,6 +242,11 @@ int myolo_conv_igemm_set(const char* name, int value);   // conv_igemm.hip: "ige
 // conv_small.hip: split-K kernel for small maps (eval epilogues); -1 = layer does not qualify
 int myolo_conv_small_try(const myolo_conv_desc* d, void* stream);
 int myolo_conv_small_set(const char* name, int value);
+// conv_mid.hip: LDS-DMA staged 128-byte K steps, 8 waves per tile, for the training convolutions of the mid-size / small maps;
+// -1 = layer does not qualify.  myolo_conv_mid_mode(): 0 off, 1 instead of conv_igemm, 2 ahead of the halo / streaming kernels too
+int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_mid_set(const char* name, int value);
+int myolo_conv_mid_mode();
 // conv_wgrad_tile.hip: weight gradient over LDS-staged spatial tiles; -1 = layer does not qualify
 int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, int* out_cop, int* out_cip, int* used_ws);
 int myolo_wgrad_tile_set(const char* name, int value);

@@ -76,6 +76,44 @@ if os.environ.get('PROBE') == 'one':
     shp = tuple(int(v) for v in os.environ['PROBE_SHAPE'].split(','))
     print(shp, f'{run(*shp):.1f} us with stats, {run(*shp, stats_on=False):.1f} without', flush=True)
     sys.exit(0)
+if os.environ.get('PROBE') == 'mid':
+    # conv_mid (LDS-DMA ring, 8 waves) against the kernels it replaces, forward (statistics) and dgrad-shaped (no statistics) calls
+    P = [(128, 128, 3, 1, 1, 32, 64), (128, 128, 1, 1, 1, 32, 64), (256, 256, 1, 1, 1, 32, 64), (256, 128, 1, 1, 1, 32, 64), (512, 256, 1, 1, 1, 32, 64),
+         (512, 512, 1, 1, 1, 16, 32), (256, 256, 1, 1, 1, 16, 32), (256, 256, 3, 1, 1, 16, 32), (1024, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 16, 32),
+         (256, 128, 3, 1, 1, 64, 128), (128, 256, 3, 1, 1, 64, 128), (128, 256, 3, 2, 1, 64, 128), (256, 512, 3, 2, 1, 32, 64),
+         (64, 64, 3, 1, 1, 64, 128), (128, 128, 1, 1, 1, 64, 128), (64, 64, 1, 1, 1, 64, 128), (256, 128, 1, 1, 1, 64, 128), (64, 128, 3, 2, 1, 128, 256),
+         (64, 64, 1, 1, 1, 128, 256)]
+    V = [('old', {'mid_mode': 0}), ('mid', {'mid_mode': 2}), ('v2', {'mid_mode': 2, 'mid_var': 2}), ('v3', {'mid_mode': 2, 'mid_var': 3})]
+    for shp in P:
+        cin, cout, k, s, d, H, W = shp
+        M = B * ((H + s - 1) // s) * ((W + s - 1) // s)
+        byt = B * H * W * cin * 2 + M * cout * 2 + cout * cin * k * k * 2
+        fl = 2.0 * M * cout * cin * k * k
+        ideal = max(byt / 8e12, fl / 2.5e15) * 1e6
+        row = []
+        for name, opts in V:
+            for kk, vv in {'mid_mode': 1, 'mid_var': 0, **opts}.items():
+                lib.myolo_set_option(kk.encode(), vv)
+            row.append(f'{name} {run(*shp):.1f}/{run(*shp, stats_on=False):.1f}')
+        for kk, vv in {'mid_mode': 1, 'mid_var': 0}.items():
+            lib.myolo_set_option(kk.encode(), vv)
+        print(f'{str(shp):34s} roofline {ideal:5.1f} us | ' + ' | '.join(row), '(us with stats / without)', flush=True)
+    sys.exit(0)
+if os.environ.get('PROBE') == 'mid_dbg':
+    # where conv_mid's time goes: dbg bits 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores; tile variants
+    P = [(128, 128, 3, 1, 1, 32, 64), (256, 128, 3, 1, 1, 64, 128), (256, 256, 1, 1, 1, 32, 64), (512, 512, 1, 1, 1, 16, 32), (128, 128, 1, 1, 1, 32, 64)]
+    V = [('v1', 1, 0), ('noload', 1, 1), ('noread', 1, 2), ('nomfma', 1, 4), ('nostore', 1, 8), ('load only', 1, 6), ('mfma only', 1, 3),
+         ('skeleton', 1, 15), ('v4 256x128', 4, 0), ('v4 noload', 4, 1), ('v4 nomfma', 4, 4), ('v5 4-stage', 5, 0), ('v3 64x128', 3, 0)]
+    for shp in P:
+        row = []
+        for name, var, dbg in V:
+            for kk, vv in {'mid_mode': 2, 'mid_var': var, 'mid_dbg': dbg}.items():
+                lib.myolo_set_option(kk.encode(), vv)
+            row.append(f'{name} {run(*shp):.1f}/{run(*shp, stats_on=False):.1f}')
+        for kk, vv in {'mid_mode': 1, 'mid_var': 0, 'mid_dbg': 0}.items():
+            lib.myolo_set_option(kk.encode(), vv)
+        print(f'{str(shp):30s} ' + ' | '.join(row), flush=True)
+    sys.exit(0)
 if os.environ.get('PROBE') == 'igemm':
     # LDS-tiled kernel on the mid-size layers: tile shape / grid experiments
     for shp in [(256, 256, 1, 1, 1, 32, 64), (128, 128, 1, 1, 1, 32, 64), (256, 128, 1, 1, 1, 32, 64), (512, 512, 1, 1, 1, 16, 32), (512, 256, 1, 1, 1, 16, 32),

@@ -1,0 +1,104 @@
+"""-m gpu: conv_mid.hip (LDS-DMA staged 128-byte K steps, 8 waves per tile) through the raw C ABI (`myolo_conv`, myolo.h) against
+torch's fp32 convolution on the CPU over the SAME fp16-rounded inputs and weights: forward conv with BatchNorm statistics, dgrad-shaped
+calls (accumulate, residual, strided parity output view), every tile variant, ragged pixel counts, 25 taps, stride 2, dilation.
+Tolerance 2e-3 relative L2 on the fp16-rounded output (fp32 accumulation: the only error is the output rounding, ~3e-4)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import check
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _tdesc(L, t, c=None):
+    n, h, w, cc = t.shape
+    sn, sh, sw, _ = t.stride()
+    return L.Tensor(t.data_ptr(), n, h, w, cc if c is None else c, sn, sh, sw, L.F16, 0)
+
+
+def _run(cin, cout, k, s, d, B, H, W, var, stats=True, accumulate=False, res=False, mode=2, seed=0):
+    from multiyolov5_amd import _lib as L, engine as E
+    lib = L.lib()
+    g = torch.Generator().manual_seed(seed)
+    Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
+    x = (torch.randn(B, H, W, cin, generator=g) * 0.5).half()
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)).half()
+    y0 = (torch.randn(B, Ho, Wo, cout, generator=g) * 0.3).half()
+    r0 = (torch.randn(B, Ho, Wo, cout, generator=g) * 0.3).half()
+    pad = d * (k // 2)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, s, pad, d).permute(0, 2, 3, 1).contiguous()
+    raw = ref.clone()
+    if res:
+        ref = ref + r0.float()
+    if accumulate:
+        ref = ref + y0.float()
+    xd, yd, rd = x.to(DEV), y0.to(DEV).clone(), r0.to(DEV)
+    cin_pad, cout_pad = E.rup(cin, 32), E.rup(cout, 32)
+    wp = torch.zeros(cout_pad, k * k, cin_pad, device=DEV, dtype=torch.float16)
+    L.check(lib.myolo_pack_weight(L.ptr(w.float().to(DEV)), L.F32, cout, cin, k, k, L.ptr(wp), L.F16, cout_pad, cin_pad, 0, None, L.stream_ptr()))
+    st = torch.zeros(L.STAT_COPIES * 2 * cout, device=DEV)
+    dd = L.ConvDesc()
+    dd.x, dd.y, dd.w = _tdesc(L, xd), _tdesc(L, yd), wp.data_ptr()
+    dd.cin_pad, dd.cout_pad, dd.wtaps, dd.ntaps, dd.stride, dd.up_shift = cin_pad, cout_pad, k * k, k * k, s, 0
+    E.fill_taps(dd, *E.taps_fwd(k, d, pad))
+    dd.res = _tdesc(L, rd) if res else E.null_tensor()
+    dd.act, dd.stats, dd.accumulate = L.ACT_NONE, (st.data_ptr() if stats else None), int(accumulate)
+    lib.myolo_set_option(b'mid_mode', mode)
+    lib.myolo_set_option(b'mid_var', var)
+    try:
+        L.check(lib.myolo_conv(C.byref(dd), L.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        lib.myolo_set_option(b'mid_mode', 2)
+        lib.myolo_set_option(b'mid_var', 0)
+    bad = []
+    tag = f'mid/{cin}->{cout} k{k}s{s}d{d} {B}x{H}x{W} var{var}'
+    check(tag + '/y', yd, ref, 2e-3, collect=bad)
+    if stats:
+        ss = st.view(L.STAT_COPIES, 2, cout).sum(0).cpu()
+        flat = raw.reshape(-1, cout)
+        check(tag + '/sum', ss[0], flat.sum(0), 1e-3, collect=bad)
+        check(tag + '/sumsq', ss[1], (flat * flat).sum(0), 1e-4, collect=bad)
+    assert not bad, '\n'.join(bad)
+
+
+SHAPES = [
+    # cin, cout, k, s, d, B, H, W
+    (128, 128, 3, 1, 1, 2, 32, 64),          # 6.m.0.cv2
+    (128, 128, 1, 1, 1, 2, 32, 64),          # two K steps: the ring's prologue + drain only
+    (256, 256, 1, 1, 1, 2, 32, 64),          # two N tiles
+    (256, 128, 3, 1, 1, 1, 64, 128),         # PSP head 3x3 (K = 2304)
+    (256, 256, 3, 1, 1, 2, 16, 32),          # 9.m.0.cv2: M = 1024
+    (128, 256, 3, 2, 1, 2, 64, 128),         # 5.conv (stride 2)
+    (64, 64, 3, 1, 2, 2, 32, 64),            # dilation 2, 64-wide tiles
+    (64, 64, 5, 1, 1, 1, 32, 48),            # RFB1's 5x5: 25 taps, ragged pixel count (1536 = 12 tiles)
+    (128, 192, 1, 1, 1, 1, 31, 37),          # ragged: M = 1147, cout 192 (64-wide tiles)
+    (512, 512, 1, 1, 1, 2, 16, 32),          # 8 K steps
+]
+
+
+@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('shape', SHAPES, ids=[f'{s[0]}-{s[1]}k{s[2]}s{s[3]}d{s[4]}_{s[5]}x{s[6]}x{s[7]}' for s in SHAPES])
+def test_conv_mid_forward_with_statistics(shape, var):
+    _run(*shape, var=var)
+
+
+@pytest.mark.parametrize('var', [1, 2, 3, 4, 5])
+def test_conv_mid_dgrad_epilogues(var):
+    """the dgrad call shapes: no statistics, accumulate into y, residual add, both"""
+    _run(128, 128, 3, 1, 1, 2, 32, 64, var, stats=False, accumulate=True)
+    _run(256, 128, 1, 1, 1, 2, 32, 64, var, stats=False, res=True)
+    _run(128, 256, 1, 1, 1, 1, 33, 64, var, stats=False, accumulate=True, res=True)
+
+
+def test_conv_mid_takes_the_layers_and_is_deterministic():
+    """mode 1 (default): a layer conv_igemm would run goes to conv_mid -- same call twice gives identical bits (no atomics on y), and
+    mode 0 (conv_igemm) agrees within fp16 rounding"""
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    _run(128, 128, 3, 1, 1, 2, 32, 64, 0, mode=1)
+    _run(128, 128, 3, 1, 1, 2, 32, 64, 0, mode=0)
