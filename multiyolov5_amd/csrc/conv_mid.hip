@@ -38,6 +38,7 @@ struct MidK {
   int stride, ntaps, kchunks, nsteps;
   int wrow_bytes;                  // bytes between two output-channel rows of the packed weights (wtaps * cin_pad * 2)
   int ntile_p, tiles_per_xcd, accumulate;
+  BnbArgs bnb;                     // BNS: BatchNorm-backward statistics of the layer(s) whose output gradient this launch completes
   int dbg;                         // profiling only: 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores
   int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
   int tap_xoff[MYOLO_MAX_TAPS];    // (dy * x_sh + dx * x_sw) bytes
@@ -53,7 +54,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // BM x BN output tile (pixels x channels), WP x WC waves (each (BM/WP) pixels x (BN/WC) channels), NST LDS stages
-template <int BM, int BN, int WP, int WC, int NST, bool DBG>
+// BNS: the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb; conv_igemm.hip has the same fold):
+//   dsum0 += dz, dsum1 += dz * xhat with dz = gout * act'(bn(y)) on the final, storage-rounded values, per channel
+template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false>
 __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   constexpr int NT = 64 * WP * WC;
   constexpr int PW = BM / WP, CW = BN / WC;       // wave tile
@@ -93,6 +96,25 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   for (int q = 0; q < CF / 2; ++q)
 #pragma unroll
     for (int i = 0; i < 8; ++i) { st_s[q][i] = 0.f; st_q[q][i] = 0.f; }
+
+  int sgi = -1;                                     // BNS: the segment this N tile belongs to (host: segments are BN-aligned)
+  float* sBN = reinterpret_cast<float*>(smem + NST * STAGE);      // [4][BN] mean, invstd, gamma*invstd, beta - mean*gamma*invstd
+  if (BNS) {
+    for (int i = 0; i < p.bnb.n; ++i)
+      if (tn * BN >= p.bnb.seg[i].c0 && tn * BN < p.bnb.seg[i].c1) sgi = i;
+    if (sgi >= 0) {
+      const BnbSeg& sg = p.bnb.seg[sgi];
+      const int Cs = sg.c1 - sg.c0;
+      for (int c = tid; c < BN; c += NT) {
+        const int ci = tn * BN + c - sg.c0;
+        const bool in = ci < Cs;
+        const float mean = in ? sg.saved[ci] : 0.f, istd = in ? sg.saved[Cs + ci] : 0.f;
+        const float sc = in ? sg.gamma[ci] * istd : 0.f;
+        sBN[c] = mean; sBN[BN + c] = istd; sBN[2 * BN + c] = sc; sBN[3 * BN + c] = in ? sg.beta[ci] - mean * sc : 0.f;
+      }
+    }
+    __syncthreads();
+  }
 
   for (int tslot = bslot; tslot < p.tiles_per_xcd; tslot += bstride) {
     const int tp = xcd * p.tiles_per_xcd + tslot;
@@ -241,13 +263,27 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
       const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
       const unsigned yoff = (unsigned)(n * p.y_sn + oy * p.y_sh + ox * p.y_sw);
       const unsigned roff = (unsigned)(n * p.r_sn + oy * p.r_sh + ox * p.r_sw);
+      uint4 yv[CF / 2];                            // BNS: the layer's raw conv output at this pixel (loads issued ahead of the stores)
+      if (BNS) {
+        if (sgi >= 0) {
+          const BnbSeg& sg = p.bnb.seg[sgi];
+          const unsigned boff = (unsigned)(n * (int)sg.y_sn + oy * (int)sg.y_sh + ox * (int)sg.y_sw) * 2u;
+#pragma unroll
+          for (int h = 0; h < CF / 2; ++h) {
+            const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
+            yv[h] = ldg16((mvalid && c0 < sg.c1) ? sg.y + boff + (c0 - sg.c0) * 2 : zero_page());
+          }
+        }
+      }
 #pragma unroll
       for (int h = 0; h < CF / 2; ++h) {
         float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) { v[r] = acc[2 * h][q][r]; v[4 + r] = acc[2 * h + 1][q][r]; }
+        if (!BNS) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { st_s[h][i] += v[i]; st_q[h][i] += v[i] * v[i]; }
+          for (int i = 0; i < 8; ++i) { st_s[h][i] += v[i]; st_q[h][i] += v[i] * v[i]; }
+        }
         const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
         if (mvalid && c0 < p.Cout && !(DBG && (p.dbg & 8))) {
           if (p.res) {
@@ -261,13 +297,28 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
           }
           const u32x4_t o = pack_h8(v);
           stg16(yp, uint4{o.x, o.y, o.z, o.w});
+          if (BNS) {
+            if (sgi >= 0 && c0 < p.bnb.seg[sgi].c1) {
+              float gq[8], yf[8];
+              Vec<half_t>::unpack(uint4{o.x, o.y, o.z, o.w}, gq);     // gout as stored (what the apply pass reads back)
+              Vec<half_t>::unpack(yv[h], yf);
+              const int cl = wc * CW + 32 * h + 8 * lq;
+              const int act = p.bnb.seg[sgi].act;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float dz = gq[i] * act_grad_f(fmaf(yf[i], sBN[2 * BN + cl + i], sBN[3 * BN + cl + i]), act);
+                st_s[h][i] += dz;
+                st_q[h][i] += dz * (yf[i] - sBN[cl + i]) * sBN[BN + cl + i];
+              }
+            }
+          }
         }
       }
     }
   }
 
-  if (p.stats) {
-    // the 16 pixel lanes of a lane group -> one value (shuffles), pixel waves -> LDS, one atomic per channel and workgroup
+  if (BNS ? sgi >= 0 : p.stats != nullptr) {
+    // the 16 pixel lanes of a lane group -> one value (DPP row sums), pixel waves -> LDS, one atomic per channel and workgroup
     float* red = reinterpret_cast<float*>(smem);       // [WP][2][BN]  (every tile ended with a barrier; a workgroup without tiles reads nothing)
 #pragma unroll
     for (int h = 0; h < CF / 2; ++h)
@@ -285,21 +336,27 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
       float a = 0.f;
 #pragma unroll
       for (int k = 0; k < WP; ++k) a += red[(k * 2 + which) * BN + cl];
-      const int c = tn * BN + cl;
-      if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + which * p.Cout + c, a);
+      if (BNS) {
+        const BnbSeg& sg = p.bnb.seg[sgi];
+        const int Cs = sg.c1 - sg.c0, ci = tn * BN + cl - sg.c0;
+        if (ci < Cs) atomicAdd(sg.dsum + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * Cs + which * Cs + ci, a);
+      } else {
+        const int c = tn * BN + cl;
+        if (c < p.Cout) atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + which * p.Cout + c, a);
+      }
     }
   }
 }
 
-template <int BM, int BN, int WP, int WC, int NST, bool DBG = false>
+template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false>
 int launch(const MidK& k, int per_cu, int ntile_c, hipStream_t st) {
   constexpr int NT = 64 * WP * WC;
-  constexpr int SMEM = NST * (BM + BN) * 128;
+  constexpr int SMEM = NST * (BM + BN) * 128 + (BNS ? 4 * BN * 4 : 0);
   static_assert(SMEM >= WP * 2 * BN * 4, "statistics reduction area");
   int per_xcd = (256 * per_cu / ntile_c + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
-  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG>;
+  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS>;
   MYOLO_ENSURE_DYN_SMEM(kern, SMEM);
   hipLaunchKernelGGL(kern, dim3(per_xcd * 8, ntile_c), dim3(NT), SMEM, st, k);
   MYOLO_CHECK_LAUNCH();
@@ -324,10 +381,11 @@ int myolo_conv_mid_mode() {
   return g_mid_mode;
 }
 
-// -1: the layer does not qualify (caller goes on to the next kernel family), else 0 / hipError_t.  The caller runs the BatchNorm-backward
-// reduce pass (myolo_conv_desc.bnb) itself: this kernel does not fold it.
-int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream) {
+// -1: the layer does not qualify (caller goes on to the next kernel family), else 0 / hipError_t.  *bnb_done = 1: the BatchNorm-backward
+// sums (myolo_conv_desc.bnb) were produced in the epilogue; 0: the caller runs the reduce pass itself.
+int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   using namespace mid;
+  *bnb_done = 0;
   {   // bisecting aid: MYOLO_MID_SKIP bits exclude call classes (1 statistics, 2 no statistics, 4 accumulate, 8 residual, 16 k x k, 32 1 x 1,
       // 64 strided output view, 128 channel-slice input, 256 bnb)
     static const int skip = getenv("MYOLO_MID_SKIP") ? atoi(getenv("MYOLO_MID_SKIP")) : 0;
@@ -376,10 +434,16 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream) {
   k.ntile_p = (int)((M + bm - 1) / bm);
   k.tiles_per_xcd = (k.ntile_p + 7) / 8;
   hipStream_t st = (hipStream_t)stream;
-  if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 3, true>(k, 1, ntile_c, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
-  if (var == 1) return launch<128, 128, 4, 2, 3>(k, 1, ntile_c, st);
-  if (var == 4) return launch<256, 128, 4, 2, 3>(k, 1, ntile_c, st);      // 64 x 64 wave tiles: 2/3 of the LDS and L2 bytes per MFMA
-  if (var == 5) return launch<128, 128, 4, 2, 4>(k, 1, ntile_c, st);      // four stages
-  if (var == 2) return launch<128, 64, 2, 2, 3>(k, 2, d->cout_pad / 64, st);
-  return launch<64, 128, 1, 4, 3>(k, 2, ntile_c, st);
+  const int bn_eff = var == 2 ? 64 : 128, ntc = d->cout_pad / bn_eff;
+  // the BatchNorm-backward sums of the layer(s) below ride in the epilogue when every segment is a whole number of N tiles
+  static const int no_fold = getenv("MYOLO_MID_NO_BNB") != nullptr;
+  const bool fold = d->bnb && d->nbnb > 0 && d->nbnb <= MYOLO_MAX_BNB && !d->stats && !no_fold && !k.dbg && bnb_aligned(d, bn_eff);
+  k.bnb.n = 0;
+  if (fold) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
+  if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 3, true>(k, 1, ntc, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
+  if (var == 1) return fold ? launch<128, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 3>(k, 1, ntc, st);
+  if (var == 4) return fold ? launch<256, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<256, 128, 4, 2, 3>(k, 1, ntc, st);   // 64 x 64 wave tiles
+  if (var == 5) return fold ? launch<128, 128, 4, 2, 4, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 4>(k, 1, ntc, st);   // four stages
+  if (var == 2) return fold ? launch<128, 64, 2, 2, 3, false, true>(k, 2, ntc, st) : launch<128, 64, 2, 2, 3>(k, 2, ntc, st);
+  return fold ? launch<64, 128, 1, 4, 3, false, true>(k, 2, ntc, st) : launch<64, 128, 1, 4, 3>(k, 2, ntc, st);
 }

@@ -244,7 +244,7 @@ int myolo_conv_small_try(const myolo_conv_desc* d, void* stream);
 int myolo_conv_small_set(const char* name, int value);
 // conv_mid.hip: LDS-DMA staged 128-byte K steps, 8 waves per tile, for the training convolutions of the mid-size / small maps;
 // -1 = layer does not qualify.  myolo_conv_mid_mode(): 0 off, 1 instead of conv_igemm, 2 ahead of the halo / streaming kernels too
-int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 int myolo_conv_mid_set(const char* name, int value);
 int myolo_conv_mid_mode();
 // conv_wgrad_tile.hip: weight gradient over LDS-staged spatial tiles; -1 = layer does not qualify

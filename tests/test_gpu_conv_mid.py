@@ -102,3 +102,62 @@ def test_conv_mid_takes_the_layers_and_is_deterministic():
     lib = L.lib()
     _run(128, 128, 3, 1, 1, 2, 32, 64, 0, mode=1)
     _run(128, 128, 3, 1, 1, 2, 32, 64, 0, mode=0)
+
+
+@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('case', ['1x1', '3x3_acc', 'two_segments', 'narrow_segments', 'slice_end'])
+def test_conv_mid_bn_backward_sums_in_the_epilogue(case, var):
+    """myolo_conv_desc.bnb through conv_mid: the sums the conv launch leaves in `dsum` equal what myolo_bn_act_bwd_reduce computes from the
+    gradient that launch stored.  'two_segments': 128 + 128 channels (one N tile each); 'narrow_segments': 64 + 192 (not tile aligned for
+    the 128-wide tiles: the library's own reduce launch); 'slice_end': a segment that ends at y.c = 192 inside the last tile"""
+    from multiyolov5_amd import _lib as L, engine as E
+    lib = L.lib()
+    torch.manual_seed(1)
+    n, H, W, cin = 2, 24, 40, 128
+    k = 3 if case == '3x3_acc' else 1
+    cout = {'1x1': 128, '3x3_acc': 128, 'two_segments': 256, 'narrow_segments': 256, 'slice_end': 192}[case]
+    segs = {'1x1': [(0, 128)], '3x3_acc': [(0, 128)], 'two_segments': [(0, 128), (128, 256)], 'narrow_segments': [(0, 64), (64, 256)],
+            'slice_end': [(0, 64), (64, 192)]}[case]
+    acc = case == '3x3_acc'
+
+    def td(t, c0=0, c=None):
+        nn, h, w, cc = t.shape
+        return L.Tensor(t.data_ptr() + c0 * 2, nn, h, w, cc if c is None else c, h * w * cc, w * cc, cc, L.F16, 0)
+    x = (torch.randn(n, H, W, cin, device=DEV) * 0.3).half()
+    wt = torch.randn(cout, cin, k, k, device=DEV) * (1.0 / (cin * k * k) ** 0.5)
+    cin_pad, cout_pad = E.rup(cin, 32), E.rup(cout, 32)
+    wp = torch.zeros(cout_pad, k * k, cin_pad, device=DEV, dtype=torch.float16)
+    L.check(lib.myolo_pack_weight(L.ptr(wt), L.F32, cout, cin, k, k, L.ptr(wp), L.F16, cout_pad, cin_pad, 0, None, L.stream_ptr()))
+    gx = (torch.randn(n, H, W, cout, device=DEV) * 0.1).half() if acc else torch.zeros(n, H, W, cout, device=DEV, dtype=torch.float16)
+    yraw = [torch.randn(n, H, W, c1 - c0, device=DEV).half() for c0, c1 in segs]
+    saved = [torch.cat([torch.randn(c1 - c0, device=DEV) * 0.2, torch.rand(c1 - c0, device=DEV) + 0.5]) for c0, c1 in segs]
+    gam = [torch.rand(c1 - c0, device=DEV) + 0.5 for c0, c1 in segs]
+    bet = [torch.randn(c1 - c0, device=DEV) * 0.1 for c0, c1 in segs]
+    dsum = [torch.zeros(L.STAT_COPIES * 2 * (c1 - c0), device=DEV) for c0, c1 in segs]
+    bnb = (L.BnBwdSeg * len(segs))()
+    for i, (c0, c1) in enumerate(segs):
+        bnb[i].c0, bnb[i].c1, bnb[i].y = c0, c1, td(yraw[i])
+        bnb[i].saved, bnb[i].gamma, bnb[i].beta, bnb[i].dsum, bnb[i].act = saved[i].data_ptr(), gam[i].data_ptr(), bet[i].data_ptr(), \
+            dsum[i].data_ptr(), L.ACT_SILU
+    d = L.ConvDesc()
+    d.x, d.y, d.w = td(x), td(gx), wp.data_ptr()
+    d.cin_pad, d.cout_pad, d.wtaps, d.ntaps, d.stride, d.up_shift = cin_pad, cout_pad, k * k, k * k, 1, 0
+    E.fill_taps(d, *E.taps_fwd(k, 1, k // 2))
+    d.res, d.act, d.accumulate = E.null_tensor(), L.ACT_NONE, int(acc)
+    d.nbnb, d.bnb = len(segs), C.cast(bnb, C.POINTER(L.BnBwdSeg))
+    lib.myolo_set_option(b'mid_mode', 2)
+    lib.myolo_set_option(b'mid_var', var)
+    try:
+        L.check(lib.myolo_conv(C.byref(d), L.stream_ptr()), 'myolo_conv')
+        torch.cuda.synchronize()
+    finally:
+        lib.myolo_set_option(b'mid_var', 0)
+    for i, (c0, c1) in enumerate(segs):
+        ref = torch.zeros_like(dsum[i])
+        gd, yd = td(gx, c0, c1 - c0), td(yraw[i])
+        L.check(lib.myolo_bn_act_bwd_reduce(C.byref(gd), C.byref(yd), L.ptr(saved[i]), L.ptr(gam[i]), L.ptr(bet[i]), L.ACT_SILU, L.ptr(ref),
+                                            L.stream_ptr()))
+        got = dsum[i].view(L.STAT_COPIES, 2, c1 - c0).sum(0)
+        want = ref.view(L.STAT_COPIES, 2, c1 - c0).sum(0)
+        assert float(want.abs().max()) > 1e-3
+        check(f'mid_bnb/{case}/var{var}/seg{i}', got, want, 2e-4)
