@@ -30,6 +30,8 @@ class Ctx:
         self.dropout_p = dropout_p   # Base/BiSe heads (yolo.py:65,140); tests pin with 0.0
         self.record = record         # optional dict: name -> tensor (per-layer taps)
         self.dropout_fn = None       # tests: replay a given keep-mask instead of drawing one (dropout parity is statistical)
+        self.maxpool_fn = None       # tests: fn(x, k) replacing F.max_pool2d(x, k, 1, k // 2) -- replays the arg-max choices another run made
+                                     # at windows whose top-2 values are a rounding-noise tie (tests/gpu_util.pool_replay)
 
     def has(self, key):
         return key in self.sd
@@ -76,7 +78,8 @@ def c3(ctx, p, x, n, shortcut):  # common.py:127-139
 
 def spp(ctx, p, x, ks=(5, 9, 13)):  # common.py:163-174
     x = conv_block(ctx, p + '.cv1', x)
-    return conv_block(ctx, p + '.cv2', torch.cat([x] + [F.max_pool2d(x, k, 1, k // 2) for k in ks], 1))
+    pool = ctx.maxpool_fn if ctx.maxpool_fn is not None else (lambda t, k: F.max_pool2d(t, k, 1, k // 2))
+    return conv_block(ctx, p + '.cv2', torch.cat([x] + [pool(x, k) for k in ks], 1))
 
 
 def c3spp(ctx, p, x):  # common.py:142-152
@@ -255,10 +258,12 @@ def detect(ctx, p, xs, nc, stride):  # yolo.py:206-230
     return raw if ctx.training else (torch.cat(z, 1), raw)
 
 
-def forward(cfg, sd, x, training, dropout_p=0.1, record=None, dropout_fn=None):
-    """Model.forward_once (yolo.py:293-316): returns [det_out, seg_out].  dropout_fn: tests replay a given keep-mask (Ctx.dropout_fn)."""
+def forward(cfg, sd, x, training, dropout_p=0.1, record=None, dropout_fn=None, maxpool_fn=None):
+    """Model.forward_once (yolo.py:293-316): returns [det_out, seg_out].  dropout_fn: tests replay a given keep-mask (Ctx.dropout_fn);
+    maxpool_fn: tests replay given arg-max choices of the SPP pools (Ctx.maxpool_fn)."""
     ctx = Ctx(sd, training, dropout_p, record)
     ctx.dropout_fn = dropout_fn
+    ctx.maxpool_fn = maxpool_fn
     gd, gw, nc = cfg['depth_multiple'], cfg['width_multiple'], cfg['nc']
     ys = []
     for i, (f, n, m, args) in enumerate(cfg['backbone'] + cfg['head']):

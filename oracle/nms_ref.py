@@ -28,27 +28,34 @@ def greedy_nms(boxes, scores, thr):
 
 
 def non_max_suppression(pred, conf_thres=0.25, iou_thres=0.45, multi_label=False, max_wh=4096, max_det=300,
-                        max_nms=30000, classes=None, agnostic=False):
-    """pred: [B,A,5+nc] float32 (xywh, obj, cls).  Returns list of [n,6] (xyxy, conf, cls) float32."""
-    pred = np.asarray(pred, np.float32)
+                        max_nms=30000, classes=None, agnostic=False, half=False):
+    """pred: [B,A,5+nc] (xywh, obj, cls).  Returns list of [n,6] (xyxy, conf, cls) float32.
+    half=True: detect.py --half -- the reference runs general.py:421-509 on an fp16 prediction tensor: the threshold compares, cls*obj
+    (462) and xywh2xyxy (265-272) are fp16 arithmetic (every operation rounded to fp16, as torch's CPU half kernels and numpy's float16
+    do), `torch.cat((box, conf, j.float()))` (473) promotes the rows to float32 and everything behind it (class offsets, torchvision
+    nms) is float32.  Pinned by the goldens the reference wrote on pred.half() (tests/test_oracle_golden.py)."""
+    ft = np.float16 if half else np.float32
+    pred = np.asarray(pred, ft)
+    thr = ft(conf_thres)
     nc = pred.shape[2] - 5
     multi_label = multi_label and nc > 1
     out = []
     for x in pred:
-        x = x[x[:, 4] > conf_thres]                                   # general.py:430,446 (obj threshold)
+        x = x[x[:, 4] > thr]                                          # general.py:430,446 (obj threshold)
         if not len(x):
             out.append(np.zeros((0, 6), np.float32)); continue
         x = x.copy()
         x[:, 5:] *= x[:, 4:5]                                         # 462
-        box = np.stack((x[:, 0] - x[:, 2] / 2, x[:, 1] - x[:, 3] / 2,
-                        x[:, 0] + x[:, 2] / 2, x[:, 1] + x[:, 3] / 2), 1).astype(np.float32)   # 265-272
+        two = ft(2)
+        box = np.stack((x[:, 0] - x[:, 2] / two, x[:, 1] - x[:, 3] / two,
+                        x[:, 0] + x[:, 2] / two, x[:, 1] + x[:, 3] / two), 1).astype(ft)   # 265-272
         if multi_label:                                               # 468-470
-            i, j = np.nonzero(x[:, 5:] > conf_thres)
-            x = np.concatenate((box[i], x[i, j + 5, None], j[:, None].astype(np.float32)), 1)
+            i, j = np.nonzero(x[:, 5:] > thr)
+            x = np.concatenate((box[i].astype(np.float32), x[i, j + 5, None].astype(np.float32), j[:, None].astype(np.float32)), 1)
         else:                                                         # 472-473
             j = x[:, 5:].argmax(1)
             conf = x[np.arange(len(x)), 5 + j]
-            x = np.concatenate((box, conf[:, None], j[:, None].astype(np.float32)), 1)[conf > conf_thres]
+            x = np.concatenate((box.astype(np.float32), conf[:, None].astype(np.float32), j[:, None].astype(np.float32)), 1)[conf > thr]
         if classes is not None:                                       # 476-477 class filter
             x = x[np.isin(x[:, 5].astype(np.int64), np.asarray(classes, np.int64))]
         if not len(x):

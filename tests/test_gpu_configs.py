@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import loss_ref, model_ref, synth
-from tests.gpu_util import check
+from tests.gpu_util import check, pool_replay
 from tests.test_gpu_model import assert_argmax_exact_or_near_tie
 from tests.util import CFG, TAGS, load_cfg, synth_sd
 
@@ -45,16 +45,12 @@ def _oracle_params(sd):
 
 
 def _grad_tol(k, tag):
-    # parameters upstream of a max-pool (backbone up to SPP.cv1; the Base head's C3SPP.cv1) see ~1e5 pool windows at this resolution,
-    # a handful with top-2 values inside the rounding noise of two summation orders: the arg-max of those flips (measured ~2e-3 of the
-    # gradient energy, tests/test_gpu_model.py) -- everything else is held to 1e-3.  WHICH windows flip changes from run to run (the
-    # BatchNorm statistics are fp32 atomics: their last bits depend on the arrival order): 12 runs of config 1 gave 1.2e-3 .. 1.2e-2 on
-    # the worst of these parameters, hence 2.5e-2 here
-    upstream = any(k.startswith(f'model.{i}.') for i in range(8)) or k.startswith('model.8.cv1.')
-    if tag == 's_base':
-        upstream = upstream or any(k.startswith(f'model.{i}.') for i in range(8, 17)) or k.startswith('model.24.m.0.') or \
-            k.startswith('model.24.m.1.cv1.') or k.startswith('model.24.m.1.cv2.') or k.startswith('model.24.m.1.m.cv1.')
-    return 2.5e-2 if upstream else 1e-3
+    # round 4: every parameter is held to 1e-3.  Rounds 2-3 allowed 2.5e-2 for everything upstream of a max-pool
+    # (the whole backbone; for the Base head most of the head too): at this resolution a handful of the ~1e5 pool windows have top-2
+    # values inside the rounding noise of two summation orders and their arg-max flips.  The oracle now REPLAYS the product's own pool
+    # choices (tests/gpu_util.pool_replay: read from the index planes the backward uses, each proven a maximum of the oracle's window up
+    # to 1e-4 of max|x|), so a 2 % dgrad / wgrad error at these shapes can no longer hide behind that allowance.
+    return 1e-3
 
 
 def test_config1_s_base_full_resolution_joint_step_with_dropout_replay():
@@ -82,8 +78,11 @@ def test_config1_s_base_full_resolution_joint_step_with_dropout_replay():
     rate = float(keep.float().mean())
     assert abs(rate - (1 - P)) < 4 * (P * (1 - P) / keep.numel()) ** 0.5, rate
     params, sdt = _oracle_params(sd)
+    replay, rstat = pool_replay(m)
     rdet, rseg = model_ref.forward(load_cfg(tag), sdt, x, training=True, dropout_p=P,
-                                   dropout_fn=lambda t: t * keep.to(t.dtype) / (1.0 - P))
+                                   dropout_fn=lambda t: t * keep.to(t.dtype) / (1.0 - P), maxpool_fn=replay)
+    assert rstat['pools'] == 6 and rstat['windows'] > 0, rstat      # backbone SPP + the head's C3SPP
+    print('cfg1 max-pool replay:', rstat)
     rl, _ = loss_ref.compute_loss(rdet, targets, sd['model.25.anchors'], hyp)
     rs = loss_ref.seg_ce(rseg, mask)
     (rl * 0.6 + rs * B * 0.35).backward()
@@ -117,7 +116,10 @@ def test_config4_m_lab_full_resolution_forward_backward():
     segloss = SegmentationLosses()(seg, mask.to(DEV))
     (loss * 0.6 + segloss * B * 0.35).backward()
     params, sdt = _oracle_params(sd)
-    rdet, rseg = model_ref.forward(load_cfg(tag), sdt, x, training=True, dropout_p=0.0)
+    replay, rstat = pool_replay(m)
+    rdet, rseg = model_ref.forward(load_cfg(tag), sdt, x, training=True, dropout_p=0.0, maxpool_fn=replay)
+    assert rstat['pools'] == 3 and rstat['windows'] > 0, rstat
+    print('cfg4 max-pool replay:', rstat)
     rl, _ = loss_ref.compute_loss(rdet, targets, sd['model.25.anchors'], hyp)
     rs = loss_ref.seg_ce(rseg, mask)
     (rl * 0.6 + rs * B * 0.35).backward()
@@ -132,6 +134,45 @@ def test_config4_m_lab_full_resolution_forward_backward():
     for k, b in m.named_buffers():
         if 'running' in k:
             check(f'cfg4/{k}', b, sdt[k], 2e-4, collect=bad)
+    assert not bad, f'{len(bad)} off:\n' + '\n'.join(bad[:20])
+
+
+def test_config2_bench_batch_of_16_distinct_images_joint_step_fp32():
+    """BASELINE configs[1] at the bench's own batch: yolov5s + PSP, 16 DISTINCT 3x512x1024 images (test_bench_batch16_step_invariants
+    repeats two images eight times and compares the product with itself), fp32, train-mode forward + ComputeLoss + seg CE + backward
+    against the oracle: losses 1e-4, every parameter gradient 1e-3 (max-pool choices replayed), running statistics"""
+    from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
+    tag, HH, WW, B = 's_psp', 512, 1024, 16
+    m, sd = _model(tag)
+    m.train()
+    hyp = loss_ref.scaled_hyp(1024, 10, 3)
+    m.hyp, m.gr, m.nc = hyp, 1.0, 10
+    x = synth.synth_images(B, HH, WW, seed=5)
+    assert float((x[0] - x[1]).abs().max()) > 0.1 and float((x[3] - x[11]).abs().max()) > 0.1
+    targets = synth.synth_det_targets(B, 8, 10, seed=5)
+    mask = synth.synth_seg_targets(B, HH, WW, 19, seed=5)
+    det, seg = m(x.to(DEV))
+    loss, _ = ComputeLoss(m)(det, targets.to(DEV))
+    segloss = SegmentationLosses()(seg, mask.to(DEV))
+    (loss * 0.6 + segloss * B * 0.35).backward()
+    params, sdt = _oracle_params(sd)
+    replay, rstat = pool_replay(m)
+    rdet, rseg = model_ref.forward(load_cfg(tag), sdt, x, training=True, dropout_p=0.0, maxpool_fn=replay)
+    print('cfg2 bs16 max-pool replay:', rstat)
+    rl, _ = loss_ref.compute_loss(rdet, targets, sd['model.25.anchors'], hyp)
+    rs = loss_ref.seg_ce(rseg, mask)
+    (rl * 0.6 + rs * B * 0.35).backward()
+    bad = []
+    for i, d in enumerate(det):
+        check(f'cfg2b16/det{i}', d, rdet[i], 2e-4, collect=bad)
+    check('cfg2b16/seg_sub', seg[:, :, ::8, ::8], rseg[:, :, ::8, ::8], 2e-4, atol=1e-3, collect=bad)
+    check('cfg2b16/loss_det', loss, rl, 1e-4, collect=bad)
+    check('cfg2b16/loss_seg', segloss, rs, 1e-4, collect=bad)
+    for k, p in m.named_parameters():
+        check(f'cfg2b16/grad/{k}', p.grad, params[k].grad, 1e-3, collect=bad)
+    for k, b in m.named_buffers():
+        if 'running' in k:
+            check(f'cfg2b16/{k}', b, sdt[k], 2e-4, collect=bad)
     assert not bad, f'{len(bad)} off:\n' + '\n'.join(bad[:20])
 
 
@@ -169,7 +210,10 @@ def test_config5_fused_eval_forward_1024x2048(dtype):
         _argmax_near_tie(f'cfg5/{dtype}/seg_argmax_kernel', lab.cpu(), rlab, rseg, eps)
     n2 = assert_argmax_exact_or_near_tie(f'cfg5/{dtype}/seg_argmax_tensor', lab_ref_path.cpu(), rlab, rseg, eps=eps) if f32 else \
         _argmax_near_tie(f'cfg5/{dtype}/seg_argmax_tensor', lab_ref_path.cpu(), rlab, rseg, eps)
-    assert n1 <= (20 if f32 else 10 ** 9) and n2 <= (20 if f32 else 10 ** 9)
+    # fp16: every differing pixel is a proven near-tie of the oracle (above); their NUMBER is capped too: 0.5 % of the map
+    cap = 20 if f32 else int(0.005 * HH * WW)
+    print(f'cfg5/{dtype}: {n1} (fused kernel) / {n2} (tensor argmax) of {HH * WW} pixels differ from the oracle, all near-ties; cap {cap}')
+    assert n1 <= cap and n2 <= cap, (n1, n2, cap)
 
 
 def _argmax_near_tie(name, got, ref, ref_logits, eps):
@@ -196,6 +240,9 @@ LAYERS = [
     (32, 64, 3, 2, 1, 256, 512, '1.conv'),
     (64, 128, 3, 2, 1, 128, 256, '3.conv'),
     (256, 512, 3, 2, 1, 32, 64, '7.conv'),
+    (128, 256, 3, 2, 1, 64, 128, '5.conv (stride 2: dgrad = four parity sub-convolutions through conv_mid)'),
+    (128, 128, 1, 1, 1, 32, 64, '6.m.0.cv1 (two K steps)'),
+    (512, 512, 1, 1, 1, 16, 32, '9.cv3'),
     (256, 256, 3, 1, 1, 16, 32, '9.m.0.cv2'),
     (256, 128, 1, 1, 1, 64, 128, '24.m8.0'),
     (384, 64, 1, 1, 1, 64, 128, '24.out.0.branch0.0'),
@@ -259,4 +306,56 @@ def test_fp16_conv_layer_at_its_real_shape(layer, training):
         with torch.no_grad():
             y = mod(x.to(DEV))
         check(f'layer/{name}/eval/y', y, yr, 5e-3, collect=bad)
+    assert not bad, '\n'.join(bad)
+
+
+# ---- fp16 block cases at real shapes: the split BatchNorm of C3's merged entry convs, the one-pass pools of
+# PyramidPooling, the LDS-plane SPP pools and the stride-2 dgrad at the sizes where the kernel selection of the bench applies --------------
+BLOCKS16 = {
+    'c3_L4_64x128': (lambda C: C.C3(128, 128, 1, True), lambda c, p, x: model_ref.c3(c, p, x, 1, True), (2, 128, 64, 128)),
+    'c3_L6_32x64': (lambda C: C.C3(256, 256, 1, True), lambda c, p, x: model_ref.c3(c, p, x, 1, True), (2, 256, 32, 64)),
+    'c3_L9_16x32_noshort': (lambda C: C.C3(512, 512, 1, False), lambda c, p, x: model_ref.c3(c, p, x, 1, False), (2, 512, 16, 32)),
+    'spp_L8_16x32': (lambda C: C.SPP(512, 512), lambda c, p, x: model_ref.spp(c, p, x), (2, 512, 16, 32)),
+    'pyramid_psp_64x128': (lambda C: C.PyramidPooling(128), lambda c, p, x: model_ref.pyramid_pooling(c, p, x), (2, 128, 64, 128)),
+    'conv_s2_L5': (lambda C: C.Conv(128, 256, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), (2, 128, 64, 128)),
+    'conv_s2_L7': (lambda C: C.Conv(256, 512, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), (2, 256, 32, 64)),
+    'bottleneck_32x64': (lambda C: C.Bottleneck(128, 128, True), lambda c, p, x: model_ref.bottleneck(c, p, x, True), (2, 128, 32, 64)),
+}
+
+
+@pytest.mark.parametrize('name', list(BLOCKS16))
+def test_fp16_block_at_its_real_shape(name):
+    """train-mode forward + backward of a block in fp16 at the shape it has at 512x1024 (batch 2) against the fp32 oracle on the same
+    fp16-rounded input and conv weights: output 1e-2, input gradient 2e-2, parameter gradients 3e-2 relative L2 (a few fp16 layers deep;
+    the fp16-only kernels -- conv_mid / conv_halo / conv_stream, wgrad_tile, the fused stride-2 dgrad, split BatchNorm passes, one-pass
+    adaptive pools, LDS-plane SPP -- are selected by these sizes, not by the 64x128-image block tests)"""
+    from multiyolov5_amd.models import common as C
+    from multiyolov5_amd.utils.torch_utils import initialize_weights
+    from tests.test_gpu_ops import _oracle, _randomize
+    ctor, fn, shape = BLOCKS16[name]
+    torch.manual_seed(2)
+    mod = ctor(C)
+    initialize_weights(mod)
+    _randomize(mod, seed=4)
+    with torch.no_grad():
+        for p in mod.parameters():
+            if p.dim() == 4:
+                p.copy_(p.half().float())
+    mod = mod.to(DEV).train()
+    g = torch.Generator().manual_seed(5)
+    x_cpu = torch.randn(shape, generator=g).half()
+    ref_out, ref_params, ref_xin, ref_sd = _oracle(fn, mod, [x_cpu], True)
+    x = x_cpu.to(DEV).requires_grad_()
+    out = mod(x)
+    bad = []
+    check(f'block16/{name}/out', out, ref_out, 1e-2, collect=bad)
+    r = torch.randn(ref_out.shape, generator=g)
+    (ref_out * r).sum().backward()
+    (out.float() * r.to(DEV)).sum().backward()
+    check(f'block16/{name}/dx', x.grad, ref_xin[0].grad, 2e-2, collect=bad)
+    for k, p in mod.named_parameters():
+        check(f'block16/{name}/d{k}', p.grad, ref_params['m.' + k].grad, 3e-2, collect=bad)
+    for k, b in mod.named_buffers():
+        if 'running' in k:
+            check(f'block16/{name}/{k}', b, ref_sd['m.' + k], 1e-2, collect=bad)
     assert not bad, '\n'.join(bad)

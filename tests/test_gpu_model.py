@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import loss_ref, model_ref, synth
-from tests.gpu_util import TOL, check
+from tests.gpu_util import TOL, check, pool_replay
 from tests.util import CFG, TAGS, fp16_storage, golden, load_cfg, synth_sd, tie_free_images
 
 pytestmark = pytest.mark.gpu
@@ -246,7 +246,7 @@ def test_full_resolution_joint_train_step_vs_oracle(dtype):
     mask = synth.synth_seg_targets(B, HH, WW, 19, seed=2)
     cfg = load_cfg(tag)
 
-    def oracle_step(storage16):
+    def oracle_step(storage16, maxpool_fn=None):
         params = {k: v.clone().requires_grad_() for k, v in sd.items()
                   if v.dtype.is_floating_point and 'running' not in k and 'anchor' not in k}
         sdt = {k: (params[k] if k in params else v.clone()) for k, v in sd.items()}
@@ -254,12 +254,21 @@ def test_full_resolution_joint_train_step_vs_oracle(dtype):
             with fp16_storage():
                 rdet, rseg = model_ref.forward(cfg, sdt, x.half().float(), training=True, dropout_p=0.0)
         else:
-            rdet, rseg = model_ref.forward(cfg, sdt, x, training=True, dropout_p=0.0)
+            rdet, rseg = model_ref.forward(cfg, sdt, x, training=True, dropout_p=0.0, maxpool_fn=maxpool_fn)
         rl, _ = loss_ref.compute_loss(rdet, targets, sd['model.25.anchors'], hyp)
         rs = loss_ref.seg_ce(rseg, mask)
         (rl * 0.6 + rs * B * 0.35).backward()
         return rdet, rseg, rl.detach(), rs.detach(), params, sdt
-    rdet, rseg, rl, rs, params, sdt = oracle_step(False)
+    # the product first: in fp32 the oracle replays the product's max-pool choices at rounding-noise ties (tests/gpu_util.pool_replay)
+    det, seg = m(x.to(DEV, dtype))
+    loss, items = ComputeLoss(m)(det, targets.to(DEV))
+    segloss = SegmentationLosses()(seg, mask.to(DEV))
+    (loss * 0.6 + segloss * B * 0.35).backward()
+    replay, rstat = pool_replay(m) if dtype == torch.float32 else (None, None)
+    rdet, rseg, rl, rs, params, sdt = oracle_step(False, replay)
+    if rstat is not None:
+        assert rstat['pools'] == 3 and rstat['windows'] > 0, rstat
+        print('fulltrain max-pool replay:', rstat)
     rel = lambda a, b: ((a.detach().float().cpu() - b.detach().float().cpu()).norm() / b.detach().float().norm().clamp_min(1e-20)).item()
     noise_g, noise_f = {}, {}
     if dtype == torch.float16:
@@ -267,10 +276,6 @@ def test_full_resolution_joint_train_step_vs_oracle(dtype):
         noise_g = {k: rel(qparams[k].grad, params[k].grad) for k in params}
         noise_f = {f'det{i}': rel(qdet[i], rdet[i]) for i in range(3)}
         noise_f['seg'] = rel(qseg[:, :, ::8, ::8], rseg[:, :, ::8, ::8])
-    det, seg = m(x.to(DEV, dtype))
-    loss, items = ComputeLoss(m)(det, targets.to(DEV))
-    segloss = SegmentationLosses()(seg, mask.to(DEV))
-    (loss * 0.6 + segloss * B * 0.35).backward()
     tol = TOL[dtype]
     bad = []
     ftol = lambda key: tol if dtype == torch.float32 else max(tol, 2.0 * noise_f[key])      # fp16: 2x the oracle's own fp16-storage noise
@@ -287,8 +292,9 @@ def test_full_resolution_joint_train_step_vs_oracle(dtype):
         # resolution the three pools see ~10^5 distinct windows and a handful of them have top-2 values closer than the fp32 rounding
         # noise of two different summation orders -- the arg-max (gradient routing) of those flips and moves ~2e-3 of the gradient
         # energy (measured; the small-resolution tests pick tie-free inputs instead, tests/util.tie_free_images)
-        upstream = any(k.startswith(f'model.{i}.') for i in range(8)) or k.startswith('model.8.cv1.')
-        gt = (1e-2 if upstream else tol * 5) if dtype == torch.float32 else max(tol, 2.0 * noise_g[k])
+        # round 4: fp32 holds EVERY parameter to 1e-3 (the 1e-2 allowance upstream of the SPP pools is gone: the oracle replays the
+        # product's pool choices, see above)
+        gt = tol * 5 if dtype == torch.float32 else max(tol, 2.0 * noise_g[k])
         check(f'fulltrain/{dtype}/grad/{k}', p.grad, params[k].grad, gt, collect=worst)
         if dtype == torch.float16:      # product-fp16 vs oracle-with-fp16-storage directly (logged; same rounding points, different order)
             check(f'fulltrain/{dtype}/grad_vs_q16/{k}', p.grad, qparams[k].grad, 1.0, collect=[])

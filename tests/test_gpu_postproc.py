@@ -125,12 +125,17 @@ def test_nms_per_class_segments_match_the_oracle(case):
         kw['agnostic'] = True
     if case == 'classes_filter':
         kw['classes'] = [1, 3, 8]
-    ref = nms_ref.non_max_suppression(pred.numpy(), **kw)
-    for dt in (torch.float32,):
-        out = non_max_suppression(pred.to(DEV, dt), **kw)
+    for dt in (torch.float32, torch.float16):                 # fp16: detect.py --half (config 5 feeds NMS fp16 predictions)
+        half = dt == torch.float16
+        p = pred.half() if half else pred
+        ref = nms_ref.non_max_suppression(p.numpy(), half=half, **kw)      # (half=True is pinned to the reference's own fp16 run)
+        out = non_max_suppression(p.to(DEV), **kw)
         for i in range(pred.shape[0]):
-            _same(out[i].cpu().numpy(), ref[i], f'nms/{case}/{i}')
+            assert out[i].dtype == torch.float32
+            _same(out[i].cpu().numpy(), ref[i], f'nms/{case}/{dt}/{i}')
             assert out[i].shape[0] <= 300
+        if case == 'one_class_many_kept':
+            assert out[0].shape[0] == 300
 
 
 def test_seg_argmax_fused_matches_oracle_and_model_output():
