@@ -428,11 +428,17 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   const int bn = d->cout_pad % 128 == 0 ? 128 : 64;
   const int ntile_c = d->cout_pad / bn;
   int var = g_mid_var;
-  if (var == 0) var = bn == 64 ? 2 : (((M + 127) / 128) * ntile_c < g_mid_min_tiles ? 3 : 1);
+  if (var == 0) {
+    var = bn == 64 ? 2 : (((M + 127) / 128) * ntile_c < g_mid_min_tiles ? 3 : 1);
+    // K-heavy layers with >= 2 tiles of 256 x 128 per CU: 64 x 64 wave tiles (2/3 of the LDS and L2 bytes per MFMA; the segmentation
+    // head's 3x3 256 -> 128 at 64x128: 106 -> 94 us, its dgrad 114 -> 103; scripts/conv_train_ubench.py PROBE=mid)
+    if (var == 1 && ((M + 255) / 256) * ntile_c >= 512 && d->ntaps * (d->cin_pad / 64) >= 16) var = 4;
+  }
   if (bn == 64) var = 2;
   const int bm = var == 3 ? 64 : (var == 4 ? 256 : 128);
   k.ntile_p = (int)((M + bm - 1) / bm);
   k.tiles_per_xcd = (k.ntile_p + 7) / 8;
+  if (var == 1 && k.nsteps < 3) var = 5;               // (the four-stage ring's prologue issues three K steps)
   hipStream_t st = (hipStream_t)stream;
   const int bn_eff = var == 2 ? 64 : 128, ntc = d->cout_pad / bn_eff;
   // the BatchNorm-backward sums of the layer(s) below ride in the epilogue when every segment is a whole number of N tiles
@@ -440,10 +446,10 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   const bool fold = d->bnb && d->nbnb > 0 && d->nbnb <= MYOLO_MAX_BNB && !d->stats && !no_fold && !k.dbg && bnb_aligned(d, bn_eff);
   k.bnb.n = 0;
   if (fold) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
-  if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 3, true>(k, 1, ntc, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
-  if (var == 1) return fold ? launch<128, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 3>(k, 1, ntc, st);
+  if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 4, true>(k, 1, ntc, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
+  if (var == 1) return fold ? launch<128, 128, 4, 2, 4, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 4>(k, 1, ntc, st);     // four stages: loads three K steps ahead
   if (var == 4) return fold ? launch<256, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<256, 128, 4, 2, 3>(k, 1, ntc, st);   // 64 x 64 wave tiles
-  if (var == 5) return fold ? launch<128, 128, 4, 2, 4, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 4>(k, 1, ntc, st);   // four stages
+  if (var == 5) return fold ? launch<128, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 3>(k, 1, ntc, st);   // three stages
   if (var == 2) return fold ? launch<128, 64, 2, 2, 3, false, true>(k, 2, ntc, st) : launch<128, 64, 2, 2, 3>(k, 2, ntc, st);
   return fold ? launch<64, 128, 1, 4, 3, false, true>(k, 2, ntc, st) : launch<64, 128, 1, 4, 3>(k, 2, ntc, st);
 }

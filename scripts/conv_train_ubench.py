@@ -83,7 +83,8 @@ if os.environ.get('PROBE') == 'mid':
          (256, 128, 3, 1, 1, 64, 128), (128, 256, 3, 1, 1, 64, 128), (128, 256, 3, 2, 1, 64, 128), (256, 512, 3, 2, 1, 32, 64),
          (64, 64, 3, 1, 1, 64, 128), (128, 128, 1, 1, 1, 64, 128), (64, 64, 1, 1, 1, 64, 128), (256, 128, 1, 1, 1, 64, 128), (64, 128, 3, 2, 1, 128, 256),
          (64, 64, 1, 1, 1, 128, 256)]
-    V = [('old', {'mid_mode': 0}), ('mid', {'mid_mode': 2}), ('v2', {'mid_mode': 2, 'mid_var': 2}), ('v3', {'mid_mode': 2, 'mid_var': 3})]
+    V = [('old', {'mid_mode': 0}), ('mid', {'mid_mode': 2}), ('v5', {'mid_mode': 2, 'mid_var': 5}), ('v2', {'mid_mode': 2, 'mid_var': 2}), ('v3', {'mid_mode': 2, 'mid_var': 3}),
+         ('v4', {'mid_mode': 2, 'mid_var': 4})]
     for shp in P:
         cin, cout, k, s, d, H, W = shp
         M = B * ((H + s - 1) // s) * ((W + s - 1) // s)
@@ -103,7 +104,7 @@ if os.environ.get('PROBE') == 'mid_dbg':
     # where conv_mid's time goes: dbg bits 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores; tile variants
     P = [(128, 128, 3, 1, 1, 32, 64), (256, 128, 3, 1, 1, 64, 128), (256, 256, 1, 1, 1, 32, 64), (512, 512, 1, 1, 1, 16, 32), (128, 128, 1, 1, 1, 32, 64)]
     V = [('v1', 1, 0), ('noload', 1, 1), ('noread', 1, 2), ('nomfma', 1, 4), ('nostore', 1, 8), ('load only', 1, 6), ('mfma only', 1, 3),
-         ('skeleton', 1, 15), ('v4 256x128', 4, 0), ('v4 noload', 4, 1), ('v4 nomfma', 4, 4), ('v5 4-stage', 5, 0), ('v3 64x128', 3, 0)]
+         ('skeleton', 1, 15), ('skel-nobar', 1, 31), ('nobar', 1, 16), ('mfma only nobar', 1, 19), ('v4 256x128', 4, 0), ('v4 noload', 4, 1), ('v4 nomfma', 4, 4), ('v5 4-stage', 5, 0), ('v3 64x128', 3, 0)]
     for shp in P:
         row = []
         for name, var, dbg in V:
