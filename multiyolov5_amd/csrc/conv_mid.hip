@@ -31,6 +31,7 @@ typedef __attribute__((address_space(3))) void lptr_t;
 
 struct MidK {
   const char* x; const char* w; char* y; const char* res; float* stats;
+  const float* scale; const float* shift; int act;      // EPI: y = act(conv * scale[c] + shift[c]) (eval: folded BatchNorm / bias + activation)
   int x_sn, x_sh, x_sw;            // bytes
   int y_sn, y_sh, y_sw;
   int r_sn, r_sh, r_sw;
@@ -56,8 +57,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 // BM x BN output tile (pixels x channels), WP x WC waves (each (BM/WP) pixels x (BN/WC) channels), NST LDS stages
 // BNS: the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb; conv_igemm.hip has the same fold):
 //   dsum0 += dz, dsum1 += dz * xhat with dz = gout * act'(bn(y)) on the final, storage-rounded values, per channel
-template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false>
+// EPI (exclusive with BNS): per-channel scale / shift and activation ahead of the residual add (the eval epilogue of conv_igemm.hip)
+template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false, bool EPI = false>
 __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
+  static_assert(!(BNS && EPI), "one epilogue table");
   constexpr int NT = 64 * WP * WC;
   constexpr int PW = BM / WP, CW = BN / WC;       // wave tile
   constexpr int PF = PW / 16, CF = CW / 16;       // 16 x 16 fragments per wave
@@ -112,6 +115,14 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
         const float sc = in ? sg.gamma[ci] * istd : 0.f;
         sBN[c] = mean; sBN[BN + c] = istd; sBN[2 * BN + c] = sc; sBN[3 * BN + c] = in ? sg.beta[ci] - mean * sc : 0.f;
       }
+    }
+    __syncthreads();
+  }
+  if (EPI) {                                        // the same LDS area: [2][BN] scale, shift of this N tile
+    for (int c = tid; c < BN; c += NT) {
+      const int cg = tn * BN + c;
+      sBN[c] = (p.scale && cg < p.Cout) ? p.scale[cg] : 1.f;
+      sBN[BN + c] = (p.shift && cg < p.Cout) ? p.shift[cg] : 0.f;
     }
     __syncthreads();
   }
@@ -285,6 +296,11 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
           for (int i = 0; i < 8; ++i) { st_s[h][i] += v[i]; st_q[h][i] += v[i] * v[i]; }
         }
         const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
+        if (EPI) {
+          const int cl = wc * CW + 32 * h + 8 * lq;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = act_f(fmaf(v[i], sBN[cl + i], sBN[BN + cl + i]), p.act);
+        }
         if (mvalid && c0 < p.Cout && !(DBG && (p.dbg & 8))) {
           if (p.res) {
             const uint4 g = ldg16(p.res + roff + c0 * 2);
@@ -348,15 +364,15 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   }
 }
 
-template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false>
+template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false, bool EPI = false>
 int launch(const MidK& k, int per_cu, int ntile_c, hipStream_t st) {
   constexpr int NT = 64 * WP * WC;
-  constexpr int SMEM = NST * (BM + BN) * 128 + (BNS ? 4 * BN * 4 : 0);
+  constexpr int SMEM = NST * (BM + BN) * 128 + (BNS ? 4 * BN * 4 : (EPI ? 2 * BN * 4 : 0));
   static_assert(SMEM >= WP * 2 * BN * 4, "statistics reduction area");
   int per_xcd = (256 * per_cu / ntile_c + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
-  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS>;
+  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS, EPI>;
   MYOLO_ENSURE_DYN_SMEM(kern, SMEM);
   hipLaunchKernelGGL(kern, dim3(per_xcd * 8, ntile_c), dim3(NT), SMEM, st, k);
   MYOLO_CHECK_LAUNCH();
@@ -401,7 +417,10 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
       if ((skip & 256) && d->bnb && d->nbnb > 0) return -1;
     }
   }
-  if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->scale || d->shift || d->act != MYOLO_ACT_NONE || d->up_shift != 0) return -1;
+  if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->up_shift != 0) return -1;
+  const bool epi = d->scale || d->shift || d->act != MYOLO_ACT_NONE;
+  static const int no_epi = getenv("MYOLO_MID_NO_EPI") != nullptr;
+  if (epi && (d->stats || (d->bnb && d->nbnb > 0) || no_epi)) return -1;                // (statistics are taken from the raw accumulators only)
   if (d->cin_pad % 64 || d->x.c != d->cin_pad || d->cout_pad % 64 || d->y.c % 8 || d->ntaps > 25) return -1;
   if (d->ntaps * (d->cin_pad / 64) < 2) return -1;                  // (the ring's prologue issues two K steps)
   if (d->res.ptr && (d->res.c < d->y.c)) return -1;
@@ -412,6 +431,7 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   if ((int64_t)d->cout_pad * d->wtaps * d->cin_pad * 2 >= (1ll << 31)) return -1;
   MidK k;
   k.x = (const char*)d->x.ptr; k.w = (const char*)d->w; k.y = (char*)d->y.ptr; k.res = (const char*)d->res.ptr; k.stats = d->stats;
+  k.scale = d->scale; k.shift = d->shift; k.act = d->act;
   k.x_sn = (int)d->x.sn * 2; k.x_sh = (int)d->x.sh * 2; k.x_sw = (int)d->x.sw * 2;
   k.y_sn = (int)d->y.sn * 2; k.y_sh = (int)d->y.sh * 2; k.y_sw = (int)d->y.sw * 2;
   k.r_sn = (int)d->res.sn * 2; k.r_sh = (int)d->res.sh * 2; k.r_sw = (int)d->res.sw * 2;
@@ -447,9 +467,13 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   k.bnb.n = 0;
   if (fold) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
   if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 4, true>(k, 1, ntc, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
-  if (var == 1) return fold ? launch<128, 128, 4, 2, 4, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 4>(k, 1, ntc, st);     // four stages: loads three K steps ahead
-  if (var == 4) return fold ? launch<256, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<256, 128, 4, 2, 3>(k, 1, ntc, st);   // 64 x 64 wave tiles
-  if (var == 5) return fold ? launch<128, 128, 4, 2, 3, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 3>(k, 1, ntc, st);   // three stages
-  if (var == 2) return fold ? launch<128, 64, 2, 2, 3, false, true>(k, 2, ntc, st) : launch<128, 64, 2, 2, 3>(k, 2, ntc, st);
-  return fold ? launch<64, 128, 1, 4, 3, false, true>(k, 2, ntc, st) : launch<64, 128, 1, 4, 3>(k, 2, ntc, st);
+#define MID_GO(BM_, BN_, WP_, WC_, NST_, PCU_)                                                   \
+  return fold ? launch<BM_, BN_, WP_, WC_, NST_, false, true>(k, PCU_, ntc, st)                   \
+              : (epi ? launch<BM_, BN_, WP_, WC_, NST_, false, false, true>(k, PCU_, ntc, st) : launch<BM_, BN_, WP_, WC_, NST_>(k, PCU_, ntc, st))
+  if (var == 1) MID_GO(128, 128, 4, 2, 4, 1);       // four stages: loads three K steps ahead
+  if (var == 4) MID_GO(256, 128, 4, 2, 3, 1);       // 64 x 64 wave tiles
+  if (var == 5) MID_GO(128, 128, 4, 2, 3, 1);       // three stages
+  if (var == 2) MID_GO(128, 64, 2, 2, 3, 2);
+  MID_GO(64, 128, 1, 4, 3, 2);
+#undef MID_GO
 }

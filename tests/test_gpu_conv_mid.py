@@ -161,3 +161,47 @@ def test_conv_mid_bn_backward_sums_in_the_epilogue(case, var):
         want = ref.view(L.STAT_COPIES, 2, c1 - c0).sum(0)
         assert float(want.abs().max()) > 1e-3
         check(f'mid_bnb/{case}/var{var}/seg{i}', got, want, 2e-4)
+
+
+@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('shape', [(128, 128, 3, 1, 1, 1, 64, 128), (64, 64, 3, 1, 1, 1, 128, 256), (256, 192, 1, 1, 1, 1, 33, 64), (128, 256, 3, 2, 1, 1, 64, 128)],
+                         ids=['128-128k3', '64-64k3', '256-192k1_ragged', '128-256k3s2'])
+def test_conv_mid_eval_epilogue(shape, var):
+    """the eval epilogue (folded BatchNorm scale / shift, SiLU, Bottleneck residual; reference common.py:45-46 fuseforward + :105) of the
+    layers conv_mid takes in a detect.py frame, against torch fp32 on the same fp16-rounded operands"""
+    from multiyolov5_amd import _lib as L, engine as E
+    lib = L.lib()
+    cin, cout, k, s, d, B, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
+    x = (torch.randn(B, H, W, cin, generator=g) * 0.5).half()
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)).half()
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.3
+    r0 = (torch.randn(B, Ho, Wo, cout, generator=g) * 0.3).half()
+    pad = d * (k // 2)
+    conv = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, s, pad, d).permute(0, 2, 3, 1)
+    ref = F.silu(conv * scale + shift) + r0.float()
+    xd, rd = x.to(DEV), r0.to(DEV)
+    yd = torch.zeros(B, Ho, Wo, cout, device=DEV, dtype=torch.float16)
+    cin_pad, cout_pad = E.rup(cin, 32), E.rup(cout, 32)
+    wp = torch.zeros(cout_pad, k * k, cin_pad, device=DEV, dtype=torch.float16)
+    L.check(lib.myolo_pack_weight(L.ptr(w.float().to(DEV)), L.F32, cout, cin, k, k, L.ptr(wp), L.F16, cout_pad, cin_pad, 0, None, L.stream_ptr()))
+    sc, sh = scale.to(DEV), shift.to(DEV)
+    dd = L.ConvDesc()
+    dd.x, dd.y, dd.w = _tdesc(L, xd), _tdesc(L, yd), wp.data_ptr()
+    dd.cin_pad, dd.cout_pad, dd.wtaps, dd.ntaps, dd.stride, dd.up_shift = cin_pad, cout_pad, k * k, k * k, s, 0
+    E.fill_taps(dd, *E.taps_fwd(k, d, pad))
+    dd.res = _tdesc(L, rd)
+    dd.act, dd.stats, dd.accumulate = L.ACT_SILU, None, 0
+    dd.scale, dd.shift = sc.data_ptr(), sh.data_ptr()
+    lib.myolo_set_option(b'mid_mode', 2)
+    lib.myolo_set_option(b'mid_var', var)
+    lib.myolo_set_option(b'small_off', 1)              # (the split-K small-map kernel would take the batch-1 shapes first)
+    try:
+        L.check(lib.myolo_conv(C.byref(dd), L.stream_ptr()))
+        torch.cuda.synchronize()
+    finally:
+        lib.myolo_set_option(b'mid_var', 0)
+        lib.myolo_set_option(b'small_off', 0)
+    check(f'mid_eval/{shape}/var{var}', yd, ref, 2e-3)
