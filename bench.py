@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-stock-baseline', action='store_true',
+                    help='skip the stock PyTorch-ROCm (ATen + MIOpen) run of the same graph on this GPU (SURVEY 8(d) last line; ~25 s)')
     ap.add_argument('--sync-bn', action='store_true', help='train.py --sync-bn: nn.SyncBatchNorm statistics over all ranks (N > 1)')
     ap.add_argument('--ddp', default='reducer', choices=['reducer', 'stock'],
                     help="N > 1 gradient exchange: 'reducer' = parallel.GradReducer (3 flat slices on a side stream), 'stock' = the model "
@@ -394,6 +396,31 @@ SURVEY_FWD_BYTES_PER_IMAGE = {          # conv input + weights +
     'yolov5s_city_seg.yaml': 200.8e6, 'yolov5s_city_seg_base.yaml': 233.6e6, 'yolov5m_city_seg_lab.yaml': 333.6e6}
 
 
+def stock_rocm_baseline(args):
+    """SURVEY 8(d) 'unmodified reference on MI355X': the reference graph as the ATen ops its modules call (oracle.rocm_stock_bench: ATen +
+    MIOpen under torch.autocast(fp16), torch.optim.SGD, GradScaler, foreach EMA), on THIS GPU, in its own process, after every timed
+    region of this file.  A baseline beside `cpu_baseline`, never the product path."""
+    import subprocess
+    env = dict(os.environ, MIOPEN_FIND_MODE='FAST', MIOPEN_USER_DB_PATH='/tmp/miopen', MIOPEN_LOG_LEVEL='2')
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK'):
+        env.pop(k, None)
+    out = {'what': 'oracle.rocm_stock_bench: PyTorch %s ATen + MIOpen (immediate mode, no gfx950 find-db), NCHW, autocast fp16, same synthetic '
+                   'batch; train = fwd + both losses + bwd + SGD + EMA, infer = fused fp16 forward + seg argmax WITHOUT NMS' % torch.__version__}
+    try:
+        r = subprocess.run([sys.executable, '-m', 'oracle.rocm_stock_bench', '--cfg', args.cfg, '--batch', str(args.batch), '--img',
+                            str(args.img[0]), str(args.img[1]), '--steps', '6', '--warmup', '2'], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=240)
+        for ln in r.stdout.splitlines():
+            if ln.startswith('{'):
+                j = json.loads(ln)
+                out[j.pop('leg')] = j
+        if r.returncode != 0 and len(out) == 1:
+            out['error'] = r.stderr[-400:]
+    except Exception as e:                                # a baseline must not take the primary line down
+        out['error'] = repr(e)
+    return out
+
+
 def whole_step_roofline(tr, ms):
     """SURVEY 8(d) convention: a training step moves 3x the forward's conv bytes (forward + dgrad + wgrad; every conv operand once,
     no fusion credit, nothing else counted) -- 3 x 200.8 MB x 16 = 9.64 GB for the benchmarked step -- over the WHOLE step time."""
@@ -603,7 +630,7 @@ def main():
                 traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/' + os.path.basename(pmc) + ': ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
-                               'kernel': 'myolo_conv launches of one step: conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below counts that reduce pass\'s gout + y bytes)',
+                               'kernel': 'myolo_conv launches of one step: conv_mid_kernel + conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below counts that reduce pass\'s gout + y bytes)',
                                'launches_per_step': n,
                                'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
                                'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,
@@ -636,6 +663,13 @@ def main():
                 out['augment'] = {'error': repr(e)}
         if args.stage == 'train' and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
+        if args.stage == 'train' and not args.no_stock_baseline and not args.no_infer:
+            del tr                                       # (the stock run needs a few GB of the same GPU)
+            torch.cuda.empty_cache()
+            out['stock_rocm_baseline'] = stock_rocm_baseline(args)
+            sb = out['stock_rocm_baseline'].get('train', {}).get('images_per_s')
+            if sb:
+                out['stock_rocm_baseline']['speedup_train'] = out['value'] / sb
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
