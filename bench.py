@@ -78,6 +78,7 @@ def spawn_ranks(args):
 
 
 def setup_dist(args):
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')         # before the first HIP call: RCCL needs dmabuf IPC on this driver
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -581,6 +582,8 @@ def main():
     barrier(world)
     if getattr(tr, 'reducer', None) is not None:
         tr.reducer.exposed = []                          # (two event records per step; the wait itself is unchanged)
+    from multiyolov5_amd.engine import SyncPoint
+    SyncPoint.calls, SyncPoint.host_s = 0, 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         tr.step()
@@ -612,6 +615,10 @@ def main():
     }
     assert out['n_gpus'] == args.gpus, (out['n_gpus'], args.gpus)
     out['checks'] = checks
+    if args.sync_bn:
+        # nn.SyncBatchNorm: host-issued all-reduces of the per-layer statistics (2 per Conv+BatchNorm layer and step), each cutting the
+        # native launch program (engine.SyncPoint); their enqueue cost on this rank
+        out['syncbn'] = {'collectives_per_step': SyncPoint.calls / max(args.steps, 1), 'host_ms_per_step': SyncPoint.host_s / max(args.steps, 1) * 1e3}
     if world > 1:
         # the main stream's wait for the RCCL slices at the end of the backward (HIP events, mean over the timed steps, this rank):
         # what the overlap with the backward did NOT hide

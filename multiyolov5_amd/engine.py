@@ -134,14 +134,19 @@ class SyncPoint:
     before BatchNorm's forward, the backward sums before its apply pass).  Behaves like a Call in the Python launch loops; the native
     executor's program is cut at it (NativeProg.run)."""
     __slots__ = ('t', 'group', 'name', 'side', 'args', 'keep')
+    calls, host_s = 0, 0.0          # process-wide tally (bench.py --sync-bn reports collectives and their host cost per step)
 
     def __init__(self, t, group):
         self.t, self.group = t, group
         self.name, self.side, self.args, self.keep = 'sync_allreduce', False, (), t
 
     def __call__(self, st=None):
+        import time
         import torch.distributed as dist
+        t0 = time.perf_counter()
         dist.all_reduce(self.t, op=dist.ReduceOp.SUM, group=self.group)     # RCCL: stream-ordered behind / before the neighbouring launches
+        SyncPoint.calls += 1
+        SyncPoint.host_s += time.perf_counter() - t0
 
 
 class Op:
