@@ -266,7 +266,7 @@ def conv_kernel_timing(trainer, nsteps=3):
     orig = E.Call.__call__
 
     def timed(self, st):
-        if self.name not in ('myolo_conv', 'myolo_conv_dgrad_s2'):
+        if self.name not in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
             return orig(self, st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -286,7 +286,7 @@ def conv_kernel_timing(trainer, nsteps=3):
         E.GRAPH_TRAIN = graph_mode
         E.NATIVE_EXEC = native_mode
     tot_t = sum(e0.elapsed_time(e1) for _, e0, e1 in rec) * 1e-3 / nsteps
-    tot_b = sum(E.conv_call_bytes(c) + E.bnb_call_bytes(c) for c, _, _ in rec) / nsteps     # (+ the BatchNorm-backward reduce passes a dgrad launch carries)
+    tot_b = sum(E.conv_call_bytes(c) + E.bnb_call_bytes(c) + E.apply_fold_bytes(c) for c, _, _ in rec) / nsteps     # (+ the BatchNorm-backward reduce / apply passes a dgrad launch carries)
     tot_f = sum(E.conv_call_flops(c) for c, _, _ in rec) / nsteps
     return tot_b, tot_f, tot_t, len(rec) // nsteps
 
@@ -637,7 +637,7 @@ def main():
                 traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/' + os.path.basename(pmc) + ': ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
-                               'kernel': 'myolo_conv launches of one step: conv_mid_kernel + conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below counts that reduce pass\'s gout + y bytes)',
+                               'kernel': 'myolo_conv launches of one step: conv_mid_kernel + conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below, or carries its own layer\'s BatchNorm-backward apply pass in its operand path (myolo_conv_dgrad_bn), counts that pass\'s bytes)',
                                'launches_per_step': n,
                                'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
                                'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,

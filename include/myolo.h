@@ -127,6 +127,26 @@ typedef struct myolo_conv_desc {
 } myolo_conv_desc;
 int myolo_conv(const myolo_conv_desc* d, void* stream);
 
+/* dgrad of a 1x1 stride-1 Conv + BatchNorm (+ activation) layer WITH the BatchNorm-backward apply pass in its operand path (round 4;
+ * reference models/common.py:42-43 `act(bn(conv(x)))`, autograd): d->x is the gradient w.r.t. the layer's ACTIVATION output (gout), `f`
+ * names the layer's saved raw conv output y, the statistics of the reduce pass and where dy (the gradient w.r.t. y, the weight gradient's
+ * operand) goes.  Same results as myolo_bn_act_bwd_apply(gout, y, ..., dy, no gres) followed by myolo_conv(d with x = dy) -- which is what
+ * runs when the layer does not qualify -- in one launch: gout and y are staged once, dy = sc*dz + cb*y + cd is formed in LDS, feeds the
+ * MFMAs and is written out by the workgroups of the first N tile; dgamma / dbeta += the reduce pass' sums. */
+typedef struct myolo_bn_apply_fold {
+  myolo_tensor y;            /* raw conv output of the layer [N,H,W,C] (saved by the forward) */
+  myolo_tensor dy;           /* OUT [N,H,W,C]: gradient w.r.t. y */
+  const float* saved;        /* fp32[2*C]: mean, invstd (myolo_bn_act_fwd) */
+  const float* gamma;
+  const float* beta;
+  const float* dsum;         /* fp32[MYOLO_STAT_COPIES*2*C]: sums of myolo_bn_act_bwd_reduce / myolo_conv_desc.bnb */
+  float* dgamma;             /* += (may be NULL) */
+  float* dbeta;
+  int32_t act;
+  int32_t reserved;
+} myolo_bn_apply_fold;
+int myolo_conv_dgrad_bn(const myolo_conv_desc* d, const myolo_bn_apply_fold* f, void* stream);
+
 /* dgrad of a STRIDE-2 convolution.  `parity[k]`, k = 2*py + px, is the stride-1 sub-convolution producing the input-gradient pixels
  * (2a+py, 2b+px) from dy and the transposed weights (the taps with (p + pad - k*d) % 2 == 0; y = the strided parity view of gx).  With
  * all n == 4 parities over one dy / one weight tensor the four run as ONE launch (dy staged once, every gx row written whole);

@@ -26,6 +26,11 @@ class BnBwdSeg(C.Structure):
                 ('dsum', C.c_void_p), ('act', C.c_int32), ('reserved', C.c_int32)]
 
 
+class BnApplyFold(C.Structure):
+    _fields_ = [('y', Tensor), ('dy', Tensor), ('saved', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('dsum', C.c_void_p),
+                ('dgamma', C.c_void_p), ('dbeta', C.c_void_p), ('act', C.c_int32), ('reserved', C.c_int32)]
+
+
 class BnSplit(C.Structure):
     _fields_ = [('c_split', C.c_int32), ('count_scale', C.c_int32), ('gamma2', C.c_void_p), ('beta2', C.c_void_p),
                 ('running_mean2', C.c_void_p), ('running_var2', C.c_void_p), ('nbt2', C.c_void_p), ('dgamma2', C.c_void_p),
@@ -108,6 +113,7 @@ _PROTOS = {
     'myolo_focus_pack': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, TP, P]),
     'myolo_conv': (C.c_int, [C.POINTER(ConvDesc), P]),
     'myolo_conv_dgrad_s2': (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.c_int, P]),
+    'myolo_conv_dgrad_bn': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BnApplyFold), P]),
     'myolo_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), P]),
     'myolo_bn_act_fwd': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, P]),
     'myolo_bn_act_bwd_reduce': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P]),

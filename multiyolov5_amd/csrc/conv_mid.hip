@@ -39,6 +39,13 @@ struct MidK {
   int stride, ntaps, kchunks, nsteps;
   int wrow_bytes;                  // bytes between two output-channel rows of the packed weights (wtaps * cin_pad * 2)
   int ntile_p, tiles_per_xcd, accumulate;
+  // BNA: the BatchNorm-backward APPLY pass of the layer this 1x1 dgrad belongs to, in its operand path: x is the gradient w.r.t. the
+  // layer's activation output (gout), `by` its saved raw conv output; dy = sc*dz + cb*y + cd (dz = gout * act'(y*sc + sh)) is formed in LDS
+  // once per 16-byte slot by the thread that loaded it, feeds the MFMAs and is stored to `bdy` (the weight gradient's operand) by the
+  // workgroups of N tile 0; workgroup (0, 0) adds dgamma / dbeta
+  const char* by; char* bdy; int by_sn, by_sh, by_sw, dy_sn, dy_sh, dy_sw;
+  const float* b_saved; const float* b_gamma; const float* b_beta; const float* b_dsum; float* b_dgamma; float* b_dbeta;
+  int b_act, b_K; float b_rM;      // channels of the layer (= this conv's K), 1 / pixels
   BnbArgs bnb;                     // BNS: BatchNorm-backward statistics of the layer(s) whose output gradient this launch completes
   int dbg;                         // profiling only: 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores
   int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
@@ -58,9 +65,9 @@ __device__ __forceinline__ float row_sum16(float v) {
 // BNS: the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb; conv_igemm.hip has the same fold):
 //   dsum0 += dz, dsum1 += dz * xhat with dz = gout * act'(bn(y)) on the final, storage-rounded values, per channel
 // EPI (exclusive with BNS): per-channel scale / shift and activation ahead of the residual add (the eval epilogue of conv_igemm.hip)
-template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false, bool EPI = false>
+template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false, bool EPI = false, bool BNA = false>
 __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
-  static_assert(!(BNS && EPI), "one epilogue table");
+  static_assert(!(BNS && EPI) && !(BNA && EPI), "one epilogue table");
   constexpr int NT = 64 * WP * WC;
   constexpr int PW = BM / WP, CW = BN / WC;       // wave tile
   constexpr int PF = PW / 16, CF = CW / 16;       // 16 x 16 fragments per wave
@@ -68,8 +75,9 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   constexpr int RPI = NT / 8;                     // rows per load instruction of the workgroup (8 lanes per 128-byte row)
   constexpr int XR = BM / RPI, WR = BN / RPI;     // loads per thread and stage
   static_assert(XR >= 1 && WR >= 1 && BM % RPI == 0 && BN % RPI == 0, "tile rows must divide over the loader lanes");
-  constexpr int LPS = XR + WR;
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int LPS = XR * (BNA ? 2 : 1) + WR;    // BNA: a second pixel tile (the layer's raw conv output) per stage, behind the weights
+  constexpr int STAGE = (BM * (BNA ? 2 : 1) + BN) * 128;
+  constexpr int MAXK = 512;                       // BNA: channels of the constant table
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -127,12 +135,32 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     __syncthreads();
   }
 
+  float* sBA = sBN + (BNS ? 4 * BN : 0);            // BNA: [4][b_K] sc, sh, cb, cd of the layer being differentiated (bn_act.hip's apply constants)
+  if (BNA) {
+    const int K = p.b_K;
+    for (int c = tid; c < K; c += NT) {
+      const float mean = p.b_saved[c], istd = p.b_saved[K + c];
+      const float sc = p.b_gamma[c] * istd;
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll 8
+      for (int k = 0; k < MYOLO_STAT_COPIES; ++k) { d0 += p.b_dsum[k * 2 * K + c]; d1 += p.b_dsum[k * 2 * K + K + c]; }
+      const float cb = -sc * (d1 * p.b_rM) * istd;
+      sBA[c] = sc; sBA[K + c] = p.b_beta[c] - mean * sc; sBA[2 * K + c] = cb; sBA[3 * K + c] = -sc * (d0 * p.b_rM) - cb * mean;
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        if (p.b_dgamma) p.b_dgamma[c] += d1;
+        if (p.b_dbeta) p.b_dbeta[c] += d0;
+      }
+    }
+    __syncthreads();
+  }
+
   for (int tslot = bslot; tslot < p.tiles_per_xcd; tslot += bstride) {
     const int tp = xcd * p.tiles_per_xcd + tslot;
     if (tp >= p.ntile_p) break;
     const int m0 = tp * BM;
 
     int xbase[XR]; unsigned xmask[XR];
+    int ybase[XR], dybase[XR];                     // BNA: the row's pixel in the raw conv output / dy tensors
 #pragma unroll
     for (int j = 0; j < XR; ++j) {
       const int m = m0 + j * RPI + lrow;
@@ -142,6 +170,10 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
       const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
       const int iy0 = oy * p.stride, ix0 = ox * p.stride;
       xbase[j] = n * p.x_sn + iy0 * p.x_sh + ix0 * p.x_sw + lsg * 16;
+      if (BNA) {
+        ybase[j] = n * p.by_sn + oy * p.by_sh + ox * p.by_sw + lsg * 16;
+        dybase[j] = n * p.dy_sn + oy * p.dy_sh + ox * p.dy_sw + lsg * 16;
+      }
       unsigned mk = 0;
       for (int t = 0; t < p.ntaps; ++t) {          // (tap offsets by readlane: a scalar table read per tap and row was a chain of ~0.25 us loads)
         const int iy = iy0 + __builtin_amdgcn_readlane(v_dy, t), ix = ix0 + __builtin_amdgcn_readlane(v_dx, t);
@@ -169,12 +201,17 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
         src[j] = ((xmask[j] >> t) & 1u) ? p.x + (unsigned)(xbase[j] + xo) : zero_page();
 #pragma unroll
       for (int j = 0; j < WR; ++j) src[XR + j] = p.w + (unsigned)(wbase[j] + wo);
+      if (BNA) {
+#pragma unroll
+        for (int j = 0; j < XR; ++j) src[XR + WR + j] = ((xmask[j] >> t) & 1u) ? p.by + (unsigned)(ybase[j] + i_kc * 128) : zero_page();
+      }
       if (++i_kc == p.kchunks) { i_kc = 0; ++i_tap; }
       const int tn_ = i_tap < p.ntaps ? i_tap : 0;
       n_xt = p.tap_xoff[tn_]; n_wt = p.tap_woff[tn_];
     };
     auto piece = [&](int i, int buf) {             // one 1 KB LDS-DMA piece of this wave: 8 rows x 128 B, lane-linear in LDS
-      char* dst = smem + buf * STAGE + wave * 1024 + (i < XR ? i * RPI * 128 : BM * 128 + (i - XR) * RPI * 128);
+      char* dst = smem + buf * STAGE + wave * 1024 +
+                  (i < XR ? i * RPI * 128 : (i < XR + WR ? BM * 128 + (i - XR) * RPI * 128 : (BM + BN) * 128 + (i - XR - WR) * RPI * 128));
       __builtin_amdgcn_global_load_lds((gptr_t*)src[i], (lptr_t*)dst, 16, 0, 0);
     };
     // One K step.  The fragment reads and their waits are inline asm: hipcc's waitcnt pass makes every ds_read it can see wait for ALL
@@ -183,6 +220,48 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     // The LDS-DMA pieces of stage s + NST-1 are issued BETWEEN the MFMA groups (an LDS-DMA issue holds its wave for 60-180 cycles,
     // MI355X_MICROARCH.md: issued in a block ahead of the reads -- both waves of a SIMD leave the barrier together -- the matrix pipe
     // idled through it; scripts/conv_train_ubench.py PROBE=mid_dbg: loads alone 4.9 us, MFMAs alone 5.4, together 11.5 of an 18-step tile).
+    // BNA: this thread's own 16-byte slots of stage `buf` (the ones its LDS-DMA pieces filled: no barrier needed in front), K chunk kc:
+    // gout and y -> dy in place of gout; all LDS traffic in inline asm like the fragment reads (hipcc would wait vmcnt(0) before each)
+    auto transform = [&](int buf, int kc) {
+      const unsigned ga = lds0 + buf * STAGE + tid * 16, ya = ga + (BM + BN) * 128;
+      const unsigned ca = lds0 + NST * STAGE + (BNS ? 4 * BN * 4 : 0) + (kc * 64 + lsg * 8) * 4;
+      const unsigned Kb = (unsigned)p.b_K * 4;
+      u32x4_t cv[8], gv[XR], yv[XR];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        asm volatile("ds_read_b128 %0, %1" : "=v"(cv[2 * a]) : "v"(ca + a * Kb) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(cv[2 * a + 1]) : "v"(ca + a * Kb) : "memory");
+      }
+#pragma unroll
+      for (int j = 0; j < XR; ++j) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(gv[j]) : "v"(ga), "n"(j * RPI * 128) : "memory");
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(yv[j]) : "v"(ya), "n"(j * RPI * 128) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int a = 0; a < 8; ++a) asm volatile("" : "+v"(cv[a]));
+#pragma unroll
+      for (int j = 0; j < XR; ++j) { asm volatile("" : "+v"(gv[j])); asm volatile("" : "+v"(yv[j])); }
+      const float* sc = reinterpret_cast<const float*>(&cv[0]);      // [8] each: sc, sh, cb, cd
+      const float* sh = reinterpret_cast<const float*>(&cv[2]);
+      const float* cb = reinterpret_cast<const float*>(&cv[4]);
+      const float* cd = reinterpret_cast<const float*>(&cv[6]);
+#pragma unroll
+      for (int j = 0; j < XR; ++j) {
+        float fg[8], fy[8], o[8];
+        Vec<half_t>::unpack(uint4{gv[j].x, gv[j].y, gv[j].z, gv[j].w}, fg);
+        Vec<half_t>::unpack(uint4{yv[j].x, yv[j].y, yv[j].z, yv[j].w}, fy);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float dz = fg[i] * silu_grad_f(fmaf(fy[i], sc[i], sh[i]));       // (host: SiLU layers only -- no per-element activation switch)
+          o[i] = fmaf(sc[i], dz, fmaf(cb[i], fy[i], cd[i]));
+        }
+        const u32x4_t ov = pack_h8(o);
+        asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ga), "v"(ov), "n"(j * RPI * 128) : "memory");
+        if (tn == 0 && (xmask[j] & 1u)) stg16(p.bdy + (unsigned)(dybase[j] + kc * 128), uint4{ov.x, ov.y, ov.z, ov.w});
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the dy slots are in LDS before the barrier lets the fragment reads go
+    };
     constexpr int G = 2 * CF;                      // MFMA groups (PF MFMAs each) per step
     auto step = [&](int buf, int nb, const bool do_issue) {
       const unsigned ax = lds0 + buf * STAGE + (wp * PW) * 128, aw = lds0 + buf * STAGE + BM * 128 + (wc * CW) * 128;
@@ -244,10 +323,11 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
 #pragma unroll
       for (int i = 0; i < LPS; ++i) piece(i, j);
     }
-    int buf = 0;
+    int buf = 0, kcur = 0;
     const int steady = p.nsteps - (NST - 1);
     for (int s = 0; s < steady; ++s) {
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPS) : "memory");
+      if (BNA) transform(buf, kcur++);
       __builtin_amdgcn_s_barrier();
       int nb = buf + NST - 1; nb = nb >= NST ? nb - NST : nb;
       step(buf, nb, true);
@@ -258,6 +338,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
       if (r == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
       else if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+      if (BNA) transform(buf, kcur++);
       __builtin_amdgcn_s_barrier();
       step(buf, 0, false);
       buf = buf + 1 == NST ? 0 : buf + 1;
@@ -286,6 +367,16 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
           }
         }
       }
+      // residual / accumulate operands of all channel groups first: one L2 round trip per pixel fragment, not one per 16-byte store
+      // (hipcc waits vmcnt(0) at the first use of each load)
+      uint4 rv[CF / 2], av[CF / 2];
+#pragma unroll
+      for (int h = 0; h < CF / 2; ++h) {
+        const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
+        const bool ok = mvalid && c0 < p.Cout;
+        if (p.res) rv[h] = ldg16(ok ? p.res + roff + c0 * 2 : zero_page());
+        if (p.accumulate) av[h] = ldg16(ok ? p.y + yoff + c0 * 2 : zero_page());
+      }
 #pragma unroll
       for (int h = 0; h < CF / 2; ++h) {
         float v[8];
@@ -302,15 +393,9 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
           for (int i = 0; i < 8; ++i) v[i] = act_f(fmaf(v[i], sBN[cl + i], sBN[BN + cl + i]), p.act);
         }
         if (mvalid && c0 < p.Cout && !(DBG && (p.dbg & 8))) {
-          if (p.res) {
-            const uint4 g = ldg16(p.res + roff + c0 * 2);
-            add_h8(v, u32x4_t{g.x, g.y, g.z, g.w});
-          }
+          if (p.res) add_h8(v, u32x4_t{rv[h].x, rv[h].y, rv[h].z, rv[h].w});
           char* yp = p.y + yoff + c0 * 2;
-          if (p.accumulate) {
-            const uint4 g = ldg16(yp);
-            add_h8(v, u32x4_t{g.x, g.y, g.z, g.w});
-          }
+          if (p.accumulate) add_h8(v, u32x4_t{av[h].x, av[h].y, av[h].z, av[h].w});
           const u32x4_t o = pack_h8(v);
           stg16(yp, uint4{o.x, o.y, o.z, o.w});
           if (BNS) {
@@ -364,15 +449,16 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   }
 }
 
-template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false, bool EPI = false>
+template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false, bool EPI = false, bool BNA = false>
 int launch(const MidK& k, int per_cu, int ntile_c, hipStream_t st) {
   constexpr int NT = 64 * WP * WC;
-  constexpr int SMEM = NST * (BM + BN) * 128 + (BNS ? 4 * BN * 4 : (EPI ? 2 * BN * 4 : 0));
+  constexpr int SMEM = NST * (BM * (BNA ? 2 : 1) + BN) * 128 + (BNS ? 4 * BN * 4 : (EPI ? 2 * BN * 4 : 0)) + (BNA ? 4 * 512 * 4 : 0);
+  static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(SMEM >= WP * 2 * BN * 4, "statistics reduction area");
   int per_xcd = (256 * per_cu / ntile_c + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
-  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS, EPI>;
+  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS, EPI, BNA>;
   MYOLO_ENSURE_DYN_SMEM(kern, SMEM);
   hipLaunchKernelGGL(kern, dim3(per_xcd * 8, ntile_c), dim3(NT), SMEM, st, k);
   MYOLO_CHECK_LAUNCH();
@@ -384,11 +470,13 @@ int launch(const MidK& k, int per_cu, int ntile_c, hipStream_t st) {
 static int g_mid_mode = -1;        // 0 off, 1 the layers conv_igemm would run, 2 every qualifying layer (ahead of halo / stream)
 static int g_mid_var = 0;          // 0 auto, 1: 128x128 (8 waves), 2: 128x64 (4 waves), 3: 64x128 (4 waves)
 static int g_mid_dbg = 0;
+static int g_mid_bna_strict = 0;   // tests: myolo_conv_dgrad_bn fails instead of running the two-launch form
 static int g_mid_min_tiles = 192;  // 128x128 tiles below this: 64-pixel tiles (twice the workgroups)
 int myolo_conv_mid_set(const char* name, int value) {
   if (!strcmp(name, "mid_mode")) { g_mid_mode = value; return 0; }
   if (!strcmp(name, "mid_var")) { g_mid_var = value; return 0; }
   if (!strcmp(name, "mid_dbg")) { g_mid_dbg = value; return 0; }
+  if (!strcmp(name, "mid_bna_strict")) { g_mid_bna_strict = value; return 0; }
   if (!strcmp(name, "mid_min_tiles")) { g_mid_min_tiles = value; return 0; }
   return MYOLO_EINVAL;
 }
@@ -399,7 +487,10 @@ int myolo_conv_mid_mode() {
 
 // -1: the layer does not qualify (caller goes on to the next kernel family), else 0 / hipError_t.  *bnb_done = 1: the BatchNorm-backward
 // sums (myolo_conv_desc.bnb) were produced in the epilogue; 0: the caller runs the reduce pass itself.
-int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
+static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf);
+int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) { return mid_launch(d, stream, bnb_done, nullptr); }
+
+static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf) {
   using namespace mid;
   *bnb_done = 0;
   {   // bisecting aid: MYOLO_MID_SKIP bits exclude call classes (1 statistics, 2 no statistics, 4 accumulate, 8 residual, 16 k x k, 32 1 x 1,
@@ -420,7 +511,18 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->up_shift != 0) return -1;
   const bool epi = d->scale || d->shift || d->act != MYOLO_ACT_NONE;
   static const int no_epi = getenv("MYOLO_MID_NO_EPI") != nullptr;
-  if (epi && (d->stats || (d->bnb && d->nbnb > 0) || no_epi)) return -1;                // (statistics are taken from the raw accumulators only)
+  if (epi && (d->stats || (d->bnb && d->nbnb > 0) || no_epi || bf)) return -1;          // (statistics are taken from the raw accumulators only)
+  if (bf) {        // BatchNorm apply in the operand path: 1x1 stride-1 dgrad over dense same-shaped gout / y / dy, <= 512 channels
+    auto same = [](const myolo_tensor& a, const myolo_tensor& b) { return a.n == b.n && a.h == b.h && a.w == b.w && a.c == b.c && a.dtype == b.dtype; };
+    // (every N tile repeats the transform of its pixel rows: beyond 256 layer channels the two-launch form is faster -- K 512 -> N 512
+    //  @16x32x16: 22.5 vs 21.4 us, -> N 1024: 38.1 vs 30.9; profiles/r4_dgrad_bn_ubench.txt)
+    static const int maxk = getenv("MYOLO_BN_APPLY_FOLD_MAXK") ? atoi(getenv("MYOLO_BN_APPLY_FOLD_MAXK")) : 256;
+    if (d->ntaps != 1 || d->stride != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stats || d->cin_pad > 512 || d->cin_pad > maxk ||
+        d->x.c != d->cin_pad) return -1;
+    if (!bf->y.ptr || !bf->dy.ptr || !same(d->x, bf->y) || !same(d->x, bf->dy) || d->x.h != d->y.h || d->x.w != d->y.w) return -1;
+    if (!bf->saved || !bf->gamma || !bf->beta || !bf->dsum || bf->act != MYOLO_ACT_SILU) return -1;
+    if ((bf->y.sw % 8) || (bf->dy.sw % 8) || ((uintptr_t)bf->y.ptr & 15) || ((uintptr_t)bf->dy.ptr & 15)) return -1;
+  }
   if (d->cin_pad % 64 || d->x.c != d->cin_pad || d->cout_pad % 64 || d->y.c % 8 || d->ntaps > 25) return -1;
   if (d->ntaps * (d->cin_pad / 64) < 2) return -1;                  // (the ring's prologue issues two K steps)
   if (d->res.ptr && (d->res.c < d->y.c)) return -1;
@@ -439,6 +541,16 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   k.stride = d->stride; k.ntaps = d->ntaps; k.kchunks = d->cin_pad / 64; k.nsteps = k.ntaps * k.kchunks;
   k.wrow_bytes = d->wtaps * d->cin_pad * 2;
   k.accumulate = d->accumulate; k.dbg = g_mid_dbg;
+  k.by = nullptr; k.bdy = nullptr; k.b_K = 0;
+  if (bf) {
+    if (extent(bf->y) >= (1ll << 31) || extent(bf->dy) >= (1ll << 31)) return -1;
+    k.by = (const char*)bf->y.ptr; k.bdy = (char*)bf->dy.ptr;
+    k.by_sn = (int)bf->y.sn * 2; k.by_sh = (int)bf->y.sh * 2; k.by_sw = (int)bf->y.sw * 2;
+    k.dy_sn = (int)bf->dy.sn * 2; k.dy_sh = (int)bf->dy.sh * 2; k.dy_sw = (int)bf->dy.sw * 2;
+    k.b_saved = bf->saved; k.b_gamma = bf->gamma; k.b_beta = bf->beta; k.b_dsum = bf->dsum; k.b_dgamma = bf->dgamma; k.b_dbeta = bf->dbeta;
+    k.b_act = bf->act; k.b_K = d->x.c; k.b_rM = 1.0f / (float)M;
+    k.dbg = 0;
+  }
   for (int t = 0; t < MYOLO_MAX_TAPS; ++t) {
     const bool in = t < d->ntaps;
     k.tap_dy[t] = in ? d->tap_dy[t] : 0; k.tap_dx[t] = in ? d->tap_dx[t] : 0;
@@ -459,6 +571,7 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   k.ntile_p = (int)((M + bm - 1) / bm);
   k.tiles_per_xcd = (k.ntile_p + 7) / 8;
   if (var == 1 && k.nsteps < 3) var = 5;               // (the four-stage ring's prologue issues three K steps)
+  if (bf) var = (var == 2 || var == 3) ? var : 5;      // (two pixel tiles per stage: three stages fill the LDS)
   hipStream_t st = (hipStream_t)stream;
   const int bn_eff = var == 2 ? 64 : 128, ntc = d->cout_pad / bn_eff;
   // the BatchNorm-backward sums of the layer(s) below ride in the epilogue when every segment is a whole number of N tiles
@@ -466,6 +579,11 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   const bool fold = d->bnb && d->nbnb > 0 && d->nbnb <= MYOLO_MAX_BNB && !d->stats && !no_fold && !k.dbg && bnb_aligned(d, bn_eff);
   k.bnb.n = 0;
   if (fold) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
+  if (bf) {
+    if (var == 5) return fold ? launch<128, 128, 4, 2, 3, false, true, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 3, false, false, false, true>(k, 1, ntc, st);
+    if (var == 2) return fold ? launch<128, 64, 2, 2, 3, false, true, false, true>(k, 1, ntc, st) : launch<128, 64, 2, 2, 3, false, false, false, true>(k, 1, ntc, st);
+    return fold ? launch<64, 128, 1, 4, 3, false, true, false, true>(k, 1, ntc, st) : launch<64, 128, 1, 4, 3, false, false, false, true>(k, 1, ntc, st);
+  }
   if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 4, true>(k, 1, ntc, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
 #define MID_GO(BM_, BN_, WP_, WC_, NST_, PCU_)                                                   \
   return fold ? launch<BM_, BN_, WP_, WC_, NST_, false, true>(k, PCU_, ntc, st)                   \
@@ -476,4 +594,27 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   if (var == 2) MID_GO(128, 64, 2, 2, 3, 2);
   MID_GO(64, 128, 1, 4, 3, 2);
 #undef MID_GO
+}
+
+// ---- 1x1 dgrad with the BatchNorm-backward apply pass in its operand path (myolo.h) ----
+extern "C" int myolo_conv_dgrad_bn(const myolo_conv_desc* d, const myolo_bn_apply_fold* f, void* stream) {
+  if (!d || !f || !d->x.ptr || !d->y.ptr || !d->w || !f->y.ptr || !f->dy.ptr) return MYOLO_EINVAL;
+  static const int off = getenv("MYOLO_BN_APPLY_FOLD") ? atoi(getenv("MYOLO_BN_APPLY_FOLD")) == 0 : 0;
+  const bool want_bnb = d->bnb != nullptr && d->nbnb > 0;
+  if (!off && d->x.dtype == MYOLO_F16 && myolo_conv_mid_mode() > 0) {
+    int done = 0;
+    const int r = mid_launch(d, stream, &done, f);
+    if (r != -1) {
+      if (r) return r;
+      return (want_bnb && !done) ? myolo_bnb_fallback(d, &d->y, stream) : 0;
+    }
+  }
+  // not foldable (fp32, more than 512 channels, strided views ...): the apply pass as its own launch, then the plain dgrad over dy
+  if (g_mid_bna_strict) return MYOLO_EINVAL;
+  myolo_tensor none{};
+  int r = myolo_bn_act_bwd_apply(&d->x, &f->y, f->saved, f->gamma, f->beta, f->act, f->dsum, f->dgamma, f->dbeta, &f->dy, &none, 0, stream);
+  if (r) return r;
+  myolo_conv_desc d2 = *d;
+  d2.x = f->dy;
+  return myolo_conv(&d2, stream);
 }

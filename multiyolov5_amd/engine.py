@@ -31,6 +31,9 @@ GRAPH_BWD = os.environ.get('MYOLO_GRAPH_BWD', 'seg')
 WGRAD_WG = int(os.environ.get('MYOLO_WGRAD_WG_HINT', '0'))                 # 0: library default (128)
 WGRAD_WG_TAIL = int(os.environ.get('MYOLO_WGRAD_WG_TAIL', '0'))
 WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
+# round 4: the BatchNorm-backward apply pass of a 1x1 stride-1 Conv+BatchNorm layer rides in the operand path of the layer's own dgrad
+# (myolo_conv_dgrad_bn, csrc/conv_mid.hip): one launch instead of two, dy still written for the weight gradient.  =0: the two-launch form
+BN_APPLY_FOLD = os.environ.get('MYOLO_BN_APPLY_FOLD', '1') != '0'
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -468,7 +471,15 @@ class ConvOp(Op):
                     calls.append(Call('myolo_bn_act_bwd_reduce', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
                                                                   L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
                 calls += sync                    # SyncBatchNorm: the sums of all ranks, before the apply pass reads them
-                if self.bn2 is not None or self.sync_world > 1:
+                self.apply_fold = None
+                if (BN_APPLY_FOLD and dt == torch.float16 and self.k == 1 and self.s == 1 and self.bn2 is None and self.sync_world == 1 and
+                        not grd.ptr and self.x.requires_grad and self.cout % 64 == 0 and self.cout <= 512 and self.out.c == self.cout):
+                    f = L.BnApplyFold()
+                    f.y, f.dy = self.yd, self.dyd
+                    f.saved, f.gamma, f.beta, f.dsum = self.saved.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), self.dsum.data_ptr()
+                    f.dgamma, f.dbeta, f.act = plan.pgrad(bn.weight).data_ptr(), plan.pgrad(bn.bias).data_ptr(), self.act
+                    self.apply_fold = f                  # (the dgrad call below carries it: no apply launch of its own)
+                elif self.bn2 is not None or self.sync_world > 1:
                     calls.append(Call('myolo_bn_act_bwd_apply_split', (
                         C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act,
                         L.ptr(self.dsum), L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd),
@@ -536,6 +547,9 @@ class ConvOp(Op):
                     self.dg.append(g)
                     if s == 2:
                         par.append(g)
+                    elif getattr(self, 'apply_fold', None) is not None:
+                        g.x = self.god                   # the gradient w.r.t. the activation output: dy is formed inside the launch
+                        calls.append(Call('myolo_conv_dgrad_bn', (C.byref(g), C.byref(self.apply_fold))))
                     else:
                         calls.append(Call('myolo_conv', (C.byref(g),)))
             if par:
@@ -1924,6 +1938,15 @@ def conv_call_bytes(call):
     return (xin + yout + w) * es
 
 
+def apply_fold_bytes(call):
+    """algorithmic bytes of the BatchNorm-backward apply pass a myolo_conv_dgrad_bn launch carries in its operand path: the layer's raw
+    conv output read + dy written (gout is the launch's own input operand, counted by conv_call_bytes) -- the unfused pass' byte count"""
+    if call.name != 'myolo_conv_dgrad_bn':
+        return 0
+    f = call.args[1]._obj
+    return _tensor_bytes(f.y) + _tensor_bytes(f.dy)
+
+
 def bnb_call_bytes(call):
     """algorithmic bytes of the BatchNorm-backward reduce passes a conv launch carries in its epilogue (myolo_conv_desc.bnb): the
     unfused pass reads the output gradient and the raw conv output of every segment once"""
@@ -1952,7 +1975,7 @@ def call_algorithmic_bytes(call):
     result written once -- conv / dgrad: input + weights + output; wgrad: x + dy + fp32 gradient; BatchNorm forward: raw + out
     (+ residual); backward reduce: gout + raw; backward apply: gout + raw + dy (+ residual gradient).  None for other launches."""
     n = call.name
-    if n in ('myolo_conv', 'myolo_conv_dgrad_s2'):
+    if n in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
         return conv_call_bytes(call)
     if n == 'myolo_conv_wgrad':
         d = call.args[0]._obj
@@ -1972,7 +1995,7 @@ def call_algorithmic_bytes(call):
 def plan_algorithmic_bytes(plan):
     """{family: bytes} over the forward + backward launch lists of a training plan"""
     out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
-    fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
+    fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_dgrad_bn': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
            'myolo_bn_act_bwd_apply': 'batchnorm', 'myolo_bn_act_fwd_split': 'batchnorm', 'myolo_bn_act_bwd_reduce_split': 'batchnorm',
            'myolo_bn_act_bwd_apply_split': 'batchnorm'}
     for op in plan.ops:
@@ -1980,6 +2003,6 @@ def plan_algorithmic_bytes(plan):
             b = call_algorithmic_bytes(c)
             if b is not None:
                 out[fam[c.name]] += b
-            if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2'):
-                out['batchnorm'] += bnb_call_bytes(c)          # (reduce passes folded into dgrad epilogues keep their unfused byte count)
+            if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
+                out['batchnorm'] += bnb_call_bytes(c) + apply_fold_bytes(c)    # (reduce / apply passes folded into dgrad launches keep their unfused byte count)
     return out

@@ -42,7 +42,7 @@ orig = E.Call.__call__
 
 
 def timed(self, st):
-    if self.name not in ('myolo_conv', 'myolo_conv_dgrad_s2'):
+    if self.name not in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
         return orig(self, st)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

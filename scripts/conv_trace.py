@@ -12,7 +12,7 @@ calls = []
 for o in h.plan.ops:
     calls += [('f', c) for c in o.fwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2')]
 for o in reversed(h.plan.ops):
-    calls += [('b', c) for c in o.bwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2')]
+    calls += [('b', c) for c in o.bwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn')]
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 sgd = [i for i, r in enumerate(rows) if 'mt_sgd' in r['Kernel_Name']]

@@ -205,3 +205,97 @@ def test_conv_mid_eval_epilogue(shape, var):
         lib.myolo_set_option(b'mid_var', 0)
         lib.myolo_set_option(b'small_off', 0)
     check(f'mid_eval/{shape}/var{var}', yd, ref, 2e-3)
+
+
+@pytest.mark.parametrize('var', [0, 2, 3])
+@pytest.mark.parametrize('case', ['k128_n128', 'k256_n256', 'k512_n256_small', 'k128_n64', 'k256_bnb', 'ragged_acc'])
+def test_conv_dgrad_with_batchnorm_apply_in_the_operand_path(case, var):
+    """myolo_conv_dgrad_bn (round 4: the BatchNorm-backward apply pass of a 1x1 Conv+BN+SiLU layer folded into its dgrad) against the two
+    launches it replaces -- myolo_bn_act_bwd_apply then myolo_conv over dy -- on the same inputs: dy identical up to fp16 rounding of
+    one fused multiply-add chain, the input gradient 2e-3, dgamma / dbeta 1e-5; with `accumulate`, with a BatchNorm-backward statistics
+    segment riding in the epilogue (bnb) and with a ragged pixel count"""
+    from multiyolov5_amd import _lib as L, engine as E
+    lib = L.lib()
+    torch.manual_seed(3)
+    K, N, n, H, W = {'k128_n128': (128, 128, 2, 32, 64), 'k256_n256': (256, 256, 2, 32, 64), 'k512_n256_small': (512, 256, 2, 16, 32),
+                     'k128_n64': (128, 64, 1, 64, 128), 'k256_bnb': (256, 128, 2, 24, 40), 'ragged_acc': (128, 128, 1, 33, 37)}[case]
+    acc = case == 'ragged_acc'
+    M = n * H * W
+
+    def td(t):
+        nn, h, w, cc = t.shape
+        return L.Tensor(t.data_ptr(), nn, h, w, cc, h * w * cc, w * cc, cc, L.F16, 0)
+    gout = (torch.randn(n, H, W, K, device=DEV) * 0.3).half()
+    y = torch.randn(n, H, W, K, device=DEV).half()
+    saved = torch.cat([torch.randn(K, device=DEV) * 0.2, torch.rand(K, device=DEV) + 0.5])
+    gam, bet = torch.rand(K, device=DEV) + 0.5, torch.randn(K, device=DEV) * 0.1
+    dsum = torch.zeros(L.STAT_COPIES * 2 * K, device=DEV)
+    L.check(lib.myolo_bn_act_bwd_reduce(C.byref(td(gout)), C.byref(td(y)), L.ptr(saved), L.ptr(gam), L.ptr(bet), L.ACT_SILU, L.ptr(dsum), L.stream_ptr()))
+    wt = torch.randn(N, K, 1, 1, device=DEV) * (1.0 / K ** 0.5)                  # the dgrad's "weights": [gx channels][dy channels]
+    wp = torch.zeros(E.rup(N, 32), 1, K, device=DEV, dtype=torch.float16)
+    L.check(lib.myolo_pack_weight(L.ptr(wt), L.F32, N, K, 1, 1, L.ptr(wp), L.F16, E.rup(N, 32), K, 0, None, L.stream_ptr()))
+    gx0 = (torch.randn(n, H, W, N, device=DEV) * 0.1).half() if acc else torch.zeros(n, H, W, N, device=DEV, dtype=torch.float16)
+    # bnb segment (the layer below): its own y / saved / sums
+    yb = torch.randn(n, H, W, N, device=DEV).half()
+    savedb = torch.cat([torch.randn(N, device=DEV) * 0.2, torch.rand(N, device=DEV) + 0.5])
+    gamb, betb = torch.rand(N, device=DEV) + 0.5, torch.randn(N, device=DEV) * 0.1
+
+    def run(fused):
+        gx = gx0.clone()
+        dy = torch.zeros_like(gout)
+        dg, db = torch.zeros(K, device=DEV), torch.zeros(K, device=DEV)
+        dsb = torch.zeros(L.STAT_COPIES * 2 * N, device=DEV)
+        d = L.ConvDesc()
+        d.x, d.y, d.w = td(gout if fused else dy), td(gx), wp.data_ptr()
+        d.cin_pad, d.cout_pad, d.wtaps, d.ntaps, d.stride, d.up_shift = K, E.rup(N, 32), 1, 1, 1, 0
+        E.fill_taps(d, [0], [0], [0])
+        d.res, d.act, d.accumulate = E.null_tensor(), L.ACT_NONE, int(acc)
+        keep = None
+        if case == 'k256_bnb':
+            bnb = (L.BnBwdSeg * 1)()
+            bnb[0].c0, bnb[0].c1, bnb[0].y = 0, N, td(yb)
+            bnb[0].saved, bnb[0].gamma, bnb[0].beta, bnb[0].dsum, bnb[0].act = savedb.data_ptr(), gamb.data_ptr(), betb.data_ptr(), dsb.data_ptr(), L.ACT_SILU
+            d.nbnb, d.bnb = 1, C.cast(bnb, C.POINTER(L.BnBwdSeg))
+            keep = bnb
+        if fused:
+            f = L.BnApplyFold()
+            f.y, f.dy = td(y), td(dy)
+            f.saved, f.gamma, f.beta, f.dsum, f.dgamma, f.dbeta, f.act = saved.data_ptr(), gam.data_ptr(), bet.data_ptr(), dsum.data_ptr(), \
+                dg.data_ptr(), db.data_ptr(), L.ACT_SILU
+            lib.myolo_set_option(b'mid_var', var)
+            lib.myolo_set_option(b'mid_bna_strict', int(K <= 256))   # (the one-launch form must really run: no silent two-launch fallback;
+                                                                    #  beyond 256 channels the library itself prefers the two launches)
+            try:
+                L.check(lib.myolo_conv_dgrad_bn(C.byref(d), C.byref(f), L.stream_ptr()), 'myolo_conv_dgrad_bn')
+            finally:
+                lib.myolo_set_option(b'mid_var', 0)
+                lib.myolo_set_option(b'mid_bna_strict', 0)
+        else:
+            L.check(lib.myolo_bn_act_bwd_apply(C.byref(td(gout)), C.byref(td(y)), L.ptr(saved), L.ptr(gam), L.ptr(bet), L.ACT_SILU, L.ptr(dsum),
+                                               L.ptr(dg), L.ptr(db), C.byref(td(dy)), C.byref(E.null_tensor()), 0, L.stream_ptr()))
+            L.check(lib.myolo_conv(C.byref(d), L.stream_ptr()), 'myolo_conv')
+        torch.cuda.synchronize()
+        return gx, dy, dg, db, dsb.view(L.STAT_COPIES, 2, N).sum(0)
+    gx_f, dy_f, dg_f, db_f, sb_f = run(True)
+    gx_r, dy_r, dg_r, db_r, sb_r = run(False)
+    bad = []
+    check(f'dgrad_bn/{case}/var{var}/dy', dy_f, dy_r, 1e-3, collect=bad)
+    check(f'dgrad_bn/{case}/var{var}/gx', gx_f, gx_r, 2e-3, collect=bad)
+    check(f'dgrad_bn/{case}/var{var}/dgamma', dg_f, dg_r, 1e-5, collect=bad)
+    check(f'dgrad_bn/{case}/var{var}/dbeta', db_f, db_r, 1e-5, collect=bad)
+    if case == 'k256_bnb':
+        check(f'dgrad_bn/{case}/var{var}/bnb_sums', sb_f, sb_r, 1e-3, collect=bad)
+    # and against first principles (fp32 on the CPU): dy = gamma*istd*(dz - mean(dz) - xhat*mean(dz*xhat))
+    g32, y32 = gout.float().cpu(), y.float().cpu()
+    mean, istd = saved[:K].cpu(), saved[K:].cpu()
+    xh = (y32 - mean) * istd
+    z = xh * gam.cpu() + bet.cpu()
+    sg = torch.sigmoid(z)
+    dz = g32 * (sg * (1 + z * (1 - sg)))
+    ref_dy = gam.cpu() * istd * (dz - dz.reshape(-1, K).mean(0) - xh * (dz * xh).reshape(-1, K).mean(0))
+    check(f'dgrad_bn/{case}/var{var}/dy_vs_fp32', dy_f, ref_dy, 2e-3, collect=bad)
+    ref_gx = ref_dy.half().float().reshape(M, K) @ wp[:N, 0].float().cpu().t()
+    if acc:
+        ref_gx = ref_gx + gx0.float().cpu().reshape(M, N)
+    check(f'dgrad_bn/{case}/var{var}/gx_vs_fp32', gx_f.reshape(M, N), ref_gx, 3e-3, collect=bad)
+    assert not bad, '\n'.join(bad)
