@@ -662,6 +662,22 @@ class PlannedModule(nn.Module):
     def _sig(self):
         return tuple(t.data_ptr() for t in self._tensors())
 
+    # Re-allocation of parameters / buffers happens through nn.Module._apply (.to / .half / .float / .cuda) or load_state_dict(assign=True):
+    # every PlannedModule bumps ONE process-wide epoch there, and a forward re-reads the ~170-350 data pointers only when the epoch moved
+    # since its plan last checked them (round 4: 16 us of host time per detect.py frame, profiles/r3k_infer_timeline.md).  A `.half()`
+    # called directly on a LEAF nn.Conv2d / nn.BatchNorm2d inside the model is not seen (like replacing a Parameter object): invalidate_plans().
+    _EPOCH = [0]
+
+    def _apply(self, fn, *args, **kwargs):
+        r = super()._apply(fn, *args, **kwargs)
+        PlannedModule._EPOCH[0] += 1
+        return r
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        PlannedModule._EPOCH[0] += 1
+        return r
+
     def _holder(self, tensors, spec):
         for t in tensors:
             L.require_gpu(t)
@@ -671,7 +687,13 @@ class PlannedModule(nn.Module):
                str(spec), dtype, bool(self.training), grad, self._sync_world())
         plans = self.__dict__.setdefault('_plans', {})
         h = plans.get(key)
-        sig = self._sig()
+        epoch = PlannedModule._EPOCH[0]
+        if h is not None and h.__dict__.get('_sig_epoch') == epoch:
+            sig = h.sig                                  # nothing re-allocated since this plan compared the pointers
+        else:
+            sig = self._sig()
+            if h is not None:
+                h.__dict__['_sig_epoch'] = epoch
         if h is None or h.sig != sig:
             # module.training decides BatchNorm batch statistics (and builds the backward launch list);
             # `grad` only decides whether autograd is wired through PlanFn
@@ -679,6 +701,7 @@ class PlannedModule(nn.Module):
             sig = self._sig()
             h = PlanHolder(self, tensors, spec, dtype, bool(self.training))
             h.sig = sig
+            h.__dict__['_sig_epoch'] = epoch
             plans[key] = h
             self.__dict__['_prepared_version'] = self._param_version()
         elif not self.training:

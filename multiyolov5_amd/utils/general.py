@@ -46,6 +46,9 @@ import ctypes as _C
 from .. import _lib as _L
 
 
+_NMS_SCRATCH = {}
+
+
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
                         labels=()):
     """general.py:421-509: list (one per image) of [n,6] tensors (x1, y1, x2, y2, conf, cls), descending conf, n <= 300.
@@ -73,26 +76,45 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     multi = bool(multi_label and nc > 1)                          # general.py:438
     cap = A * nc if multi else A
     dev = pred.device
-    counts = torch.empty(B, dtype=torch.int32, device=dev)
-    cand = torch.empty(B * cap * 6, dtype=torch.float32, device=dev)
-    cidx = torch.empty(B * cap, dtype=torch.int32, device=dev)
-    srt = torch.empty(B * max_nms * 6, dtype=torch.float32, device=dev)
+    # scratch of the launch sequence: reused across calls with the same geometry on the same stream (stream order makes the reuse safe;
+    # eight torch.empty per frame were ~25 us of host time on the detect.py path).  `out` -- the rows the caller keeps -- is fresh.
+    use_ws = bool(multi or conf_thres < 0.05)
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, A, no, multi, use_ws)
+    sc = _NMS_SCRATCH.get(key)
+    if sc is None:
+        if len(_NMS_SCRATCH) > 16:
+            _NMS_SCRATCH.clear()
+        sc = {'counts': torch.empty(B, dtype=torch.int32, device=dev), 'cand': torch.empty(B * cap * 6, dtype=torch.float32, device=dev),
+              'cidx': torch.empty(B * cap, dtype=torch.int32, device=dev), 'srt': torch.empty(B * max_nms * 6, dtype=torch.float32, device=dev),
+              'nkeep': torch.empty(B, dtype=torch.int32, device=dev), 'host': torch.empty(B, dtype=torch.int32).pin_memory(),
+              'ev': torch.cuda.Event(),
+              # long candidate lists (test.py: conf 0.001 + multi_label, 1e5 per image): counting sort instead of the O(n^2) rank kernel
+              'ws': torch.empty(B * (3 * 65536 + cap), dtype=torch.int32, device=dev) if use_ws else None, 'mws': None, 'mws_bytes': 0}
+        # short single-label lists (detect.py): rank / bit matrix on the whole device + a one-wave scan (csrc/nms.hip); 9 MB per image
+        if sc['ws'] is None and B <= 64:
+            sc['mws_bytes'] = int(_L.lib().myolo_nms_ws_bytes(B, cap))
+            sc['mws'] = torch.empty(sc['mws_bytes'], dtype=torch.uint8, device=dev)
+        _NMS_SCRATCH[key] = sc
+    counts, cand, cidx, srt, nkeep, ws, mws, mws_bytes = (sc[k] for k in ('counts', 'cand', 'cidx', 'srt', 'nkeep', 'ws', 'mws', 'mws_bytes'))
     out = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
-    nkeep = torch.empty(B, dtype=torch.int32, device=dev)
-    # long candidate lists (test.py: conf 0.001 + multi_label, 1e5 per image): counting sort instead of the O(n^2) rank kernel
-    ws = torch.empty(B * (3 * 65536 + cap), dtype=torch.int32, device=dev) if (multi or conf_thres < 0.05) else None
-    # short single-label lists (detect.py): rank / bit matrix on the whole device + a one-wave scan (csrc/nms.hip); 9 MB per image
-    mws, mws_bytes = None, 0
-    if ws is None and B <= 64:
-        mws_bytes = int(_L.lib().myolo_nms_ws_bytes(B, cap))
-        mws = torch.empty(mws_bytes, dtype=torch.uint8, device=dev)
     _L.check(_L.lib().myolo_nms(_L.ptr(pred), _L.DT[pred.dtype], B, A, no, _C.c_float(conf_thres), _C.c_float(iou_thres),
                                 int(multi), int(bool(agnostic)), _C.c_float(max_wh), max_nms, max_det, cap, _L.ptr(counts),
                                 _L.ptr(cand), _L.ptr(cidx), _L.ptr(srt), _L.ptr(out), _L.ptr(nkeep), class_mask,
                                 _L.ptr(ws) if ws is not None else None, _L.ptr(mws) if mws is not None else None, mws_bytes,
                                 _L.stream_ptr()),
              'myolo_nms')
-    n = nkeep.tolist()                                            # the one sync (the reference syncs per image, 446-495)
+    # the one sync (the reference syncs per image, 446-495): the keep counts through pinned memory, the host POLLS the event instead of
+    # sleeping in a blocking copy (the interrupt wake-up was ~40 us per frame, profiles/r3k_infer_timeline.md)
+    host, ev = sc['host'], sc['ev']
+    host.copy_(nkeep, non_blocking=True)
+    ev.record()
+    spins = 0
+    while not ev.query():
+        spins += 1
+        if spins > 200000:                                        # (a long-running queue in front: stop burning the core)
+            ev.synchronize()
+            break
+    n = host.tolist()
     return [out[i, :n[i]] for i in range(B)]
 
 

@@ -104,6 +104,7 @@ class FusedSGD(torch.optim.Optimizer):
                     'myolo_mt_check_finite')
         L.check(lib.myolo_mt_sgd(L.ptr(t.table), L.ptr(t.chunks), t.nchunks, CHUNK, C.byref(hy), L.ptr(scale), L.ptr(found_inf),
                                  st), 'myolo_mt_sgd')
+        _bump_version(ps[0])                                 # (raw-pointer update: see ema_update)
         return None
 
 
@@ -163,6 +164,13 @@ _EMA_TABLES = {}
 
 
 @torch.no_grad()
+def _bump_version(t):
+    try:
+        torch.autograd.graph.increment_version(t)
+    except AttributeError:                                   # (older torch)
+        t.add_(0)
+
+
 def ema_update(pairs, d, model_sd=None):
     """v = d*v + (1-d)*m for every (ema tensor, model tensor) pair (floating state_dict entries, buffers included), one
     launch.  `pairs` may also be the EMA state_dict with `model_sd` the model's (torch_utils.py:296-300 call shape)."""
@@ -183,3 +191,7 @@ def ema_update(pairs, d, model_sd=None):
     tab.update(ptrs, numels, [0] * len(ptrs))
     L.check(L.lib().myolo_mt_ema(L.ptr(tab.table), L.ptr(tab.chunks), tab.nchunks, CHUNK, C.c_float(d), L.stream_ptr()),
             'myolo_mt_ema')
+    # the kernel wrote through raw pointers: tell autograd's version counters (an eval plan of the EMA model -- test.py runs ema.ema
+    # every epoch -- re-derives its packed weights / folded BatchNorm constants when the parameter versions move; one bump is enough
+    # for runtime.PlannedModule._param_version, which sums them)
+    _bump_version(pairs[0][0])

@@ -100,3 +100,49 @@ def test_model_ema_matches_reference_formula():
             check(f'ema/{k}', v, ref[k], 1e-6)
         else:
             assert int(v) == int(ref[k])                      # integer buffers are not averaged (torch_utils.py:297)
+
+
+def test_eval_plan_follows_fused_ema_and_sgd_updates():
+    """train.py evaluates ema.ema with test.py after every epoch: the multi-tensor EMA / SGD kernels write the parameters through raw
+    pointers, so they must move autograd's version counters themselves -- an eval plan built in epoch 1 re-derives its packed weights and
+    folded BatchNorm constants in epoch 2 (round 4: it did not, the second evaluation ran on the first epoch's weights)"""
+    import os
+    from multiyolov5_amd.models.yolo import Model
+    from multiyolov5_amd.utils.optim import FusedSGD
+    from multiyolov5_amd.utils.torch_utils import ModelEMA
+    from tests.util import CFG, TAGS, synth_sd
+    m = Model(os.path.join(CFG, TAGS['s_psp']))
+    m.load_state_dict(synth_sd('s_psp'), strict=True)
+    m = m.to(DEV)
+    ema = ModelEMA(m)
+    x = torch.rand(1, 3, 64, 128, device=DEV)
+    with torch.no_grad():
+        (p0, _), s0 = ema.ema(x)
+        p0, s0 = p0.clone(), s0.clone()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.5)                                      # "training" moved the weights
+    ema.updates = 100000                                     # decay ~ 0.9999: force a visible step instead
+    ema.decay = lambda n: 0.5
+    ema.update(m)
+    with torch.no_grad():
+        (p1, _), s1 = ema.ema(x)
+    ref = ModelEMA(m)                                        # the same EMA weights in a fresh module (fresh plan)
+    ref.ema.load_state_dict(ema.ema.state_dict())
+    with torch.no_grad():
+        (pr, _), sr = ref.ema(x)
+    assert float((s1 - s0).abs().max()) > 1e-3, 'the EMA step changed the outputs of the evaluated model'
+    torch.testing.assert_close(s1, sr, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(p1, pr, rtol=1e-5, atol=1e-5)
+    # FusedSGD: an eval forward of the trained model itself after a step
+    m.eval()
+    with torch.no_grad():
+        _, a0 = m(x)
+        a0 = a0.clone()
+    opt = FusedSGD(m.parameters(), lr=0.5, momentum=0.0, nesterov=False)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p) * 1e-2
+    opt.step()
+    with torch.no_grad():
+        _, a1 = m(x)
+    assert float((a1 - a0).abs().max()) > 1e-4, 'the optimizer step is visible to the eval plan'
