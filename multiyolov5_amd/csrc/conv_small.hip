@@ -198,7 +198,7 @@ int myolo_conv_small_set(const char* name, int value) {
 int myolo_conv_small_try(const myolo_conv_desc* d, void* stream) {
   using namespace small;
   if (g_small_off < 0) g_small_off = getenv("MYOLO_NO_SMALL") != nullptr;
-  if (g_small_max_tiles < 0) g_small_max_tiles = getenv("MYOLO_SMALL_MAX_TILES") ? atoi(getenv("MYOLO_SMALL_MAX_TILES")) : 256;
+  if (g_small_max_tiles < 0) g_small_max_tiles = getenv("MYOLO_SMALL_MAX_TILES") ? atoi(getenv("MYOLO_SMALL_MAX_TILES")) : 128;   // (round 4: 256 -> 128, conv_mid takes the layers in between: 912 -> 955 FPS at 2048x1024, 1325 -> 1406 at 1024x512)
   if (g_small_raw < 0) g_small_raw = getenv("MYOLO_SMALL_RAW") ? atoi(getenv("MYOLO_SMALL_RAW")) : 0;
   if (g_small_off) return -1;
   if (!g_small_raw && !g_small_force && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE) return -1;
