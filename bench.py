@@ -291,7 +291,7 @@ def conv_kernel_timing(trainer, nsteps=3):
     return tot_b, tot_f, tot_t, len(rec) // nsteps
 
 
-def infer_report(args, dev, frames=60, warm=8, H=1024, W=2048, cpu=False):
+def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
     """detect.py path (detect.py:144-193): fused eval forward at 1x3xHxW fp16 (hipGraph replay) + NMS + seg upsample/argmax.
     Returns the FPS of the whole frame loop (wall clock, the per-frame host sync of NMS included), the per-stage split measured with
     HIP events on the launch stream, whether the forward really was a graph replay, and the frame's HBM roofline (SURVEY 8(d):

@@ -5,7 +5,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 import bench
 class A: pass
-a = A(); a.batch = 16; a.img = (512, 1024); a.cfg = sys.argv[1] if len(sys.argv) > 1 else 'yolov5s_city_seg.yaml'; a.dtype = 'f16'; a.stage = 'train'
+a = A(); a.batch = 16; a.img = (512, 1024); a.cfg = sys.argv[1] if len(sys.argv) > 1 else 'yolov5s_city_seg.yaml'; a.dtype = 'f16'; a.stage = 'train'; a.sync_bn = False; a.ddp = 'reducer'
 dev = torch.device('cuda', 0)
 tr = bench.Trainer(a, 1, 0, dev)
 for _ in range(5):
