@@ -7,8 +7,8 @@
 //
 //   This kernel:
 //     * 128-byte K steps (64 halves) staged with LDS-DMA (`global_load_lds_dwordx4`: no staging registers, no ds_write pass) into a
-//       3-stage ring; the loads of step s+2 are issued before the MFMAs of step s, waits are COUNTED (`s_waitcnt vmcnt(L)`: the next
-//       stage stays in flight across the barrier), one raw `s_barrier` per step;
+//       3- or 4-stage ring; the loads of step s+2 / s+3 are issued between the MFMA groups of step s, waits are COUNTED (`s_waitcnt
+//       vmcnt(L)`: the younger stages stay in flight across the barrier), one raw `s_barrier` per step;
 //     * 8 waves per 128 x 128 tile (two per SIMD: one wave's LDS reads sit under the other's MFMAs), 16 MFMAs per wave and step;
 //     * the per-row addresses (pixel base offset, a bit mask of the taps that fall inside the image) are computed once per tile; a
 //       K step costs two scalar table reads, one select and one add per load;
@@ -19,7 +19,9 @@
 //       16-byte NHWC stores straight from the accumulators, BatchNorm statistics reduced over the 16 pixel lanes by shuffles.
 //
 // Replaces: nn.Conv2d in training mode (reference models/common.py:34-46: the conv of Conv / Bottleneck / C3 / SPP / PSP head) and its
-// autograd dgrad.  Epilogues: raw store (+ statistics) (+ residual) (+ accumulate).  Everything else stays on conv_igemm.
+// autograd dgrad.  Epilogues: raw store (+ statistics) (+ residual) (+ accumulate); BNS: + the BatchNorm-backward sums of the layer below
+// (myolo_conv_desc.bnb); EPI: folded BatchNorm scale / shift + activation (eval, common.py:45-46); BNA: myolo_conv_dgrad_bn -- the layer's own
+// BatchNorm-backward apply pass in the operand path of its 1x1 dgrad.  fp32, Detect's permuted output and odd channel counts stay on conv_igemm.
 #include "myolo_dev.h"
 #include <string.h>
 #include <stdlib.h>
@@ -317,12 +319,14 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     // ring of NST stages: the loads of step s + NST-1 are issued during the MFMAs of step s.  A wait leaves the younger stages in
     // flight; the barrier behind it says that everybody's loads of stage s have landed AND that every wave is done reading the buffer of
     // step s-1, which this step's loads overwrite.  (nsteps >= NST-1: host)
+    const int inflight = p.nsteps < NST - 1 ? p.nsteps : NST - 1;      // stages the prologue issues (short K loops: fewer than the ring holds)
 #pragma unroll
-    for (int j = 0; j < NST - 1; ++j) {
-      addresses();
+    for (int j = 0; j < NST - 1; ++j)
+      if (j < inflight) {
+        addresses();
 #pragma unroll
-      for (int i = 0; i < LPS; ++i) piece(i, j);
-    }
+        for (int i = 0; i < LPS; ++i) piece(i, j);
+      }
     int buf = 0, kcur = 0;
     const int steady = p.nsteps - (NST - 1);
     for (int s = 0; s < steady; ++s) {
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     }
 #pragma unroll
     for (int r = NST - 2; r >= 0; --r) {           // drain: no more issues, r stages stay in flight
+      if (r >= inflight) continue;                 // (uniform: a K loop shorter than the ring)
       if (r == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
       else if (r == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
@@ -524,10 +529,12 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
     if ((bf->y.sw % 8) || (bf->dy.sw % 8) || ((uintptr_t)bf->y.ptr & 15) || ((uintptr_t)bf->dy.ptr & 15)) return -1;
   }
   if (d->cin_pad % 64 || d->x.c != d->cin_pad || d->cout_pad % 64 || d->y.c % 8 || d->ntaps > 25) return -1;
-  if (d->ntaps * (d->cin_pad / 64) < 2) return -1;                  // (the ring's prologue issues two K steps)
   if (d->res.ptr && (d->res.c < d->y.c)) return -1;
   const int64_t M = (int64_t)d->y.n * d->y.h * d->y.w;
   if (M < 1024 || M > (1 << 24)) return -1;
+  // one-step K loops (1x1, 64 channels) are pure streaming: on the 128x256 maps the streaming kernel wins (39.3 vs 43.6 us at batch 16), on
+  // the 64x128 maps this one (18.2 -> 13.7)
+  if (d->ntaps * (d->cin_pad / 64) < 2 && M > 300000) return -1;
   auto extent = [](const myolo_tensor& t) { return ((int64_t)t.n * t.sn + (int64_t)t.h * t.sh + (int64_t)t.w * t.sw + t.c) * 2; };
   if (extent(d->x) >= (1ll << 31) || extent(d->y) >= (1ll << 31) || (d->res.ptr && extent(d->res) >= (1ll << 31))) return -1;
   if ((int64_t)d->cout_pad * d->wtaps * d->cin_pad * 2 >= (1ll << 31)) return -1;
@@ -570,7 +577,7 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   const int bm = var == 3 ? 64 : (var == 4 ? 256 : 128);
   k.ntile_p = (int)((M + bm - 1) / bm);
   k.tiles_per_xcd = (k.ntile_p + 7) / 8;
-  if (var == 1 && k.nsteps < 3) var = 5;               // (the four-stage ring's prologue issues three K steps)
+  if (var == 1 && k.nsteps < 3) var = 5;               // (short K loops: the three-stage ring)
   if (bf) var = (var == 2 || var == 3) ? var : 5;      // (two pixel tiles per stage: three stages fill the LDS)
   hipStream_t st = (hipStream_t)stream;
   const int bn_eff = var == 2 ? 64 : 128, ntc = d->cout_pad / bn_eff;

@@ -78,6 +78,8 @@ SHAPES = [
     (64, 64, 5, 1, 1, 1, 32, 48),            # RFB1's 5x5: 25 taps, ragged pixel count (1536 = 12 tiles)
     (128, 192, 1, 1, 1, 1, 31, 37),          # ragged: M = 1147, cout 192 (64-wide tiles)
     (512, 512, 1, 1, 1, 2, 16, 32),          # 8 K steps
+    (64, 64, 1, 1, 1, 2, 64, 128),           # ONE K step: prologue + drain of a ring that is longer than the loop
+    (64, 128, 1, 1, 1, 1, 40, 56),
 ]
 
 
