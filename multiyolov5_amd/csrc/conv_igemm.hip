@@ -442,7 +442,8 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
     int r = myolo_conv_small_try(d, stream);          // small maps, eval epilogue: split-K over the waves, operands straight from L2 (conv_small.hip)
     if (r != -1) return r;
     const int mid = myolo_conv_mid_mode();
-    r = mid >= 2 ? myolo_conv_mid_try(d, stream, &done) : -1;         // (experiments: ahead of the halo / streaming kernels)
+    r = myolo_conv_midx_try(d, stream);                               // k x k stride-1 training layers: input halo resident in LDS, weights streamed (conv_midx.hip; MYOLO_CONV_MIDX)
+    if (r == -1) r = mid >= 2 ? myolo_conv_mid_try(d, stream, &done) : -1;         // (mode 2: ahead of the halo / streaming kernels)
     if (r == -1) r = myolo_conv_halo_try(d, stream, &done);    // k x k stride-1 layers: input halo tiles staged in LDS (conv_halo.hip)
     if (r == -1) r = myolo_conv_stream_try(d, stream, &done);      // HBM-bound 1x1 / strided layers: the streaming kernel (conv_stream.hip)
     if (r == -1 && mid == 1) {                                      // mid-size / small training maps: LDS-DMA staged 8-wave tiles (conv_mid.hip)

@@ -247,6 +247,9 @@ int myolo_conv_small_set(const char* name, int value);
 int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 int myolo_conv_mid_set(const char* name, int value);
 int myolo_conv_mid_mode();
+// conv_midx.hip: conv_mid with the input of a k x k stride-1 layer resident in LDS as a halo tile; -1 = layer does not qualify
+int myolo_conv_midx_try(const myolo_conv_desc* d, void* stream);
+int myolo_conv_midx_set(const char* name, int value);
 // conv_wgrad_tile.hip: weight gradient over LDS-staged spatial tiles; -1 = layer does not qualify
 int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, int* out_cop, int* out_cip, int* used_ws);
 int myolo_wgrad_tile_set(const char* name, int value);

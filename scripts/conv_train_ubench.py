@@ -93,12 +93,27 @@ if os.environ.get('PROBE') == 'mid':
         ideal = max(byt / 8e12, fl / 2.5e15) * 1e6
         row = []
         for name, opts in V:
-            for kk, vv in {'mid_mode': 1, 'mid_var': 0, **opts}.items():
+            for kk, vv in {'mid_mode': 1, 'mid_var': 0, 'midx_mode': 0, **opts}.items():
                 lib.myolo_set_option(kk.encode(), vv)
             row.append(f'{name} {run(*shp):.1f}/{run(*shp, stats_on=False):.1f}')
-        for kk, vv in {'mid_mode': 1, 'mid_var': 0}.items():
+        for kk, vv in {'mid_mode': 2, 'mid_var': 0, 'midx_mode': 1}.items():
             lib.myolo_set_option(kk.encode(), vv)
         print(f'{str(shp):34s} roofline {ideal:5.1f} us | ' + ' | '.join(row), '(us with stats / without)', flush=True)
+    sys.exit(0)
+if os.environ.get('PROBE') == 'midx':
+    # conv_midx (input halo resident in LDS, weights streamed) against conv_mid on the k x k stride-1 layers
+    P = [(64, 64, 3, 1, 1, 64, 128), (128, 128, 3, 1, 1, 32, 64), (256, 256, 3, 1, 1, 16, 32), (256, 128, 3, 1, 1, 64, 128), (128, 256, 3, 1, 1, 64, 128),
+         (64, 64, 3, 1, 2, 64, 128), (64, 64, 3, 1, 3, 64, 128)]
+    V = [('mid', {'midx_mode': 0}), ('midx', {'midx_mode': 1}), ('x1', {'midx_mode': 1, 'midx_var': 1}), ('x2', {'midx_mode': 1, 'midx_var': 2}), ('x3', {'midx_mode': 1, 'midx_var': 3})]
+    for shp in P:
+        row = []
+        for name, opts in V:
+            for kk, vv in {'midx_mode': 0, 'midx_var': 0, **opts}.items():
+                lib.myolo_set_option(kk.encode(), vv)
+            row.append(f'{name} {run(*shp):.1f}/{run(*shp, stats_on=False):.1f}')
+        for kk, vv in {'midx_mode': 1, 'midx_var': 0}.items():
+            lib.myolo_set_option(kk.encode(), vv)
+        print(f'{str(shp):34s} ' + ' | '.join(row), '(us with stats / without)', flush=True)
     sys.exit(0)
 if os.environ.get('PROBE') == 'mid_dbg':
     # where conv_mid's time goes: dbg bits 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores; tile variants

@@ -20,7 +20,7 @@ def _tdesc(L, t, c=None):
     return L.Tensor(t.data_ptr(), n, h, w, cc if c is None else c, sn, sh, sw, L.F16, 0)
 
 
-def _run(cin, cout, k, s, d, B, H, W, var, stats=True, accumulate=False, res=False, mode=2, seed=0):
+def _run(cin, cout, k, s, d, B, H, W, var, stats=True, accumulate=False, res=False, mode=2, seed=0, midx=0):
     from multiyolov5_amd import _lib as L, engine as E
     lib = L.lib()
     g = torch.Generator().manual_seed(seed)
@@ -49,14 +49,16 @@ def _run(cin, cout, k, s, d, B, H, W, var, stats=True, accumulate=False, res=Fal
     dd.act, dd.stats, dd.accumulate = L.ACT_NONE, (st.data_ptr() if stats else None), int(accumulate)
     lib.myolo_set_option(b'mid_mode', mode)
     lib.myolo_set_option(b'mid_var', var)
+    lib.myolo_set_option(b'midx_mode', midx)               # (conv_midx is consulted first: off unless the test is about it)
     try:
         L.check(lib.myolo_conv(C.byref(dd), L.stream_ptr()))
         torch.cuda.synchronize()
     finally:
         lib.myolo_set_option(b'mid_mode', 2)
         lib.myolo_set_option(b'mid_var', 0)
+        lib.myolo_set_option(b'midx_mode', 1)
     bad = []
-    tag = f'mid/{cin}->{cout} k{k}s{s}d{d} {B}x{H}x{W} var{var}'
+    tag = f'mid{"x" if midx else ""}/{cin}->{cout} k{k}s{s}d{d} {B}x{H}x{W} var{var}'
     check(tag + '/y', yd, ref, 2e-3, collect=bad)
     if stats:
         ss = st.view(L.STAT_COPIES, 2, cout).sum(0).cpu()
@@ -149,11 +151,13 @@ def test_conv_mid_bn_backward_sums_in_the_epilogue(case, var):
     d.nbnb, d.bnb = len(segs), C.cast(bnb, C.POINTER(L.BnBwdSeg))
     lib.myolo_set_option(b'mid_mode', 2)
     lib.myolo_set_option(b'mid_var', var)
+    lib.myolo_set_option(b'midx_mode', 0)
     try:
         L.check(lib.myolo_conv(C.byref(d), L.stream_ptr()), 'myolo_conv')
         torch.cuda.synchronize()
     finally:
         lib.myolo_set_option(b'mid_var', 0)
+        lib.myolo_set_option(b'midx_mode', 1)
     for i, (c0, c1) in enumerate(segs):
         ref = torch.zeros_like(dsum[i])
         gd, yd = td(gx, c0, c1 - c0), td(yraw[i])
@@ -301,3 +305,33 @@ def test_conv_dgrad_with_batchnorm_apply_in_the_operand_path(case, var):
         ref_gx = ref_gx + gx0.float().cpu().reshape(M, N)
     check(f'dgrad_bn/{case}/var{var}/gx_vs_fp32', gx_f.reshape(M, N), ref_gx, 3e-3, collect=bad)
     assert not bad, '\n'.join(bad)
+
+
+XSHAPES = [
+    # cin, cout, k, s, d, B, H, W
+    (64, 64, 3, 1, 1, 2, 64, 128),           # 4.m.0.cv2 (128-byte pixels)
+    (128, 128, 3, 1, 1, 2, 32, 64),          # 6.m.0.cv2 (256-byte pixels)
+    (256, 256, 3, 1, 1, 8, 16, 32),          # 9.m.0.cv2 (512-byte pixels)
+    (256, 128, 3, 1, 1, 1, 64, 128),         # PSP head 3x3
+    (64, 64, 3, 1, 2, 2, 32, 64),            # dilation 2
+    (64, 64, 3, 1, 3, 2, 32, 64),            # dilation 3
+    (64, 64, 5, 1, 1, 1, 40, 72),            # 5x5: 25 taps, ragged tiles (40 = 5 x 8 rows, 72 = 4.5 x 16 columns)
+    (128, 192, 3, 1, 1, 1, 37, 53),          # ragged in both directions, 64-wide tiles
+]
+
+
+@pytest.mark.parametrize('var', [0, 1, 2, 3])
+@pytest.mark.parametrize('shape', XSHAPES, ids=[f'{s[0]}-{s[1]}k{s[2]}d{s[4]}_{s[5]}x{s[6]}x{s[7]}' for s in XSHAPES])
+def test_conv_midx_halo_resident_input(shape, var):
+    """conv_midx.hip (the input halo of a k x k stride-1 layer resident in LDS, weights streamed) through myolo_conv against torch fp32:
+    forward with BatchNorm statistics and the dgrad epilogues (accumulate + residual)"""
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    lib.myolo_set_option(b'midx_var', var if var else 0)
+    if var == 0:
+        lib.myolo_set_option(b'midx_var', 0)
+    try:
+        _run(*shape, var=0, midx=1)
+        _run(*shape, var=0, stats=False, accumulate=True, res=True, seed=3, midx=1)
+    finally:
+        lib.myolo_set_option(b'midx_var', 0)
