@@ -41,9 +41,12 @@ __device__ __forceinline__ float row_sum16(float v) {
 }
 
 // TH x 16 output pixels x BN channels per tile, WP x WC waves, NST weight stages
-template <int TH, int BN, int WP, int WC, int NST>
+// (measured and dropped: the WHOLE weight tile of 3x3 64 -> 64 resident in LDS, K loop without loads, waits or barriers: 24.1 us with 8 waves,
+//  31.9 with 4 -- one workgroup per CU -- against 20.4 us for three 47 KB workgroups per CU streaming their weights)
+// TW = 16 or 32 output columns per tile row
+template <int TH, int BN, int WP, int WC, int NST, int TW = 16>
 __global__ __launch_bounds__(64 * WP * WC) void conv_midx_kernel(const MidX p) {
-  constexpr int BM = TH * 16;
+  constexpr int BM = TH * TW, FPR = TW / 16;      // fragments per tile row
   constexpr int NT = 64 * WP * WC, NW = WP * WC;
   constexpr int PW = BM / WP, CW = BN / WC;
   constexpr int PF = PW / 16, CF = CW / 16;       // a wave owns PF tile rows (16 pixels each) x CF channel fragments
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_midx_kernel(const MidX p) {
     if (tile >= p.ntiles) break;
     const int txy = p.tiles_x * p.tiles_y;
     const int n = tile / txy; const int trem = tile - n * txy;
-    const int ty0 = (trem / p.tiles_x) * TH, tx0 = (trem - (trem / p.tiles_x) * p.tiles_x) * 16;
+    const int ty0 = (trem / p.tiles_x) * TH, tx0 = (trem - (trem / p.tiles_x) * p.tiles_x) * TW;
 
     // ---- halo fill: every wave takes pieces wave, wave + NW, ... ----
     for (int pi = wave; pi < p.npieces; pi += NW) {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_midx_kernel(const MidX p) {
       for (int q = 0; q < PF; ++q) acc[c][q] = f4_t{0.f, 0.f, 0.f, 0.f};
     int hbase[PF];                                  // halo pixel of this lane's output pixel at tap offset 0
 #pragma unroll
-    for (int q = 0; q < PF; ++q) hbase[q] = (wp * PF + q) * p.HW + l15;
+    for (int q = 0; q < PF; ++q) hbase[q] = ((wp * PF + q) / FPR) * p.HW + ((wp * PF + q) % FPR) * 16 + l15;
 
     int i_tap = 0, i_kc = 0;
     int n_wt = p.tap_woff[0];
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_midx_kernel(const MidX p) {
     // ---- epilogue ----
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
-      const int oy = ty0 + wp * PF + q, ox = tx0 + l15;
+      const int oy = ty0 + (wp * PF + q) / FPR, ox = tx0 + ((wp * PF + q) % FPR) * 16 + l15;
       const bool mvalid = oy < p.Ho && ox < p.Wo;
       const unsigned yoff = (unsigned)(n * p.y_sn + oy * p.y_sh + ox * p.y_sw);
       const unsigned roff = (unsigned)(n * p.r_sn + oy * p.r_sh + ox * p.r_sw);
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_midx_kernel(const MidX p) {
   }
 }
 
-template <int TH, int BN, int WP, int WC, int NST>
+template <int TH, int BN, int WP, int WC, int NST, int TW = 16>
 int launch(const MidX& k, int per_cu, int ntile_c, hipStream_t st) {
   constexpr int NT = 64 * WP * WC;
   const int smem = k.halo_bytes + NST * BN * 128;
@@ -276,7 +279,7 @@ int launch(const MidX& k, int per_cu, int ntile_c, hipStream_t st) {
   int per_xcd = (256 * per_cu / ntile_c + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
-  auto kern = conv_midx_kernel<TH, BN, WP, WC, NST>;
+  auto kern = conv_midx_kernel<TH, BN, WP, WC, NST, TW>;
   MYOLO_ENSURE_DYN_SMEM(kern, smem);
   hipLaunchKernelGGL(kern, dim3(per_xcd * 8, ntile_c), dim3(NT), smem, st, k);
   MYOLO_CHECK_LAUNCH();
@@ -337,11 +340,11 @@ int myolo_conv_midx_try(const myolo_conv_desc* d, void* stream) {
     else return -1;
     if (want_bnb && d->cin_pad != 64) return -1;
   }
-  if (bn == 64) var = 2;
-  const int TH = var == 3 ? 16 : 8;
+  if (bn == 64 || var > 3) var = 2;
+  const int TH = var == 3 ? 16 : 8, TW = 16;
   k.mindy = mindy; k.mindx = mindx;
   const int HH = TH + (maxdy - mindy);
-  k.HW = 16 + (maxdx - mindx);
+  k.HW = TW + (maxdx - mindx);
   k.HP = HH * k.HW;
   k.pshift = d->cin_pad == 64 ? 7 : (d->cin_pad == 128 ? 8 : 9);
   k.segmask = d->cin_pad == 64 ? 7 : 15;
@@ -353,11 +356,12 @@ int myolo_conv_midx_try(const myolo_conv_desc* d, void* stream) {
     k.tap_hoff[t] = in ? (d->tap_dy[t] - mindy) * k.HW + (d->tap_dx[t] - mindx) : 0;
     k.tap_woff[t] = in ? d->tap_w[t] * d->cin_pad * 2 : 0;
   }
-  k.tiles_x = (k.Wo + 15) / 16; k.tiles_y = (k.Ho + TH - 1) / TH;
+  k.tiles_x = (k.Wo + TW - 1) / TW; k.tiles_y = (k.Ho + TH - 1) / TH;
   k.ntiles = d->y.n * k.tiles_x * k.tiles_y;
   k.tiles_per_xcd = (k.ntiles + 7) / 8;
   hipStream_t st = (hipStream_t)stream;
   const int ntc = d->cout_pad / (var == 2 ? 64 : 128);
+  // (8 x 32 pixel tiles with 8 waves and a two-stage ring with four workgroups per CU measured the same as var 2: 21.5 / 22.0 vs 20.6 us)
   if (var == 1) return launch<8, 128, 4, 2, 4>(k, 1, ntc, st);
   if (var == 3) return launch<16, 128, 4, 2, 3>(k, 1, ntc, st);
   return launch<8, 64, 2, 2, 3>(k, 3, ntc, st);
