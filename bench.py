@@ -637,7 +637,7 @@ def main():
                 traffic, tsrc = rec['conv_hbm_bytes_per_launch'], 'profiles/' + os.path.basename(pmc) + ': ' + rec['source']
             out['roofline'] = {'bound': 'hbm', 'achieved': b / t / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                'frac': b / t / 1e9 / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': tsrc,
-                               'kernel': 'myolo_conv launches of one step: conv_mid_kernel + conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below, or carries its own layer\'s BatchNorm-backward apply pass in its operand path (myolo_conv_dgrad_bn), counts that pass\'s bytes)',
+                               'kernel': 'myolo_conv launches of one step: conv_mid_kernel + conv_midx_kernel + conv_halo_kernel + conv_stream_kernel + conv_igemm_kernel (forward convs + dgrad; a dgrad launch that also produces the BatchNorm-backward sums of the layer below, or carries its own layer\'s BatchNorm-backward apply pass in its operand path (myolo_conv_dgrad_bn), counts that pass\'s bytes)',
                                'launches_per_step': n,
                                'avg_launch_us': t / n * 1e6, 'algorithmic_bytes_per_launch': b / n,
                                'mfma_tflops': f / t / 1e12, 'mfma_frac': f / t / 1e12 / MFMA_F16_PEAK_TF,

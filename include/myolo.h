@@ -68,7 +68,8 @@ int myolo_pack_weight(const void* w_oihw, int src_dtype, int cout, int cin, int 
 /* all weight packs of a plan in one launch.  jobs: device int64 [njobs][12] = {src, dst, cout, cin, ntaps, rows_pad,
  * cols_pad, transpose, src_dtype, dst_dtype, src2, cout2}; chunks: device int32 [nchunks][2] = {job, first packed element}.
  * src2 (0 = none): a second OIHW tensor [cout2][cin][taps] of the same dtype stacked behind src along cout.
- * chunk_elems == 0: LDS-tiled mode -- chunks = {job, tile}; a tile is 16 co x 32 ci (transpose = 0) or 32 co x 16 ci (transpose = 1)
+ * chunk_elems <= 0: LDS-tiled mode (-chunk_elems = the largest tap count of any job, 0 = up to MYOLO_MAX_TAPS: sizes the LDS
+ * tile) -- chunks = {job, tile}; a tile is 16 co x 32 ci (transpose = 0) or 32 co x 16 ci (transpose = 1)
  * over all taps (64 co x 64 ci for 1x1 weights), tiles numbered co-tile major over ceil(cout_all / tco) x ceil(cin / tci); only the valid region is written (the
  * caller keeps the padding of dst zero). */
 int myolo_pack_weights_mt(const int64_t* jobs, const int32_t* chunks, int nchunks, int chunk_elems, void* stream);

@@ -32,6 +32,7 @@ struct WgradK {
   int x_bytes, d_bytes, dense;   // buffer-descriptor spans; dense: 1x1 stride-1 over pixel-dense views (pixel m at m*sw)
   float* ws;           // split-K partials [ksplit][ntaps][tiles_co*64][tiles_ci*64] (plain stores) or NULL (atomics)
   int dbg;
+  int sp_tx, sp_ty;    // wgrad_small_halo_kernel: 8 x 16 pixel tiles per row / column of the map (M = tiles in all, pix_per_split = tiles per split)
 };
 
 template <typename T> struct Pitch;                       // LDS row pitch in bytes for a [KP][64] tile
@@ -455,6 +456,145 @@ __global__ __launch_bounds__(THREADS) void wgrad_fused_small_kernel(const WgradK
   for (int i = tid; i < NT * 32 * 16; i += THREADS) dst[i] = red[i];
 }
 
+// ---- the same layer class on spatial tiles.  wgrad_fused_small_kernel fetches every shifted x tile of the 3x3 separately: 11 16-byte
+// loads per thread and 128 pixels, 352 bytes per pixel through the texture path for 96 bytes of operands (Focus, alone on the chip
+// at the end of the backward: 108 us for 201 MB).  Here a K step is an 8 x 16 pixel tile of the map: its dy tile and ONE 10 x 18
+// x halo tile go to LDS (3.4 loads per thread and step, 141 bytes per pixel) and the nine taps read the halo at shifted pixel
+// rows -- the transpose read takes a per-lane address, so a tap is a uniform byte offset on the lane's base.  Stride 1, taps within
+// +-1, map dims multiples of 8 x 16 (others stay on the kernel above).
+constexpr int FTH = 8, FTW = 16, FHH = FTH + 2, FHW = FTW + 2;
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgrad_small_halo_kernel(const WgradK p) {
+  constexpr int ES = 2, SEG = 8, NT = 9;
+  constexpr int PD = 32 * ES + 16;                        // dy row pitch (bytes): 32 channels + pad
+  constexpr int PX = 16 * ES + 16;                        // x row pitch: 16 channels + pad
+  constexpr int SD_BYTES = KPS * PD, SX_BYTES = FHH * FHW * PX;
+  static_assert(SD_BYTES + SX_BYTES >= NT * 32 * 16 * 4, "the reduction tile reuses the staging area");
+  __shared__ __attribute__((aligned(16))) char smem[SD_BYTES + SX_BYTES];
+  char* sD = smem;
+  char* sX = smem + SD_BYTES;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int split = blockIdx.y;
+  const int t_begin = split * p.pix_per_split;
+  int t_end = t_begin + p.pix_per_split;
+  if (t_end > p.M) t_end = p.M;
+  const int nsteps = t_end > t_begin ? t_end - t_begin : 0;
+  const int tiles_img = p.sp_tx * p.sp_ty;
+
+  f4_t acc[NT][2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) acc[t][i] = f4_t{0.f, 0.f, 0.f, 0.f};
+
+  constexpr int OOB = 0x7fff0000;
+  const __amdgpu_buffer_rsrc_t rbx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.x), 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rbd = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(p.dy), 0, p.d_bytes, 0x00020000);
+  auto bl = [&](const __amdgpu_buffer_rsrc_t& r, int off) -> uint4 {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return uint4{v.x, v.y, v.z, v.w};
+  };
+  // per-thread constants of the two dy loads (tile pixel v >> 2, segment v & 3) and the two halo loads (halo pixel v >> 1, segment v & 1)
+  int d_off[2], x_hy[2], x_hx[2];
+  bool x_on[2];
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const int v = tid + l * THREADS;
+    const int prow = v >> 2, cd = (v & 3) * SEG;
+    d_off[l] = cd < p.Cout ? ((prow >> 4) * (int)p.d_sh + (prow & 15) * (int)p.d_sw + cd) * ES : -1;
+    const int hp = v >> 1;
+    x_on[l] = hp < FHH * FHW && (v & 1) * SEG < p.Cin;
+    x_hy[l] = hp / FHW - 1; x_hx[l] = hp % FHW - 1;
+  }
+  // two tiles of loads in flight per thread (the MFMAs of a tile take a fraction of the HBM latency: with one tile ahead and two
+  // workgroups per CU every step waited for its loads, 97 us; see the launch for the workgroup count)
+  uint4 rd[2][2], rx[2][2];
+  auto issue = [&](int s, const int b) {
+    const int tl = t_begin + s;
+    const int n = tl / tiles_img; const int r = tl - n * tiles_img; const int by = r / p.sp_tx; const int bx = r - by * p.sp_tx;
+    const int oy0 = by * FTH, ox0 = bx * FTW;
+    const int dbase = (n * (int)p.d_sn + oy0 * (int)p.d_sh + ox0 * (int)p.d_sw) * ES;
+#pragma unroll
+    for (int l = 0; l < 2; ++l) rd[b][l] = bl(rbd, d_off[l] >= 0 ? dbase + d_off[l] : OOB);
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int iy = oy0 + x_hy[l], ix = ox0 + x_hx[l];
+      const bool ok = x_on[l] && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+      rx[b][l] = bl(rbx, ok ? (n * (int)p.x_sn + iy * (int)p.x_sh + ix * (int)p.x_sw + ((tid + l * THREADS) & 1) * SEG) * ES : OOB);
+    }
+  };
+  // fragment addresses: K index 8g + 4h + k' of the wave's 32 pixels (two tile rows of 16) <-> tile pixel wave*32 + 8g + 4h + k'
+  const int g = lane >> 4, kq = (lane & 15) >> 2, q = lane & 3;
+  const int pr0 = wave * 32 + 8 * g + kq;                  // h = 0; h = 1 is 4 pixels further on the same tile row
+  const int hb0 = ((pr0 >> 4) + 1) * FHW + (pr0 & 15) + 1; // its halo pixel at tap (0, 0)
+  int tap_b[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tap_b[t] = (p.tap_dy[t] * FHW + p.tap_dx[t]) * PX;
+
+  auto step = [&](int s, const int b) {
+#pragma unroll
+    for (int l = 0; l < 2; ++l) {
+      const int v = tid + l * THREADS;
+      *reinterpret_cast<uint4*>(&sD[(v >> 2) * PD + (v & 3) * 16]) = rd[b][l];
+      if ((v >> 1) < FHH * FHW) *reinterpret_cast<uint4*>(&sX[(v >> 1) * PX + (v & 1) * 16]) = rx[b][l];
+    }
+    __syncthreads();
+    if (s + 2 < nsteps) issue(s + 2, b);                 // (the registers just stored are free)
+    h8_t fa[2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int ca = (f * 16 + q * 4) * 2;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        fp16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_t*)(&sD[(pr0 + 4 * h) * PD + ca]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fa[f][4 * h + e] = (half_t)va[e];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      h8_t fb;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+            (__attribute__((address_space(3))) fp16x4_t*)(&sX[(hb0 + 4 * h) * PX + tap_b[t] + q * 8]));
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fb[4 * h + e] = (half_t)vb[e];
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb, acc[t][i], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  if (nsteps > 0) issue(0, 0);
+  if (nsteps > 1) issue(1, 1);
+  for (int s = 0; s < nsteps; s += 2) {
+    step(s, 0);
+    if (s + 1 < nsteps) step(s + 1, 1);
+  }
+  // the four waves' partial [9][32][16] tiles meet in LDS, one wave after the other on a lane-linear image [t][i][lane][r] (16-byte
+  // accesses, no bank conflicts; fp32 LDS atomics on the [t][co][ci] image were 4-way conflicted, 72 per lane)
+  f4_t* red = reinterpret_cast<f4_t*>(smem);
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          f4_t v = acc[t][i];
+          if (w) { const f4_t o = red[(t * 2 + i) * 64 + lane]; v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3]; }
+          red[(t * 2 + i) * 64 + lane] = v;
+        }
+    }
+    __syncthreads();
+  }
+  const float* redf = reinterpret_cast<const float*>(smem);
+  float* dst = p.ws + (int64_t)split * (NT * 32 * 16);
+  for (int e = tid; e < NT * 32 * 16; e += THREADS) {      // slice layout [t][co][ci]: co = 16 i + 4 (lane >> 4) + r, ci = lane & 15
+    const int ci = e & 15, co = (e >> 4) & 31, t = e >> 9;
+    dst[e] = redf[(((t * 2 + (co >> 4)) * 64) + ((co & 15) >> 2) * 16 + ci) * 4 + (co & 3)];
+  }
+}
+
 // dw[co][ci][t] += sum over splits of ws[s][t][co][ci].  A workgroup owns 64 consecutive weights (coalesced along ci); its 4
 // waves take every 4th split and combine through LDS.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int ks, int ntaps,
@@ -471,14 +611,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       ci = (int)(i % cin); co = (int)((i / cin) % cout); t = (int)(i / ((int64_t)cin * cout));
       const float* src = ws + ((int64_t)t * CoP + co) * CiP + ci;
       float a0 = 0.f, a1 = 0.f;
-      int s = wave;
-      for (; s + 4 < ks; s += 8) { a0 += src[(int64_t)s * slice]; a1 += src[(int64_t)(s + 4) * slice]; }
-      for (; s < ks; s += 4) a0 += src[(int64_t)s * slice];
+      const int st = 4 * gridDim.y;                         // gridDim.y > 1: the splits are dealt over y, partial sums meet in fp32 atomics
+      int s = wave + 4 * blockIdx.y;
+      for (; s + st < ks; s += 2 * st) { a0 += src[(int64_t)s * slice]; a1 += src[(int64_t)(s + st) * slice]; }
+      for (; s < ks; s += st) a0 += src[(int64_t)s * slice];
       a = a0 + a1;
     }
     red[wave][lane] = a;
     __syncthreads();
-    if (wave == 0 && i < total) dw[((int64_t)co * cin + ci) * ntaps + t] += red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (wave == 0 && i < total) {
+      const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+      float* o = dw + ((int64_t)co * cin + ci) * ntaps + t;
+      if (gridDim.y > 1) atomicAdd(o, v); else *o += v;
+    }
     __syncthreads();
   }
 }
@@ -561,7 +706,8 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   const bool small = fused && !d->db && k.cout_w <= 32 && k.cin_w <= 16 && d->ws && (((uintptr_t)d->ws) & 15) == 0 &&
                      d->ws_bytes >= (int64_t)2 * 9 * 32 * 16 * (int64_t)sizeof(float) && !getenv("MYOLO_WGRAD_NO_SMALL");
   if (small) {
-    ks = d->ksplit > 0 ? d->ksplit : 512;                     // two 8-wave-equivalent workgroups per CU
+    static const int small_ks = getenv("MYOLO_WGRAD_SMALL_KS") ? atoi(getenv("MYOLO_WGRAD_SMALL_KS")) : 768;
+    ks = d->ksplit > 0 ? d->ksplit : small_ks;                // three workgroups per CU (halo kernel, 256x512 map: 256 -> 66 us, 512 -> 52, 768 -> 50, 1024 -> 62)
     const int max_ks = (int)((M + 4 * KPS - 1) / (4 * KPS));
     if (ks > max_ks) ks = max_ks;
     const int64_t fit = d->ws_bytes / ((int64_t)9 * 32 * 16 * sizeof(float));
@@ -578,9 +724,23 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   k.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   if (small) {
-    hipLaunchKernelGGL(wgrad_fused_small_kernel, dim3(1, ks), dim3(THREADS), 0, st, k);
+    bool tiles = k.stride == 1 && k.up == 0 && k.Hi == k.Ho && k.Wi == k.Wo && k.Ho % FTH == 0 && k.Wo % FTW == 0;
+    for (int t = 0; t < 9; ++t) tiles = tiles && k.tap_dy[t] >= -1 && k.tap_dy[t] <= 1 && k.tap_dx[t] >= -1 && k.tap_dx[t] <= 1;
+    static const int no_tiles = getenv("MYOLO_WGRAD_NO_SMALL_HALO") != nullptr;
+    if (tiles && !no_tiles) {                                 // 8 x 16 pixel tiles, one x halo for all taps (wgrad_small_halo_kernel)
+      k.sp_tx = k.Wo / FTW; k.sp_ty = k.Ho / FTH;
+      const int ntiles = k.N * k.sp_tx * k.sp_ty;
+      const int tps = (ntiles + ks - 1) / ks;
+      ks = (ntiles + tps - 1) / tps;
+      k.M = ntiles; k.pix_per_split = tps; k.ksplit = ks;
+      hipLaunchKernelGGL(wgrad_small_halo_kernel, dim3(1, ks), dim3(THREADS), 0, st, k);
+    } else {
+      hipLaunchKernelGGL(wgrad_fused_small_kernel, dim3(1, ks), dim3(THREADS), 0, st, k);
+    }
     const int64_t total = (int64_t)9 * k.cout_w * k.cin_w;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 64, 4096)), dim3(256), 0, st, k.ws, k.dw, ks, 9, 32, 16, k.cout_w, k.cin_w);
+    // (54 workgroups summing 512 slices each took 21 us at the very end of the step: deal the slices over 8 groups)
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total, 64, 4096), ks >= 64 ? 8 : 1), dim3(256), 0, st, k.ws, k.dw, ks, 9, 32, 16,
+                       k.cout_w, k.cin_w);
     MYOLO_CHECK_LAUNCH();
     return 0;
   }

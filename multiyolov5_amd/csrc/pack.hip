@@ -68,27 +68,31 @@ __global__ __launch_bounds__(256) void pack_weights_mt_kernel(const int64_t* job
 // OIHW), transposed in LDS, and written as 64-byte runs of the destination's fastest index.  Padding rows / columns are NOT written:
 // the packed tensors are allocated zeroed and nothing else writes them.
 constexpr int PACK_TILE = 512;             // (co x ci) pairs per tile: 16 x 32 (forward operand) or 32 x 16 (transposed); 64 x 64 for 1x1 weights
-__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const int64_t* jobs, const int32_t* chunks) {
-  extern __shared__ float tile[];          // [tco][tci * taps]
-  const int j = chunks[blockIdx.x * 2], tid_tile = chunks[blockIdx.x * 2 + 1];
-  const int64_t* e = jobs + (int64_t)j * 12;
+// NT / TR: compile-time tap count and orientation (1x1 and 3x3 weights: the index arithmetic divides by constants); NT = 0: any
+// tap count, read from the job.  The first version took the divisors from the job row for every element and always reserved the
+// 25-tap tile (51 KB: three workgroups per CU): 61 us for 45 MB at the head of every training forward.
+template <int NT, bool TR>
+__device__ __forceinline__ void pack_tile_body(float* tile, const int64_t* e, int tid_tile, int ntaps_rt, int transpose_rt) {
   const void* src = reinterpret_cast<const void*>(e[0]);
   void* dst = reinterpret_cast<void*>(e[1]);
-  const int cout = (int)e[2], cin = (int)e[3], ntaps = (int)e[4], cols_pad = (int)e[6];
-  const int transpose = (int)e[7], sdt = (int)e[8], ddt = (int)e[9];
+  const int cout = (int)e[2], cin = (int)e[3], cols_pad = (int)e[6];
+  const int sdt = (int)e[8], ddt = (int)e[9];
   const void* src2 = reinterpret_cast<const void*>(e[10]);
   const int cout_all = cout + (src2 ? (int)e[11] : 0);
+  const int ntaps = NT ? NT : ntaps_rt;
+  const bool transpose = NT ? TR : transpose_rt != 0;
   const int tco = ntaps == 1 ? 64 : (transpose ? 32 : 16), tci = ntaps == 1 ? 64 : (transpose ? 16 : 32);   // ~4-13 K elements per workgroup
   const int tiles_ci = (cin + tci - 1) / tci;
   const int co0 = (tid_tile / tiles_ci) * tco, ci0 = (tid_tile % tiles_ci) * tci;
   const bool f16s = sdt == MYOLO_F16, f16d = ddt == MYOLO_F16;
   const int run = tci * ntaps;                                   // contiguous source elements per output channel of the tile
   const int nci = cin - ci0 < tci ? cin - ci0 : tci;
+  const int live = nci * ntaps;
   for (int i = threadIdx.x; i < tco * run; i += 256) {
     const int col = i / run, r = i - col * run;
     const int co = co0 + col;
     float v = 0.f;
-    if (co < cout_all && r < nci * ntaps) {
+    if (co < cout_all && r < live) {
       const bool second = co >= cout;
       const void* sp = second ? src2 : src;
       const int64_t si = ((int64_t)(second ? co - cout : co) * cin + ci0) * ntaps + r;
@@ -109,6 +113,16 @@ __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const int64_t* 
     const int64_t di = transpose ? ((int64_t)ci * ntaps + t) * cols_pad + co : ((int64_t)co * ntaps + t) * cols_pad + ci;
     if (f16d) ((half_t*)dst)[di] = (half_t)v; else ((float*)dst)[di] = v;
   }
+}
+
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const int64_t* __restrict__ jobs, const int32_t* __restrict__ chunks) {
+  extern __shared__ float tile[];          // [tco][tci * taps]
+  const int j = chunks[blockIdx.x * 2], tid_tile = chunks[blockIdx.x * 2 + 1];
+  const int64_t* e = jobs + (int64_t)j * 12;
+  const int ntaps = (int)e[4], transpose = (int)e[7];
+  if (ntaps == 1) { if (transpose) pack_tile_body<1, true>(tile, e, tid_tile, 1, 1); else pack_tile_body<1, false>(tile, e, tid_tile, 1, 0); }
+  else if (ntaps == 9) { if (transpose) pack_tile_body<9, true>(tile, e, tid_tile, 9, 1); else pack_tile_body<9, false>(tile, e, tid_tile, 9, 0); }
+  else pack_tile_body<0, false>(tile, e, tid_tile, ntaps, transpose);
 }
 
 template <typename S, typename D>
@@ -185,10 +199,14 @@ extern "C" int myolo_focus_pack(const void* img, int src_dtype, int n, int h, in
 }
 
 extern "C" int myolo_pack_weights_mt(const int64_t* jobs, const int32_t* chunks, int nchunks, int chunk_elems, void* stream) {
-  if (!jobs || !chunks || nchunks < 0 || chunk_elems < 0) return MYOLO_EINVAL;
+  if (!jobs || !chunks || nchunks < 0) return MYOLO_EINVAL;
   if (nchunks == 0) return 0;
-  if (chunk_elems == 0) {                   // tiled mode: chunks = {job, tile of PACK_TILE (co, ci) pairs}; ntaps <= MYOLO_MAX_TAPS
-    const size_t smem = (size_t)PACK_TILE * MYOLO_MAX_TAPS * sizeof(float);      // (>= the 64 x 64 floats of a 1x1 tile)
+  if (chunk_elems <= 0) {                   // tiled mode: chunks = {job, tile of PACK_TILE (co, ci) pairs}; ntaps <= MYOLO_MAX_TAPS
+    // chunk_elems = -T: no job has more than T taps (the LDS tile is sized for it: 18 KB for 3x3 instead of 51 KB); 0: up to MYOLO_MAX_TAPS
+    const int maxt = chunk_elems < 0 ? -chunk_elems : MYOLO_MAX_TAPS;
+    if (maxt > MYOLO_MAX_TAPS) return MYOLO_EINVAL;
+    size_t smem = (size_t)PACK_TILE * maxt * sizeof(float);
+    if (smem < (size_t)64 * 64 * sizeof(float)) smem = (size_t)64 * 64 * sizeof(float);      // (the 64 x 64 floats of a 1x1 tile)
     hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3(nchunks), dim3(256), smem, (hipStream_t)stream, jobs, chunks);
     MYOLO_CHECK_LAUNCH();
     return 0;

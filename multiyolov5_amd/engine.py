@@ -1163,7 +1163,7 @@ class Plan:
         dev = self.device
         self._pack_tab = torch.tensor(rows, dtype=torch.int64).reshape(-1, 12).to(dev)
         self._pack_chunks = torch.tensor(chunks, dtype=torch.int32).reshape(-1, 2).to(dev)
-        self._pack_call = Call('myolo_pack_weights_mt', (L.ptr(self._pack_tab), L.ptr(self._pack_chunks), len(chunks), 0 if PACK_TILED else CH))
+        self._pack_call = Call('myolo_pack_weights_mt', (L.ptr(self._pack_tab), L.ptr(self._pack_chunks), len(chunks), -max(r[4] for r in rows) if PACK_TILED else CH))
 
     def add_input(self, t):
         """declare an input tensor slot (shape/stride/dtype are part of the plan; the pointer is rebound per run)."""

@@ -17,7 +17,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 sgd = [i for i, r in enumerate(rows) if 'mt_sgd' in r['Kernel_Name']]
 step = rows[sgd[-2] + 1:sgd[-1] + 1]
-ks = [r for r in step if any(n in r['Kernel_Name'] for n in ('conv_igemm_kernel', 'conv_stream_kernel', 'conv_halo_kernel', 'conv_mid_kernel'))]
+ks = [r for r in step if any(n in r['Kernel_Name'] for n in ('conv_igemm_kernel', 'conv_stream_kernel', 'conv_halo_kernel', 'conv_mid_kernel', 'conv_midx_kernel'))]
 print(len(calls), len(ks))
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0, 0.0, ''])
 import re
@@ -38,7 +38,7 @@ print('kernels consumed', ki, 'of', len(ks))
 for (ph, c), r in pairs:
     d = E._s2_descs(c)[0] if c.name == 'myolo_conv_dgrad_s2' else E._conv_desc_of(c)
     t = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
-    kn = 'stream' if 'stream' in r['Kernel_Name'] else ('halo' if 'halo' in r['Kernel_Name'] else ('mid' if 'conv_mid' in r['Kernel_Name'] else 'igemm'))
+    kn = 'stream' if 'stream' in r['Kernel_Name'] else ('halo' if 'halo' in r['Kernel_Name'] else ('midx' if 'conv_midx' in r['Kernel_Name'] else ('mid' if 'conv_mid' in r['Kernel_Name'] else 'igemm')))
     key = (ph, d.x.h, d.x.w, d.x.c, d.y.h, d.y.w, d.y.c, d.ntaps, kn)
     a = agg[key]; a[0] += 1; a[1] += t; a[2] += E.conv_call_bytes(c); a[3] += E.conv_call_flops(c)
 tot = sum(a[1] for a in agg.values())

@@ -16,7 +16,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3            # bench.py --ste
 
 def fam(name):
     name = re.sub(r'^void ', '', name)
-    name = re.sub(r'\(anonymous namespace\)::|stream::|mid::|halo::|wgt::|small::', '', name)
+    name = re.sub(r'\(anonymous namespace\)::|stream::|midx::|mid::|halo::|wgt::|small::', '', name)
     m = re.search(r'(\w+_kernel|__amd_rocclr_\w+|at::native::\w+)', name)
     if 'N12_GLOBAL__N_' in name:
         m2 = re.search(r'N_1?\d+(\w+?_kernel)', name)
@@ -44,7 +44,7 @@ for f in sorted(set(fetch) | set(write)):
     rd, wr = 2 * fetch.get(f, 0.0) * 1024 / steps, write.get(f, 0.0) * 1024 / steps
     rows.append({'kernel': f, 'launches_per_step': nf.get(f, nw.get(f, 0)) / steps, 'read_MB_per_step': rd / 1e6, 'write_MB_per_step': wr / 1e6})
 rows.sort(key=lambda r: -(r['read_MB_per_step'] + r['write_MB_per_step']))
-conv = [r for r in rows if r['kernel'] in ('conv_igemm_kernel', 'conv_stream_kernel', 'conv_halo_kernel', 'conv_mid_kernel')]
+conv = [r for r in rows if r['kernel'] in ('conv_igemm_kernel', 'conv_stream_kernel', 'conv_halo_kernel', 'conv_mid_kernel', 'conv_midx_kernel')]
 conv_bytes = sum((r['read_MB_per_step'] + r['write_MB_per_step']) * 1e6 for r in conv)
 conv_launches = sum(r['launches_per_step'] for r in conv)
 out = {

@@ -45,6 +45,7 @@ def _oracle(fn, mod, xs, training):
 CASES = {
     # name: (ctor, oracle fn, input shapes)
     'conv1x1': (lambda C: C.Conv(64, 128, 1, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 1), [(2, 64, 24, 40)]),
+    'conv3x3_small_tiles': (lambda C: C.Conv(16, 32, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(3, 16, 24, 48)]),   # Focus-sized on 8 x 16 pixel tiles: wgrad_small_halo_kernel
     'conv3x3_small': (lambda C: C.Conv(16, 32, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(3, 16, 37, 53)]),   # Focus-sized: compact wgrad kernel, ragged pixel count
     'conv3x3': (lambda C: C.Conv(32, 64, 3, 1), lambda c, p, x: model_ref.conv_block(c, p, x, 3), [(2, 32, 20, 36)]),
     'conv3x3s2': (lambda C: C.Conv(64, 128, 3, 2), lambda c, p, x: model_ref.conv_block(c, p, x, 3, 2), [(2, 64, 24, 40)]),
@@ -142,7 +143,7 @@ def force_halo_kernel():
 
 
 @pytest.mark.parametrize('training', [True, False], ids=['train', 'eval'])
-@pytest.mark.parametrize('name', ['conv3x3_small', 'conv3x3', 'conv3x3s2', 'conv3x3s2_odd', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'rfb2_global', 'rfb1', 'aspp', 'aspps',
+@pytest.mark.parametrize('name', ['conv3x3_small', 'conv3x3_small_tiles', 'conv3x3', 'conv3x3s2', 'conv3x3s2_odd', 'conv_c48', 'bottleneck', 'c3', 'rfb2', 'rfb2_global', 'rfb1', 'aspp', 'aspps',
                                   'ffm_k3', 'arm'])
 def test_block_halo_kernel(name, training, force_halo_kernel):
     """the block parity cases with the LDS-halo conv kernel forced on (ragged tiles, dilation 2/3/5/7/9, 5x5, residual, accumulate in
@@ -396,7 +397,7 @@ def test_pyramid_grouped_kernels_match_the_single_op_entry_points(shape, dt):
 
 
 def test_weight_pack_tiled_mode_equals_element_mode():
-    """myolo_pack_weights_mt: the LDS-tiled mode (chunk_elems = 0) writes exactly what the element-per-thread mode writes into the
+    """myolo_pack_weights_mt: the LDS-tiled mode (chunk_elems <= 0) writes exactly what the element-per-thread mode writes into the
     valid region, for forward / transposed operands, 1x1 / 3x3 / 5x5 taps, ragged channel counts and a stacked second source"""
     from multiyolov5_amd import _lib as L
     lib = L.lib()
@@ -408,11 +409,11 @@ def test_weight_pack_tiled_mode_equals_element_mode():
         w2 = torch.randn(co2, ci, k, k, generator=g).to(DEV) if co2 else None
         for tr in (0, 1):
             rows, cols = (((co + co2 + 31) // 32) * 32, ((ci + 31) // 32) * 32) if not tr else (((ci + 31) // 32) * 32, ((co + co2 + 31) // 32) * 32)
-            for mode in (0, 1):
+            for mode in (0, 1, 2):
                 dst = torch.zeros(rows, k * k, cols, dtype=torch.float16, device=DEV)
                 jobs.append((mode, w, w2, dst, co, ci, k * k, rows, cols, tr))
             keep += [w, w2]
-    for mode in (0, 1):
+    for mode in (0, 1, 2):                       # 0: element per thread; 1: tiled, LDS tile for MYOLO_MAX_TAPS; 2: tiled, LDS tile for the 25 taps present
         rows_, chunks = [], []
         sel = [j for j in jobs if j[0] == mode]
         for ji, (_, w, w2, dst, co, ci, nt, rp, cp, tr) in enumerate(sel):
@@ -426,12 +427,13 @@ def test_weight_pack_tiled_mode_equals_element_mode():
                 chunks += [(ji, t) for t in range(((ca + tco - 1) // tco) * ((ci + tci - 1) // tci))]
         tab = torch.tensor(rows_, dtype=torch.int64).to(DEV)
         ch = torch.tensor(chunks, dtype=torch.int32).to(DEV)
-        L.check(lib.myolo_pack_weights_mt(L.ptr(tab), L.ptr(ch), len(chunks), 8192 if mode == 0 else 0, L.stream_ptr()), 'pack')
+        L.check(lib.myolo_pack_weights_mt(L.ptr(tab), L.ptr(ch), len(chunks), (8192, 0, -25)[mode], L.stream_ptr()), 'pack')
     torch.cuda.synchronize()
     a = [j[3] for j in jobs if j[0] == 0]
     b = [j[3] for j in jobs if j[0] == 1]
-    for x, y in zip(a, b):
-        assert torch.equal(x, y)
+    c = [j[3] for j in jobs if j[0] == 2]
+    for x, y, z in zip(a, b, c):
+        assert torch.equal(x, y) and torch.equal(x, z)
         assert float(x.abs().max()) > 0
 
 
