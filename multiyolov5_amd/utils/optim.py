@@ -8,12 +8,13 @@ python loop of per-tensor ATen kernels.
 * `ema_update` -- `ModelEMA.update` body (utils/torch_utils.py:296-300)
 """
 import ctypes as C
+import os
 
 import torch
 
 from .. import _lib as L
 
-CHUNK = 16384
+CHUNK = int(os.environ.get('MYOLO_OPTIM_CHUNK', '8192'))     # elements per workgroup (yolov5s: 1109 workgroups; scripts/optim_ubench.py)
 
 
 class _Table:
