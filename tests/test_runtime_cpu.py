@@ -40,7 +40,7 @@ def test_training_plan_launch_list_structure():
     wg = [c for op in plan.ops for c in op.bwd_calls if c.name == 'myolo_conv_wgrad']
     assert all(c.side for c in wg) and len(wg) == sum(2 if op.weight2 is not None else 1 for op in plan.ops if isinstance(op, E.ConvOp))
     # one weight repack per forward, tiled
-    assert plan._pack_call is not None and plan._pack_call.args[3] == 0
+    assert plan._pack_call is not None and plan._pack_call.args[3] == -9      # tiled mode: -(largest tap count), myolo.h
 
 
 def test_eval_plan_defers_the_logit_upsample_and_merges_too(monkeypatch):
