@@ -1,5 +1,6 @@
 """micro-benchmark of myolo_conv_wgrad through the raw C ABI (B=16, fp16): hipGraph-timed launches over rotating buffers, the LDS-tile
-kernel (conv_wgrad_tile.hip) vs the round-1 kernels (`wgrad_tile_off`), numerics vs autograd (fp32)."""
+kernel (conv_wgrad_tile.hip) with its LDS-DMA loaders vs the register loaders (`wgrad_tile_dma` 0) [vs split / ring variants: `sweep`]
+[vs the round-1 kernels (`wgrad_tile_off`): `r1`], numerics of every variant vs autograd (fp32).  usage: wgrad_ubench.py [quick] [sweep] [r1] [focus]"""
 import ctypes as C
 import sys
 
@@ -75,7 +76,16 @@ def run(cin, cout, k, d, s, H, W, nbuf, iters=10):
     return e0.elapsed_time(e1) * 1e3 / (3 * iters), err
 
 
-print(f'{"shape":40s} {"MB":>6s} {"GF":>6s} {"roof us":>8s} | {"tile":>8s} {"r1 kern":>8s} | GB/s  TF/s  frac   err(tile) err(r1)')
+# variants: (label, {option: value}) -- A/B of the LDS-DMA loaders (round 4) against the register loaders of round 2 in one process
+VARIANTS = [('dma', {}), ('reg', {'wgrad_tile_dma': 0})]
+if 'sweep' in sys.argv[1:]:
+    VARIANTS += [('dma mt3', {'wgrad_tile_min_tiles': 3}), ('dma mt2', {'wgrad_tile_min_tiles': 2}), ('dma mt4 wg192', {'wgrad_tile_min_tiles': 4, 'wgrad_tile_wg': 192}),
+                 ('dma nst3', {'wgrad_tile_nst': 3}), ('dma nst4', {'wgrad_tile_nst': 4})]
+if 'r1' in sys.argv[1:]:
+    VARIANTS += [('r1 kern', {'wgrad_tile_off': 1})]
+DEFAULTS = {'wgrad_tile_dma': 1, 'wgrad_tile_min_tiles': 6, 'wgrad_tile_wg': 128, 'wgrad_tile_nst': 0, 'wgrad_tile_off': 0}
+print(f'{"shape":34s} {"MB":>6s} {"GF":>6s} {"roof us":>8s} | ' + ' '.join(f'{v[0]:>13s}' for v in VARIANTS) + ' | best GB/s  frac   err per variant')
+tot = [0.0] * len(VARIANTS)
 for cin, cout, k, d, s, H, W in SHAPES:
     pad = d * (k // 2)
     Ho, Wo = (H + 2 * pad - d * (k - 1) - 1) // s + 1, (W + 2 * pad - d * (k - 1) - 1) // s + 1
@@ -84,10 +94,15 @@ for cin, cout, k, d, s, H, W in SHAPES:
     roof = max(byt / 8e12, fl / 2.5e15) * 1e6
     nbuf = max(2, int(300e6 // byt) + 1)
     res = []
-    for off in (0, 1):
-        lib.myolo_set_option(b'wgrad_tile_off', off)
+    for _, opts in VARIANTS:
+        for o, v in {**DEFAULTS, **opts}.items():
+            lib.myolo_set_option(o.encode(), v)
         res.append(run(cin, cout, k, d, s, H, W, nbuf))
-    lib.myolo_set_option(b'wgrad_tile_off', 0)
-    us = res[0][0]
-    print(f'{cin:4d}->{cout:4d} k{k} d{d} s{s} {H:4d}x{W:4d}           {byt / 1e6:6.1f} {fl / 1e9:6.2f} {roof:8.1f} | {res[0][0]:8.1f} {res[1][0]:8.1f} | '
-          f'{byt / us / 1e3:5.0f} {fl / us / 1e6:5.0f} {roof / us:5.2f}  {res[0][1]:.1e} {res[1][1]:.1e}', flush=True)
+    for o, v in DEFAULTS.items():
+        lib.myolo_set_option(o.encode(), v)
+    us = min(r[0] for r in res)
+    for i, r in enumerate(res):
+        tot[i] += r[0]
+    print(f'{cin:4d}->{cout:4d} k{k} d{d} s{s} {H:4d}x{W:4d}     {byt / 1e6:6.1f} {fl / 1e9:6.2f} {roof:8.1f} | ' + ' '.join(f'{r[0]:13.1f}' for r in res) +
+          f' | {byt / us / 1e3:5.0f} {roof / us:5.2f}  ' + ' '.join(f'{r[1]:.1e}' for r in res), flush=True)
+print(f'{"sum us":58s} | ' + ' '.join(f'{t:13.1f}' for t in tot))
