@@ -44,7 +44,35 @@ struct WgT {
   int dbuf_bytes, xbuf_bytes;        // bytes of one dy / x LDS buffer
   int pd, px;                        // LDS pixel-row pitches (bytes) of the dy / x tiles
   int nst, dpieces, xpieces, stage_bytes;   // wgrad_tile_dma_kernel: ring stages, 1 KB pieces of the dy / x area, (dpieces + xpieces) * 1024
+  int map_mode, out_tiles;           // workgroup id -> (gradient block, pixel split): see block_of()
+  int dbg;                           // profiling only (myolo_set_option("wgrad_tile_dbg", bits)): 1 no LDS-DMA, 2 no fragment reads / MFMAs, 4 no result stores
 };
+
+
+// Workgroup id -> (gradient block b, pixel split).  Every block of one split reads the SAME dy / x pixels (x once per co block, dy once
+// per ci block: 2-8 x the operand bytes for the 128+-channel layers), and consecutive workgroup ids go round-robin over the 8 XCDs, each
+// with its own L2: with the plain (block, split) grid the blocks of a split sat on different XCDs and every re-read was an L2 miss
+// (PMC: 5.27 GB fetched per step for 3.25 GB of operands = exactly the issued bytes).  map_mode 2 (ksplit % 8 == 0): XCD x serves the
+// splits x, x + 8, ...; map_mode 1 (ksplit in {1, 2, 4}): XCD x serves split x % ksplit, the blocks dealt over the 8 / ksplit XCDs of
+// that split; map_mode 0: linear.  Returns false for the surplus workgroups of mode 1.
+__device__ __forceinline__ bool block_of(const WgT& p, int& b, int& split) {
+  const int id = blockIdx.x;
+  if (p.map_mode == 2) {
+    const int xcd = id & 7, slot = id >> 3;
+    split = xcd + 8 * (slot / p.out_tiles);
+    b = slot % p.out_tiles;
+    return true;
+  }
+  if (p.map_mode == 1) {
+    const int xcd = id & 7, slot = id >> 3;
+    split = xcd % p.ksplit;
+    b = xcd / p.ksplit + (8 / p.ksplit) * slot;
+    return b < p.out_tiles;
+  }
+  split = id / p.out_tiles;
+  b = id % p.out_tiles;
+  return true;
+}
 
 template <int NT, int COF, int CIF>
 __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
@@ -60,9 +88,9 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_kernel(const WgT p) {
   char* sD = smem;                                  // [2][TH*32][PD]
   char* sX = smem + 2 * p.dbuf_bytes;               // [2][hh*hw][PX]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int b = blockIdx.x;
+  int b, split;
+  if (!block_of(p, b, split)) return;
   const int tci = b % p.tiles_ci; const int tco = b / p.tiles_ci;
-  const int split = blockIdx.y;
   const int co0 = tco * CO_T, ci0 = tci * CI_T;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int ntl = split < p.ntiles ? (p.ntiles - split + p.ksplit - 1) / p.ksplit : 0;    // tiles split, split+ksplit, ...
@@ -222,9 +250,9 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
   constexpr int DV = CO_T / 8, XV = CI_T / 8;
   extern __shared__ __attribute__((aligned(16))) char smem[];      // [nst][dy area: dpieces KB | x area: xpieces KB]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.x;
+  int b, split;
+  if (!block_of(p, b, split)) return;
   const int tci = b % p.tiles_ci; const int tco = b / p.tiles_ci;
-  const int split = blockIdx.y;
   const int co0 = tco * CO_T, ci0 = tci * CI_T;
   const int tiles_per_img = p.tiles_x * p.tiles_y;
   const int ntl = split < p.ntiles ? (p.ntiles - split + p.ksplit - 1) / p.ksplit : 0;    // tiles split, split+ksplit, ...
@@ -262,6 +290,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
     const uint64_t zp = (uint64_t)(uintptr_t)zero_page(), dyp = (uint64_t)(uintptr_t)p.dy, xp = (uint64_t)(uintptr_t)p.x;
     const unsigned Ho = (unsigned)p.Ho, Wo = (unsigned)p.Wo, Hi = (unsigned)p.Hi, Wi = (unsigned)p.Wi;
     auto issue = [&](int tile, int stg) {
+      if (p.dbg & 1) return;
       const int n = tile / tiles_per_img; const int r0 = tile - n * tiles_per_img;
       const int ty = r0 / p.tiles_x, tx = r0 - ty * p.tiles_x;
       const int oy0 = ty * p.TH, ox0 = tx * TW;
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
     for (int i = 0; i < ntl; ++i) {
       int younger = ntl - 1 - i;
       if (younger > nst - 2) younger = nst - 2;
-      wait_vmcnt(younger * ppw);
+      if (p.dbg & 1) wait_vmcnt(0); else wait_vmcnt(younger * ppw);
       asm volatile("s_barrier" ::: "memory");
       const int nx = i + nst - 1;
       if (nx < ntl) {
@@ -325,6 +354,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
     const char* bD = smem + stg * p.stage_bytes + dlane;
     const char* bX = smem + stg * p.stage_bytes + xlane;
     stg = stg + 1 == nst ? 0 : stg + 1;
+    if (p.dbg & 2) continue;
     for (int r = 0; r < p.TH; ++r) {
       h8_t fa[COF];
 #pragma unroll
@@ -359,6 +389,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
     }
   }
 
+  if (p.dbg & 4) return;
   const int CoP = p.tiles_co * CO_T, CiP = p.tiles_ci * CI_T;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -375,18 +406,23 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
         }
 }
 
+inline int grid_blocks(const WgT& k) {
+  if (k.map_mode == 1) { const int per = 8 / k.ksplit; return 8 * ((k.out_tiles + per - 1) / per); }
+  return k.out_tiles * k.ksplit;
+}
+
 template <int NT, int COF, int CIF>
 int launch(const WgT& k, int out_tiles, int smem, hipStream_t st) {
   if (k.nst > 0) {
     auto kd = wgrad_tile_dma_kernel<NT, COF, CIF>;
     MYOLO_ENSURE_DYN_SMEM(kd, smem);
-    hipLaunchKernelGGL(kd, dim3(out_tiles, k.ksplit), dim3(THREADS), smem, st, k);
+    hipLaunchKernelGGL(kd, dim3(grid_blocks(k)), dim3(THREADS), smem, st, k);
     MYOLO_CHECK_LAUNCH();
     return 0;
   }
   auto kern = wgrad_tile_kernel<NT, COF, CIF>;
   MYOLO_ENSURE_DYN_SMEM(kern, smem);
-  hipLaunchKernelGGL(kern, dim3(out_tiles, k.ksplit), dim3(THREADS), smem, st, k);
+  hipLaunchKernelGGL(kern, dim3(grid_blocks(k)), dim3(THREADS), smem, st, k);
   MYOLO_CHECK_LAUNCH();
   return 0;
 }
@@ -412,12 +448,16 @@ static int g_wgt_dma = -1;         // 1: LDS-DMA loaders (wgrad_tile_dma_kernel)
 static int g_wgt_nst = -1;         // ring stages of the LDS-DMA kernel: 3, 4, 0 = whichever keeps more bytes in flight
 static int g_wgt_min_tiles = -1;   // split-K: at least this many tiles per workgroup
 static int g_wgt_wg = -1;          // workgroups aimed at per layer
+static int g_wgt_dbg = 0;
+static int g_wgt_xcd = -1;         // 1: XCD-aware workgroup order (block_of), 0: linear
 int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_off")) { g_wgt_off = value; return 0; }
   if (!strcmp(name, "wgrad_tile_dma")) { g_wgt_dma = value; return 0; }
   if (!strcmp(name, "wgrad_tile_nst")) { g_wgt_nst = value; return 0; }
   if (!strcmp(name, "wgrad_tile_min_tiles")) { g_wgt_min_tiles = value; return 0; }
   if (!strcmp(name, "wgrad_tile_wg")) { g_wgt_wg = value; return 0; }
+  if (!strcmp(name, "wgrad_tile_dbg")) { g_wgt_dbg = value; return 0; }
+  if (!strcmp(name, "wgrad_tile_xcd")) { g_wgt_xcd = value; return 0; }
   return MYOLO_EINVAL;
 }
 
@@ -504,6 +544,7 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   if (xb >= 0x3ffe0000LL || db >= 0x3ffe0000LL) return -1;
   k.x_bytes = (int)xb; k.d_bytes = (int)db;
   k.dbuf_bytes = dbuf; k.xbuf_bytes = xbuf; k.pd = PD; k.px = PX;
+  k.dbg = g_wgt_dbg;
   k.nst = nst; k.dpieces = nst ? dbuf / 1024 : 0; k.xpieces = nst ? xbuf / 1024 : 0; k.stage_bytes = nst ? dbuf + xbuf : 0;
   // split-K over tiles: one workgroup per CU at most (the buffers take > 80 KB), at least ~6 tiles per workgroup
   if (g_wgt_wg < 0) g_wgt_wg = getenv("MYOLO_WGRAD_TILE_WG") ? atoi(getenv("MYOLO_WGRAD_TILE_WG")) : 128;
@@ -514,6 +555,13 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int max_ks = (k.ntiles + mt - 1) / mt;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
+  if (g_wgt_xcd < 0) g_wgt_xcd = getenv("MYOLO_WGRAD_TILE_XCD") ? atoi(getenv("MYOLO_WGRAD_TILE_XCD")) : 1;
+  const bool xcd_map = g_wgt_xcd && out_tiles > 1 && d->ksplit <= 0;
+  if (xcd_map) {                                      // a split count the XCD-aware order can deal: a multiple of 8, or 1 / 2 / 4
+    if (ks >= 8) ks = ks / 8 * 8;
+    else if (ks > 4) ks = max_ks >= 8 ? 8 : 4;
+    else if (ks == 3) ks = max_ks >= 4 ? 4 : 2;
+  }
   const int CoP = k.tiles_co * CO_T, CiP = k.tiles_ci * CI_T;
   const int64_t slice_bytes = (int64_t)k.ntaps * CoP * CiP * sizeof(float);
   k.ws = nullptr;
@@ -523,6 +571,8 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
     k.ws = d->ws;
   }
   k.ksplit = ks;
+  k.out_tiles = out_tiles;
+  k.map_mode = !xcd_map ? 0 : (ks % 8 == 0 ? 2 : ((ks == 1 || ks == 2 || ks == 4) ? 1 : 0));
   *out_ks = ks; *out_cop = CoP; *out_cip = CiP; *used_ws = k.ws != nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (k.ntaps == 9) return launch_nt<9>(k, cof, cif, out_tiles, smem, st);
