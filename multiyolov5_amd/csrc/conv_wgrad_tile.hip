@@ -45,6 +45,7 @@ struct WgT {
   int pd, px;                        // LDS pixel-row pitches (bytes) of the dy / x tiles
   int nst, dpieces, xpieces, stage_bytes;   // wgrad_tile_dma_kernel: ring stages, 1 KB pieces of the dy / x area, (dpieces + xpieces) * 1024
   int map_mode, out_tiles;           // workgroup id -> (gradient block, pixel split): see block_of()
+  int nt;                            // LDS-DMA with the non-temporal policy (aux = 2): operands this launch reads once
   int dbg;                           // profiling only (myolo_set_option("wgrad_tile_dbg", bits)): 1 no LDS-DMA, 2 no fragment reads / MFMAs, 4 no result stores
 };
 
@@ -305,14 +306,16 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
         if (j < ndw) {
           const bool ok = ((unsigned)(oy0 + (drc[j] >> 16)) < Ho) & ((unsigned)(ox0 + (drc[j] & 0xffff)) < Wo);
           const uint64_t a = dyp + (uint64_t)(int64_t)(dbase + doff[j]);
-          __builtin_amdgcn_global_load_lds((gptr_t*)(uintptr_t)(ok ? a : zp), (lptr_t*)(sd + j * 4096), 16, 0, 0);
+          if (p.nt) __builtin_amdgcn_global_load_lds((gptr_t*)(uintptr_t)(ok ? a : zp), (lptr_t*)(sd + j * 4096), 16, 0, 2);
+          else __builtin_amdgcn_global_load_lds((gptr_t*)(uintptr_t)(ok ? a : zp), (lptr_t*)(sd + j * 4096), 16, 0, 0);
         }
 #pragma unroll
       for (int j = 0; j < DMA_MAXP; ++j)
         if (j < nxw) {
           const bool ok = ((unsigned)(iy0 + (xrc[j] >> 16)) < Hi) & ((unsigned)(ix0 + (xrc[j] & 0xffff)) < Wi);
           const uint64_t a = xp + (uint64_t)(int64_t)(xbase + xoff[j]);
-          __builtin_amdgcn_global_load_lds((gptr_t*)(uintptr_t)(ok ? a : zp), (lptr_t*)(sx + j * 4096), 16, 0, 0);
+          if (p.nt) __builtin_amdgcn_global_load_lds((gptr_t*)(uintptr_t)(ok ? a : zp), (lptr_t*)(sx + j * 4096), 16, 0, 2);
+          else __builtin_amdgcn_global_load_lds((gptr_t*)(uintptr_t)(ok ? a : zp), (lptr_t*)(sx + j * 4096), 16, 0, 0);
         }
     };
     const int ppw = ndw + nxw;
@@ -449,7 +452,8 @@ static int g_wgt_nst = -1;         // ring stages of the LDS-DMA kernel: 3, 4, 0
 static int g_wgt_min_tiles = -1;   // split-K: at least this many tiles per workgroup
 static int g_wgt_wg = -1;          // workgroups aimed at per layer
 static int g_wgt_dbg = 0;
-static int g_wgt_xcd = -1;         // 1: XCD-aware workgroup order (block_of), 0: linear
+static int g_wgt_xcd = -1;         // 1: XCD-aware workgroup order (block_of), 0: linear (default: measured neutral, profiles/r4e_wgrad_xcd_ubench.txt)
+static int g_wgt_nt = -1;          // LDS-DMA cache policy: 0 default, 1 non-temporal for 1x1 layers with one gradient block (every byte read once), 2 always
 int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_off")) { g_wgt_off = value; return 0; }
   if (!strcmp(name, "wgrad_tile_dma")) { g_wgt_dma = value; return 0; }
@@ -458,6 +462,7 @@ int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_wg")) { g_wgt_wg = value; return 0; }
   if (!strcmp(name, "wgrad_tile_dbg")) { g_wgt_dbg = value; return 0; }
   if (!strcmp(name, "wgrad_tile_xcd")) { g_wgt_xcd = value; return 0; }
+  if (!strcmp(name, "wgrad_tile_nt")) { g_wgt_nt = value; return 0; }
   return MYOLO_EINVAL;
 }
 
@@ -555,7 +560,7 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int max_ks = (k.ntiles + mt - 1) / mt;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
-  if (g_wgt_xcd < 0) g_wgt_xcd = getenv("MYOLO_WGRAD_TILE_XCD") ? atoi(getenv("MYOLO_WGRAD_TILE_XCD")) : 1;
+  if (g_wgt_xcd < 0) g_wgt_xcd = getenv("MYOLO_WGRAD_TILE_XCD") ? atoi(getenv("MYOLO_WGRAD_TILE_XCD")) : 0;
   const bool xcd_map = g_wgt_xcd && out_tiles > 1 && d->ksplit <= 0;
   if (xcd_map) {                                      // a split count the XCD-aware order can deal: a multiple of 8, or 1 / 2 / 4
     if (ks >= 8) ks = ks / 8 * 8;
@@ -572,6 +577,8 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   }
   k.ksplit = ks;
   k.out_tiles = out_tiles;
+  if (g_wgt_nt < 0) g_wgt_nt = getenv("MYOLO_WGRAD_TILE_NT") ? atoi(getenv("MYOLO_WGRAD_TILE_NT")) : 1;
+  k.nt = g_wgt_nt == 2 || (g_wgt_nt == 1 && out_tiles == 1 && k.ntaps == 1);
   k.map_mode = !xcd_map ? 0 : (ks % 8 == 0 ? 2 : ((ks == 1 || ks == 2 || ks == 4) ? 1 : 0));
   *out_ks = ks; *out_cop = CoP; *out_cip = CiP; *used_ws = k.ws != nullptr;
   hipStream_t st = (hipStream_t)stream;
