@@ -261,6 +261,38 @@ int myolo_pyramid_upsample_fwd(const myolo_tensor* xs, int count, const myolo_te
 int myolo_pyramid_upsample_bwd(const myolo_tensor* gout, const myolo_tensor* gxs, int count, const int32_t* accumulate, float* scratch,
                                void* stream);
 int myolo_adaptive_avgpool_bwd_multi(const myolo_tensor* gouts, int count, const myolo_tensor* gx, int accumulate, void* stream);
+/* ---- 1x1 Conv2d (+ train-mode BatchNorm2d) (+ activation) on a map of at most MYOLO_TINY_MAX_PIX pixels, forward and backward,
+ * ONE workgroup per layer and up to MYOLO_TINY_MAX_GROUP independent layers per launch (csrc/tiny_conv.hip).  Replaces, for
+ * PyramidPooling's four `Conv(in_channels, in_channels // 4, k=1)` on the 1x1 .. 6x6 pooled maps (models/common.py:521-537; Conv =
+ * nn.Conv2d + nn.BatchNorm2d + nn.SiLU, common.py:34-46), myolo_conv + myolo_bn_act_fwd in the forward and myolo_bn_act_bwd_reduce +
+ * myolo_bn_act_bwd_apply + the dgrad myolo_conv in the backward (autograd of the same); the weight gradient stays myolo_conv_wgrad over
+ * the `dy` the backward writes.  w: the OIHW fp32 master weight [cout][cin] (cast to the plan dtype inside, = autocast).
+ * gamma == NULL: no BatchNorm (z = conv, out = act(z)).  Constraints (else MYOLO_EINVAL): every tensor of one dtype, 16-byte aligned
+ * views; pixels <= MYOLO_TINY_MAX_PIX; cout <= 128; fp16: cin % 32 == 0, cin <= 512, cout % 16 == 0; fp32: cin <= 512. */
+#define MYOLO_TINY_MAX_PIX 1024
+#define MYOLO_TINY_MAX_GROUP 4
+typedef struct myolo_tiny_conv_desc {
+  myolo_tensor x;            /* [n,h,w,cin] */
+  myolo_tensor z;            /* [n,h,w,cout] raw conv output: written by the forward, read by the backward */
+  myolo_tensor out;          /* forward: act(bn(z)) */
+  const float* w;
+  const float* gamma;        /* BatchNorm weight / bias (fp32[cout]) or NULL */
+  const float* beta;
+  float*   running_mean;     /* updated by the forward like myolo_bn_act_fwd (may be NULL) */
+  float*   running_var;
+  int64_t* nbt;              /* num_batches_tracked += 1 (may be NULL) */
+  float*   saved;            /* fp32[2*cout]: batch mean, invstd -- forward writes, backward reads */
+  float    eps, momentum;
+  int32_t  act;
+  int32_t  gx_accumulate;    /* backward: 1 = gx += result */
+  myolo_tensor gout;         /* backward: gradient w.r.t. out */
+  myolo_tensor dy;           /* backward OUT: gradient w.r.t. z (the weight gradient's operand) */
+  myolo_tensor gx;           /* backward OUT: gradient w.r.t. x; ptr == NULL: not needed */
+  float*   dgamma;           /* += (may be NULL) */
+  float*   dbeta;
+} myolo_tiny_conv_desc;
+int myolo_tiny_conv_fwd(const myolo_tiny_conv_desc* d, int n, void* stream);
+int myolo_tiny_conv_bwd(const myolo_tiny_conv_desc* d, int n, void* stream);
 /* FFM gate: out = feat*att + feat, att [n,1,1,c] (common.py:228-229) */
 int myolo_gate_fwd(const myolo_tensor* feat, const myolo_tensor* att, const myolo_tensor* out, void* stream);
 int myolo_gate_bwd(const myolo_tensor* gout, const myolo_tensor* feat, const myolo_tensor* att,

@@ -97,6 +97,17 @@ class ProgOp(C.Structure):
                 ('a', C.c_uint64 * PROG_MAX_ARGS)]
 
 
+class TinyConvDesc(C.Structure):
+    """myolo_tiny_conv_desc (include/myolo.h): 1x1 Conv (+BatchNorm) (+activation) on a map of <= TINY_MAX_PIX pixels, one workgroup"""
+    _fields_ = [('x', Tensor), ('z', Tensor), ('out', Tensor), ('w', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p),
+                ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('nbt', C.c_void_p), ('saved', C.c_void_p),
+                ('eps', C.c_float), ('momentum', C.c_float), ('act', C.c_int32), ('gx_accumulate', C.c_int32),
+                ('gout', Tensor), ('dy', Tensor), ('gx', Tensor), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p)]
+
+
+TINY_MAX_PIX, TINY_MAX_GROUP = 1024, 4      # MYOLO_TINY_MAX_PIX, MYOLO_TINY_MAX_GROUP
+
+
 class MyoloError(RuntimeError):
     pass
 
@@ -130,6 +141,8 @@ _PROTOS = {
     'myolo_adaptive_avgpool_fwd': (C.c_int, [TP, TP, P, P]),
     'myolo_adaptive_avgpool_bwd': (C.c_int, [TP, TP, C.c_int, P]),
     'myolo_adaptive_avgpool_fwd_multi': (C.c_int, [TP, P, C.c_int, P, P]),
+    'myolo_tiny_conv_fwd': (C.c_int, [C.POINTER(TinyConvDesc), C.c_int, P]),
+    'myolo_tiny_conv_bwd': (C.c_int, [C.POINTER(TinyConvDesc), C.c_int, P]),
     'myolo_gate_fwd': (C.c_int, [TP, TP, TP, P]),
     'myolo_gate_bwd': (C.c_int, [TP, TP, TP, TP, C.c_int, P, P]),
     'myolo_gate_mul_fwd': (C.c_int, [TP, TP, TP, P]),

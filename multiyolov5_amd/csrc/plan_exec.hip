@@ -54,7 +54,7 @@ const Entry g_table[] = {
     REG(myolo_pyramid_upsample_fwd), REG(myolo_pyramid_upsample_bwd), REG(myolo_gate_fwd), REG(myolo_gate_bwd),
     REG(myolo_gate_mul_fwd), REG(myolo_gate_mul_bwd), REG(myolo_add), REG(myolo_fill_zero), REG(myolo_cast_from_f32),
     REG(myolo_dropout_fwd), REG(myolo_dropout_bwd), REG(myolo_seg_upsample_fwd), REG(myolo_seg_upsample_bwd),
-    REG(myolo_seg_lowgrad_apply), REG(myolo_detect_unpermute), REG(myolo_detect_decode),
+    REG(myolo_seg_lowgrad_apply), REG(myolo_detect_unpermute), REG(myolo_detect_decode), REG(myolo_tiny_conv_fwd), REG(myolo_tiny_conv_bwd),
 };
 #undef REG
 constexpr int NFN = (int)(sizeof(g_table) / sizeof(g_table[0]));

@@ -34,6 +34,9 @@ WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
 # round 4: the BatchNorm-backward apply pass of a 1x1 stride-1 Conv+BatchNorm layer rides in the operand path of the layer's own dgrad
 # (myolo_conv_dgrad_bn, csrc/conv_mid.hip): one launch instead of two, dy still written for the weight gradient.  =0: the two-launch form
 BN_APPLY_FOLD = os.environ.get('MYOLO_BN_APPLY_FOLD', '1') != '0'
+# 1x1 Conv+BatchNorm+activation layers on maps of <= 1024 pixels (PyramidPooling's branches): one workgroup per layer, the layers of a
+# module in ONE forward and ONE backward launch (csrc/tiny_conv.hip) instead of 2 + 3 launches per layer
+TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '0') != '0'
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -304,6 +307,7 @@ class ConvOp(Op):
         self.zero_first = []
         self.res_acc = 0
         self.reduce_by = None        # the op whose dgrad launch produces this layer's BatchNorm-backward sums (else: own reduce launch)
+        self.group = None            # tiny maps: the ConvOps sharing one myolo_tiny_conv_fwd / _bwd launch, forward order (Plan._plan_tiny_groups)
         self.bnb_targets = []        # [(layer op, c0, c1)]: BatchNorm layers whose output gradient this op's dgrad completes
 
     def grad_io(self):
@@ -326,8 +330,72 @@ class ConvOp(Op):
             self.acc_x, z = claim(self.x, writer=self)
             self.zero_first += [(self.x, a, b) for a, b in z]
 
+    def tiny_ok(self, plan):
+        """the conditions of myolo_tiny_conv_fwd / _bwd (include/myolo.h): a 1x1 Conv(+BatchNorm)(+activation) a single workgroup holds"""
+        if not (TINY_CONV and plan.training) or self.k != 1 or self.s != 1 or self.res is not None or self.det or self.weight2 is not None:
+            return False
+        if self.bias is not None or self.sync_world > 1 or (self.bn is None and self.act == L.ACT_NONE):
+            return False
+        x, o, w = self.x, self.out, self.weight
+        if x.n * x.h * x.w > L.TINY_MAX_PIX or (x.n, x.h, x.w) != (o.n, o.h, o.w) or x.c != self.cin or o.c != self.cout:
+            return False
+        if w.dtype != torch.float32 or not w.is_contiguous() or self.cout > 128 or self.cin > 512:
+            return False
+        if plan.dtype == torch.float16:
+            return self.cin % 32 == 0 and self.cout % 16 == 0
+        return self.cin % 4 == 0 and self.cout % 4 == 0
+
+    def _build_tiny(self, plan):
+        """this layer's descriptor (forward AND backward fields); the group's LAST member (forward order) issues both launches: every
+        member's input exists by then, and in the backward it comes first -- the consumers of every member's output ran before it"""
+        dt, dev, g = plan.dtype, plan.device, self.group
+        bn = self.bn
+        self.yraw = Buf(self.out.n, self.out.h, self.out.w, self.cout, dt)
+        self.yraw.alloc(dev, False)
+        yv = TV(plan, *self.yraw.t.shape)
+        yv.place(self.yraw, 0)
+        self.yv = yv
+        self.dy = Buf(self.out.n, self.out.h, self.out.w, self.cout, dt)
+        self.dy.alloc(dev, False)
+        dyv = TV(plan, *self.dy.t.shape)
+        dyv.place(self.dy, 0)
+        d = self.tdesc = L.TinyConvDesc()
+        d.x, d.z, d.out, d.w = self.x.desc(), yv.desc(), self.out.desc(), self.weight.data_ptr()
+        d.act, d.gx_accumulate = self.act, int(self.acc_x)
+        if bn is not None:
+            self.saved = torch.zeros(2 * self.cout, dtype=torch.float32, device=dev)
+            d.gamma, d.beta, d.saved = bn.weight.data_ptr(), bn.bias.data_ptr(), self.saved.data_ptr()
+            d.running_mean, d.running_var, d.nbt = bn.running_mean.data_ptr(), bn.running_var.data_ptr(), bn.num_batches_tracked.data_ptr()
+            d.eps, d.momentum = bn.eps, bn.momentum
+            d.dgamma, d.dbeta = plan.pgrad(bn.weight).data_ptr(), plan.pgrad(bn.bias).data_ptr()
+        d.gout, d.dy = self.out.desc(grad=True), dyv.desc()
+        d.gx = self.x.desc(grad=True) if self.x.requires_grad else null_tensor()
+        self.dy_desc = dyv.desc()
+        calls = self.bwd_calls
+        if self is g[-1]:
+            self.tarr = (L.TinyConvDesc * len(g))(*[o.tdesc for o in g])
+            self.fwd_calls.append(Call('myolo_tiny_conv_fwd', (self.tarr, len(g)), keep=[(o.bn, o.weight) for o in g]))
+            for o in g:
+                for tv, a, b in o.zero_first:
+                    z = TV(plan, tv.n, tv.h, tv.w, b - a)
+                    z.place(tv.buf, a)
+                    zd = z.desc(grad=True)
+                    calls.append(Call('myolo_fill_zero', (C.byref(zd),), keep=zd))
+            calls.append(Call('myolo_tiny_conv_bwd', (self.tarr, len(g))))
+        wd = L.WgradDesc()
+        wd.x, wd.dy = self.x.desc(), self.dy_desc
+        wd.dw, wd.db = plan.pgrad(self.weight).data_ptr(), None
+        wd.ntaps, wd.stride, wd.up_shift, wd.ksplit, wd.cout, wd.cin = 1, 1, 0, 0, self.cout, self.cin
+        ws = plan.wgrad_workspace()
+        wd.ws, wd.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        fill_taps(wd, *taps_fwd(1, 1, 0)[:2])
+        self.wds, self.wd = [wd], wd
+        calls.append(Call('myolo_conv_wgrad', (C.byref(wd),), side=True))
+
     def build(self, plan):
         super().build(plan)
+        if self.group:
+            return self._build_tiny(plan)
         dt = plan.dtype
         seg, kc = SEG[dt], KC[dt]
         dev = plan.device
@@ -1256,6 +1324,7 @@ class Plan:
                 op.plan_bwd(self)
             self._claiming = None
             self._check_group_claims()
+            self._plan_tiny_groups()
             self._plan_bn_stats()
         self._pg_first_op = {}
         for i, op in enumerate(self.ops):
@@ -1277,6 +1346,36 @@ class Plan:
         if torch.device(self.device).type == 'cuda':     # a CPU-device plan is a dry build (shape/launch-list checks only)
             self.prepare()
 
+    def _plan_tiny_groups(self):
+        """1x1 Conv+BatchNorm+activation layers on tiny maps (ConvOp.tiny_ok) leave the conv / BatchNorm launch chain: one workgroup per
+        layer (myolo_tiny_conv_fwd / _bwd).  Up to four of them share a launch when nothing that runs between the first and the last
+        depends on one of them: PyramidPooling's pool -> conv -> upsample triples (common.py:521-537) qualify when the four upsamples
+        are one fused launch at the last of them (BilinearOp._group_fused) -- then every op between two member convs is a pool, or an
+        upsample that launches nothing at its own position."""
+        if not TINY_CONV:
+            return
+        ops = self.ops
+        cand = [i for i, op in enumerate(ops) if isinstance(op, ConvOp) and op.tiny_ok(self)]
+        k = 0
+        while k < len(cand):
+            grp = [cand[k]]
+            while len(grp) < L.TINY_MAX_GROUP and k + len(grp) < len(cand):
+                j = cand[k + len(grp)]
+                between = ops[grp[-1] + 1:j]
+                free = all(isinstance(o, AvgPoolOp) or (isinstance(o, BilinearOp) and o.group is not None and o is not o.group[-1] and
+                                                        o._group_fused(self) and o._group_fused(self, training=False)) for o in between)
+                prior = [ops[i].out for i in grp]
+
+                def touches(tv):      # does tv alias the output of an earlier member?
+                    return any(tv.buf is o.buf and tv.coff < o.coff + o.c and o.coff < tv.coff + tv.c for o in prior)
+                if not free or touches(ops[j].x) or any(isinstance(o, AvgPoolOp) and touches(o.src) for o in between):
+                    break
+                grp.append(j)
+            members = [ops[i] for i in grp]
+            for o in members:
+                o.group = members
+            k += len(grp)
+
     def _plan_bn_stats(self):
         """fold `bn_act_bwd_reduce` of a Conv+BatchNorm layer into the dgrad launch that writes the LAST contribution to its output
         gradient (the values are final in that launch's epilogue): possible when that last writer is a convolution's dgrad covering
@@ -1285,7 +1384,7 @@ class Plan:
             return                                                     # 10.34 vs 10.41 ms, before the chain lost ~70 launches); =0 keeps every reduce launch
         max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
         for op in self.ops:
-            if not isinstance(op, ConvOp) or op.bn is None or op.det or op.bn2 is not None:
+            if not isinstance(op, ConvOp) or op.bn is None or op.det or op.bn2 is not None or op.group:
                 continue
             o = op.out
             if o.n * o.h * o.w * o.c > max_elems:      # big maps: the separate reduce pass streams at 3-4 TB/s, cheaper than 8-byte epilogue loads
@@ -1295,7 +1394,7 @@ class Plan:
             if not ws:
                 continue
             a, z, w = ws[-1]
-            if not isinstance(w, ConvOp) or w is op or a > lo or z < hi or len(w.bnb_targets) >= 4:
+            if not isinstance(w, ConvOp) or w is op or a > lo or z < hi or len(w.bnb_targets) >= 4 or w.group:
                 continue
             if (w.x.n, w.x.h, w.x.w) != (o.n, o.h, o.w) or w.x.buf is not o.buf:
                 continue

@@ -38,7 +38,7 @@ def test_struct_layouts_match_header():
         src = ('#include <stdio.h>\n#include <stddef.h>\n#include "myolo.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(myolo_tensor), '
                'sizeof(myolo_conv_desc), sizeof(myolo_wgrad_desc), offsetof(myolo_conv_desc, scale), offsetof(myolo_conv_desc, res), '
                'offsetof(myolo_wgrad_desc, ws));printf("%zu %zu %zu\\n", sizeof(myolo_bn_bwd_seg), offsetof(myolo_conv_desc, bnb), '
-               'offsetof(myolo_bn_bwd_seg, dsum));printf("%zu %zu %zu %zu\\n", sizeof(myolo_bn_split), offsetof(myolo_bn_split, dbeta2), sizeof(myolo_seg_sync_desc), offsetof(myolo_seg_sync_desc, lab_lut));printf("%zu %zu %zu\\n", sizeof(myolo_mosaic_desc), offsetof(myolo_mosaic_desc, M), offsetof(myolo_mosaic_desc, out_hwc));printf("%zu %zu %zu\\n", sizeof(myolo_prog_op), offsetof(myolo_prog_op, cond), offsetof(myolo_prog_op, a));return 0;}\n')
+               'offsetof(myolo_bn_bwd_seg, dsum));printf("%zu %zu %zu %zu\\n", sizeof(myolo_bn_split), offsetof(myolo_bn_split, dbeta2), sizeof(myolo_seg_sync_desc), offsetof(myolo_seg_sync_desc, lab_lut));printf("%zu %zu %zu\\n", sizeof(myolo_mosaic_desc), offsetof(myolo_mosaic_desc, M), offsetof(myolo_mosaic_desc, out_hwc));printf("%zu %zu %zu\\n", sizeof(myolo_prog_op), offsetof(myolo_prog_op, cond), offsetof(myolo_prog_op, a));printf("%zu %zu %zu %zu\\n", sizeof(myolo_tiny_conv_desc), offsetof(myolo_tiny_conv_desc, eps), offsetof(myolo_tiny_conv_desc, gout), offsetof(myolo_tiny_conv_desc, dbeta));return 0;}\n')
         with tempfile.TemporaryDirectory() as td:
             open(os.path.join(td, 'a.c'), 'w').write(src)
             inc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')
@@ -49,7 +49,9 @@ def test_struct_layouts_match_header():
                          ctypes.sizeof(_lib.BnBwdSeg), _lib.ConvDesc.bnb.offset, _lib.BnBwdSeg.dsum.offset,
                          ctypes.sizeof(_lib.BnSplit), _lib.BnSplit.dbeta2.offset, ctypes.sizeof(_lib.SegSyncDesc),
                          _lib.SegSyncDesc.lab_lut.offset, ctypes.sizeof(_lib.MosaicDesc), _lib.MosaicDesc.M.offset,
-                         _lib.MosaicDesc.out_hwc.offset, ctypes.sizeof(_lib.ProgOp), _lib.ProgOp.cond.offset, _lib.ProgOp.a.offset], sizes
+                         _lib.MosaicDesc.out_hwc.offset, ctypes.sizeof(_lib.ProgOp), _lib.ProgOp.cond.offset, _lib.ProgOp.a.offset,
+                         ctypes.sizeof(_lib.TinyConvDesc), _lib.TinyConvDesc.eps.offset, _lib.TinyConvDesc.gout.offset,
+                         _lib.TinyConvDesc.dbeta.offset], sizes
     # the native executor rejects a malformed program on the host: unknown function id, wrong argument count, unknown kind
     bad = _lib.ProgOp()
     bad.kind, bad.fn, bad.nargs = _lib.OP_CALL, 10 ** 6, 1
@@ -64,6 +66,8 @@ def test_struct_layouts_match_header():
     assert _lib.lib().myolo_conv(ctypes.byref(d), None) == -22
     w = _lib.WgradDesc()
     assert _lib.lib().myolo_conv_wgrad(ctypes.byref(w), None) == -22
+    t = (_lib.TinyConvDesc * 1)()
+    assert _lib.lib().myolo_tiny_conv_fwd(t, 1, None) == -22 and _lib.lib().myolo_tiny_conv_bwd(t, 0, None) == -22
 
 
 @pytest.mark.parametrize('tag', list(TAGS))

@@ -1,0 +1,165 @@
+"""-m gpu: csrc/tiny_conv.hip through the raw C ABI (`myolo_tiny_conv_fwd` / `_bwd`, myolo.h): 1x1 Conv2d + train-mode BatchNorm2d +
+activation on the pooled maps of PyramidPooling (reference models/common.py:521-537; Conv = common.py:34-46), one workgroup per layer,
+up to four layers per launch -- against torch on the CPU in fp32 over the SAME storage-rounded inputs: outputs, saved statistics,
+running statistics, num_batches_tracked, the gradient w.r.t. the input (plain and accumulated), dgamma / dbeta (accumulated), and the
+`dy` the weight-gradient launch consumes.  fp32 plans: 2e-4 (parity mode, scalar loops); fp16 plans: the oracle runs on the fp16-rounded
+x and weights and rounds its raw output to fp16 like the product does -- 4e-3 on fp16 tensors (one rounding of the result)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import check
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _td(L, t, dt):
+    n, h, w, c = t.shape
+    sn, sh, sw, _ = t.stride()
+    return L.Tensor(t.data_ptr(), n, h, w, c, sn, sh, sw, L.DT[dt], 0)
+
+
+def _act(z, act):
+    return F.silu(z) if act == 1 else (torch.sigmoid(z) if act == 2 else z)
+
+
+class _Layer:
+    """one layer's tensors on the device + its CPU reference"""
+
+    def __init__(self, L, n, h, w, cin, cout, bn, act, accumulate, need_gx=True, sliced=False, *, dt, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.bn, self.act, self.dt, self.accumulate, self.need_gx = bn, act, dt, accumulate, need_gx
+        self.x = (torch.randn(n, h, w, cin, generator=g) * 0.7 + 0.1).to(dt)
+        self.w = torch.randn(cout, cin, 1, 1, generator=g) * (1.5 / cin ** 0.5)
+        self.gamma, self.beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        self.rm0, self.rv0 = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+        self.gout = (torch.randn(n, h, w, cout, generator=g) * 0.05).to(dt)
+        self.gx0 = (torch.randn(n, h, w, cin, generator=g) * 0.02).to(dt)
+        self.dg0, self.db0 = torch.randn(cout, generator=g) * 0.01, torch.randn(cout, generator=g) * 0.01
+        self.eps, self.mom = 1e-3, 0.03
+        dev = lambda t: t.to(DEV).contiguous()
+        self.xd, self.wd, self.goutd = dev(self.x), dev(self.w), dev(self.gout)
+        if sliced:          # out / gx as channel slices of wider buffers (a plan's concat-free views)
+            self.obuf = torch.zeros(n, h, w, cout + 16, dtype=dt, device=DEV)
+            self.outd = self.obuf[..., 8:8 + cout]
+            self.gbuf = torch.zeros(n, h, w, cin + 8, dtype=dt, device=DEV)
+            self.gbuf[..., 8:] = self.gx0.to(DEV)
+            self.gxd = self.gbuf[..., 8:]
+        else:
+            self.outd = torch.zeros(n, h, w, cout, dtype=dt, device=DEV)
+            self.gxd = dev(self.gx0)
+        self.zd = torch.zeros(n, h, w, cout, dtype=dt, device=DEV)
+        self.dyd = torch.zeros(n, h, w, cout, dtype=dt, device=DEV)
+        self.gammad, self.betad, self.rmd, self.rvd = dev(self.gamma), dev(self.beta), dev(self.rm0), dev(self.rv0)
+        self.nbtd = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+        self.savedd = torch.zeros(2 * cout, device=DEV)
+        self.dgd, self.dbd = dev(self.dg0), dev(self.db0)
+        d = self.desc = L.TinyConvDesc()
+        d.x, d.z, d.out, d.w = _td(L, self.xd, dt), _td(L, self.zd, dt), _td(L, self.outd, dt), self.wd.data_ptr()
+        if bn:
+            d.gamma, d.beta, d.saved = self.gammad.data_ptr(), self.betad.data_ptr(), self.savedd.data_ptr()
+            d.running_mean, d.running_var, d.nbt = self.rmd.data_ptr(), self.rvd.data_ptr(), self.nbtd.data_ptr()
+            d.dgamma, d.dbeta = self.dgd.data_ptr(), self.dbd.data_ptr()
+        d.eps, d.momentum, d.act, d.gx_accumulate = self.eps, self.mom, act, int(accumulate)
+        d.gout, d.dy = _td(L, self.goutd, dt), _td(L, self.dyd, dt)
+        if need_gx:
+            d.gx = _td(L, self.gxd, dt)
+
+    def reference(self):
+        """torch fp32 on the storage-rounded operands; the raw conv output rounded to the storage type before BatchNorm (the product
+        normalises the z it stored; the batch statistics come from the unrounded accumulators)"""
+        dt = self.dt
+        x = self.x.float().permute(0, 3, 1, 2).requires_grad_(True)
+        w = (self.w.to(dt).float() if dt == torch.float16 else self.w.clone()).requires_grad_(True)
+        zfull = F.conv2d(x, w)
+        z = zfull + (zfull.detach().to(dt).float() - zfull.detach())          # value = rounded z, gradient = identity
+        r = {}
+        if self.bn:
+            gamma, beta = self.gamma.clone().requires_grad_(True), self.beta.clone().requires_grad_(True)
+            mean = zfull.detach().mean((0, 2, 3))
+            var = zfull.detach().var((0, 2, 3), unbiased=False)
+            cnt = zfull.numel() // zfull.shape[1]
+            # BatchNorm with the statistics of the unrounded z applied to the rounded z: write it out so that autograd differentiates
+            # through mean / var of z exactly like nn.BatchNorm2d (train mode) does
+            zm = z.mean((0, 2, 3), keepdim=True)
+            zv = z.var((0, 2, 3), unbiased=False, keepdim=True)
+            y = (z - zm) / torch.sqrt(zv + self.eps) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)
+            r['mean'], r['invstd'] = mean, 1.0 / torch.sqrt(var + self.eps)
+            r['rm'] = (1 - self.mom) * self.rm0 + self.mom * mean
+            r['rv'] = (1 - self.mom) * self.rv0 + self.mom * var * (cnt / max(cnt - 1, 1))
+        else:
+            y = z
+        out = _act(y, self.act)
+        out.backward(self.gout.float().permute(0, 3, 1, 2))
+        r['z'], r['out'] = zfull.detach().permute(0, 2, 3, 1), out.detach().permute(0, 2, 3, 1)
+        r['gx'] = x.grad.permute(0, 2, 3, 1) + (self.gx0.float() if self.accumulate else 0)
+        r['dw'] = w.grad
+        if self.bn:
+            r['dgamma'], r['dbeta'] = gamma.grad + self.dg0, beta.grad + self.db0
+        return r
+
+
+def _run(layers_spec, dt, seed=0):
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    layers = [_Layer(L, *sp, dt=dt, seed=seed + 7 * i) for i, sp in enumerate(layers_spec)]
+    arr = (L.TinyConvDesc * len(layers))(*[l.desc for l in layers])
+    L.check(lib.myolo_tiny_conv_fwd(arr, len(layers), L.stream_ptr()), 'myolo_tiny_conv_fwd')
+    L.check(lib.myolo_tiny_conv_bwd(arr, len(layers), L.stream_ptr()), 'myolo_tiny_conv_bwd')
+    torch.cuda.synchronize()
+    tol = 2e-4 if dt == torch.float32 else 4e-3
+    bad = []
+    for i, l in enumerate(layers):
+        r = l.reference()
+        tag = f'tiny/{i}:{tuple(l.x.shape)}->{l.outd.shape[-1]} bn{int(l.bn)} act{l.act} {str(dt)[6:]}'
+        check(tag + '/z', l.zd, r['z'], tol, collect=bad)
+        check(tag + '/out', l.outd, r['out'], tol, collect=bad)
+        if l.bn:
+            check(tag + '/saved_mean', l.savedd[:l.gamma.numel()], r['mean'], 1e-4, collect=bad)
+            check(tag + '/saved_invstd', l.savedd[l.gamma.numel():], r['invstd'], 1e-4, collect=bad)
+            check(tag + '/running_mean', l.rmd, r['rm'], 1e-5, collect=bad)
+            check(tag + '/running_var', l.rvd, r['rv'], 1e-5, collect=bad)
+            assert int(l.nbtd) == 6
+            check(tag + '/dgamma', l.dgd, r['dgamma'], 5e-3 if dt == torch.float16 else 2e-4, collect=bad)
+            check(tag + '/dbeta', l.dbd, r['dbeta'], 5e-3 if dt == torch.float16 else 2e-4, collect=bad)
+        if l.need_gx:
+            check(tag + '/gx', l.gxd, r['gx'], 8e-3 if dt == torch.float16 else 2e-4, collect=bad)
+        # dy is what the weight-gradient launch contracts with x: dW = dy^T x must be the autograd weight gradient
+        dw = torch.einsum('nhwo,nhwi->oi', l.dyd.float().cpu(), l.x.float())
+        check(tag + '/dy (through dW)', dw, r['dw'].reshape(dw.shape), 8e-3 if dt == torch.float16 else 2e-4, collect=bad)
+    assert not bad, '\n'.join(bad)
+
+
+# (n, h, w, cin, cout, bn, act, accumulate[, need_gx, sliced])
+PSP = [(16, 1, 1, 128, 32, True, 1, False), (16, 2, 2, 128, 32, True, 1, False), (16, 3, 3, 128, 32, True, 1, True), (16, 6, 6, 128, 32, True, 1, False)]
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.float32], ids=['f16', 'f32'])
+def test_pyramid_branch_group_matches_autograd(dt):
+    """the four PyramidPooling branches of yolov5s+PSP at batch 16 (common.py:521-537) in one launch each way"""
+    _run(PSP, dt)
+
+
+@pytest.mark.parametrize('dt', [torch.float16, torch.float32], ids=['f16', 'f32'])
+def test_single_layers_and_views(dt):
+    _run([(2, 6, 6, 128, 32, True, 1, True, True, True)], dt, seed=3)        # out / gx are channel slices of wider buffers, gx accumulates
+    _run([(16, 1, 1, 128, 128, False, 1, False)], dt, seed=4)                # FFM attention: bare conv + SiLU (common.py:218-224)
+    _run([(16, 1, 1, 128, 128, False, 2, True)], dt, seed=5)                 # ... + Sigmoid
+    _run([(4, 16, 16, 64, 64, True, 2, False)], dt, seed=6)                  # 1024 pixels (the limit), BatchNorm + Sigmoid (BiSe ARM, common.py:183-200)
+    _run([(3, 5, 7, 256, 48, True, 0, False)], dt, seed=7)                   # ragged pixel count, BatchNorm without activation, cout 48
+    _run([(2, 3, 3, 512, 16, True, 1, False, False)], dt, seed=8)            # cin 512 (16 K steps), no input gradient wanted
+
+
+def test_rejects_what_it_cannot_hold():
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+    l = _Layer(L, 5, 16, 16, 64, 32, True, 1, False, dt=torch.float16, seed=0)      # 1280 pixels
+    arr = (L.TinyConvDesc * 1)(l.desc)
+    assert lib.myolo_tiny_conv_fwd(arr, 1, L.stream_ptr()) == L.EINVAL
+    l = _Layer(L, 2, 2, 2, 48, 32, True, 1, False, dt=torch.float16, seed=0)        # cin % 32 != 0 in fp16
+    arr = (L.TinyConvDesc * 1)(l.desc)
+    assert lib.myolo_tiny_conv_fwd(arr, 1, L.stream_ptr()) == L.EINVAL
+    assert lib.myolo_tiny_conv_bwd(arr, 5, L.stream_ptr()) == L.EINVAL                          # more than MYOLO_TINY_MAX_GROUP layers

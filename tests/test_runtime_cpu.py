@@ -253,3 +253,57 @@ def test_staged_backward_marks_address_pruned_programs():
     md, nd = marks(plan._bwd_items(cuts, frozenset(h.ospec.det_slots)))
     assert set(mf) == set(md) and nd < nf and all(md[k] <= mf[k] for k in mf)
     assert [md[k] for k in sorted(md)] == sorted(md[k] for k in md)
+
+
+def test_tiny_conv_groups_leave_the_launch_chain(monkeypatch):
+    """MYOLO_TINY_CONV=1: PyramidPooling's four branch Conv+BatchNorm+SiLU layers (common.py:521-537) become ONE forward and ONE backward
+    launch (csrc/tiny_conv.hip) at the last branch; dependent tiny layers (FFM's two attention convs, common.py:218-224) stay separate
+    launches; the pruned one-loss schedules remain valid; fp32 plans, whose four upsamples are not one launch, do not group"""
+    from multiyolov5_amd import engine as E
+    monkeypatch.setattr(E, 'TINY_CONV', True)
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.models.yolo import Model
+
+    def _plan(dt=torch.float16):           # the bench shape (BASELINE configs[1]): at 64 x 128 most of the network is "tiny"
+        m = Model(os.path.join(CFG, TAGS['s_psp'])).train()
+        return R.PlanHolder(m, [torch.zeros(16, 3, 512, 1024)], ('t', 0), dt, True)
+    holder = _plan()
+    plan = holder.plan
+    groups, seen = [], set()
+    for op in plan.ops:
+        if isinstance(op, E.ConvOp) and op.group and id(op.group) not in seen:
+            seen.add(id(op.group))
+            groups.append(op.group)
+    sizes = sorted(len(g) for g in groups)
+    assert sizes == [1, 1, 4], sizes
+    psp = next(g for g in groups if len(g) == 4)
+    assert [o.x.h for o in psp] == [1, 2, 3, 6] and all(o.bn is not None and o.cout == 32 for o in psp)
+    fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
+    bwd = Counter(c.name for op in plan.ops for c in op.bwd_calls)
+    assert fwd['myolo_tiny_conv_fwd'] == 3 and bwd['myolo_tiny_conv_bwd'] == 3
+    # only the last member launches; every member keeps its own weight-gradient launch; no member is a BatchNorm-sum carrier or target
+    for g in groups:
+        for o in g:
+            names = [c.name for c in o.bwd_calls]
+            assert names.count('myolo_conv_wgrad') == 1 and (('myolo_tiny_conv_bwd' in names) == (o is g[-1]))
+            assert [c.name for c in o.fwd_calls] == (['myolo_tiny_conv_fwd'] if o is g[-1] else [])
+            assert o.reduce_by is None and not o.bnb_targets
+            assert not any(n.startswith('myolo_bn_act') or n == 'myolo_conv' for n in names)
+    # the launch of a group sits behind every member's zero fills and the members are pruned / kept together
+    pos = {id(op): i for i, op in enumerate(plan.ops)}
+    assert all(pos[id(g[-1])] == max(pos[id(o)] for o in g) for g in groups)
+    det = frozenset(holder.ospec.det_slots)
+    for live in (det, frozenset(range(len(holder.ospec.det_slots) + 1)) - det):
+        sched = plan.bwd_schedule(live)
+        assert isinstance(sched, list) and plan.check_bwd_schedule(sched) == []
+        kept = {e[1] for e in sched if e[0] == 'op'}
+        for g in groups:
+            assert len({pos[id(o)] in kept for o in g}) == 1
+    # the same model with the flag off has 9 forward / 13 backward launches more (8 -> 1 and 12 -> 1 for the pyramid, 2 x (2 -> 1) each way for FFM)
+    nf, nb = sum(len(o.fwd_calls) for o in plan.ops), sum(len(o.bwd_calls) for o in plan.ops)
+    monkeypatch.setattr(E, 'TINY_CONV', False)
+    off = _plan().plan
+    assert sum(len(o.fwd_calls) for o in off.ops) - nf == 9 and sum(len(o.bwd_calls) for o in off.ops) - nb == 13
+    monkeypatch.setattr(E, 'TINY_CONV', True)
+    p32 = _plan(dt=torch.float32).plan
+    assert sorted(len(o.group) for o in p32.ops if isinstance(o, E.ConvOp) and o.group) == [1] * 6
