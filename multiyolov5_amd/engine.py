@@ -341,9 +341,17 @@ class ConvOp(Op):
             return False
         if w.dtype != torch.float32 or not w.is_contiguous() or self.cout > 128 or self.cin > 512:
             return False
+        # the workgroup's LDS: 6 floats per output channel + the weights (tiny_check, csrc/tiny_conv.hip): forward [cout][cin + 8] halves /
+        # [cout][cin] floats, backward [cin][cout rounded up to 32, + 8] halves / [cout][cin] floats; <= 150 KB
         if plan.dtype == torch.float16:
-            return self.cin % 32 == 0 and self.cout % 16 == 0
-        return self.cin % 4 == 0 and self.cout % 4 == 0
+            if self.cin % 32 or self.cout % 16:
+                return False
+            wb = max(self.cout * (self.cin + 8), self.cin * (rup(self.cout, 32) + 8)) * 2
+        else:
+            if self.cin % 4 or self.cout % 4:
+                return False
+            wb = self.cout * self.cin * 4
+        return 24 * self.cout + wb <= 150 * 1024
 
     def _build_tiny(self, plan):
         """this layer's descriptor (forward AND backward fields); the group's LAST member (forward order) issues both launches: every
@@ -1365,10 +1373,12 @@ class Plan:
                 free = all(isinstance(o, AvgPoolOp) or (isinstance(o, BilinearOp) and o.group is not None and o is not o.group[-1] and
                                                         o._group_fused(self) and o._group_fused(self, training=False)) for o in between)
                 prior = [ops[i].out for i in grp]
+                prior_x = [ops[i].x for i in grp]
 
-                def touches(tv):      # does tv alias the output of an earlier member?
-                    return any(tv.buf is o.buf and tv.coff < o.coff + o.c and o.coff < tv.coff + tv.c for o in prior)
-                if not free or touches(ops[j].x) or any(isinstance(o, AvgPoolOp) and touches(o.src) for o in between):
+                def touches(tv, others=prior):      # does tv alias the output (the input) of an earlier member?
+                    return any(tv.buf is o.buf and tv.coff < o.coff + o.c and o.coff < tv.coff + tv.c for o in others)
+                # (two members reading the SAME tensor would add their input gradients into one range from two workgroups at once)
+                if not free or touches(ops[j].x) or touches(ops[j].x, prior_x) or touches(ops[j].out) or any(isinstance(o, AvgPoolOp) and touches(o.src) for o in between):
                     break
                 grp.append(j)
             members = [ops[i] for i in grp]

@@ -307,3 +307,33 @@ def test_tiny_conv_groups_leave_the_launch_chain(monkeypatch):
     monkeypatch.setattr(E, 'TINY_CONV', True)
     p32 = _plan(dt=torch.float32).plan
     assert sorted(len(o.group) for o in p32.ops if isinstance(o, E.ConvOp) and o.group) == [1] * 6
+
+
+@pytest.mark.parametrize('res', [(2, 64, 128), (16, 512, 1024)], ids=['64x128', '512x1024'])
+@pytest.mark.parametrize('tag', list(TAGS))
+def test_every_tiny_conv_launch_passes_the_librarys_host_checks(tag, res, monkeypatch):
+    """engine.ConvOp.tiny_ok mirrors tiny_check (csrc/tiny_conv.hip): every descriptor array a plan builds is accepted by the entry
+    points' host-side validation (no GPU: an accepted call fails later, at the launch, with a HIP error -- never MYOLO_EINVAL); no two
+    members of a group read the same tensor (their input gradients would race) or depend on each other"""
+    from multiyolov5_amd import engine as E, runtime as R, _lib as L
+    from multiyolov5_amd.models.yolo import Model
+    monkeypatch.setattr(E, 'TINY_CONV', True)
+    lib = L.lib()
+    m = Model(os.path.join(CFG, TAGS[tag])).train()
+    for dt in (torch.float16, torch.float32):
+        plan = R.PlanHolder(m, [torch.zeros(res[0], 3, res[1], res[2])], ('t', 0), dt, True).plan
+        n = 0
+        for op in plan.ops:
+            for calls, fn in ((op.fwd_calls, 'myolo_tiny_conv_fwd'), (op.bwd_calls, 'myolo_tiny_conv_bwd')):
+                for c in calls:
+                    if getattr(c, 'name', '') == fn:
+                        n += 1
+                        assert getattr(lib, fn)(c.args[0], c.args[1], None) != L.EINVAL, (tag, dt, fn, op.cin, op.cout)
+            g = op.group if isinstance(op, E.ConvOp) else None
+            if g and op is g[-1]:
+                def overlap(a, b):
+                    return a.buf is b.buf and a.coff < b.coff + b.c and b.coff < a.coff + a.c
+                for i, a in enumerate(g):
+                    for b in g[i + 1:]:
+                        assert not overlap(a.x, b.x) and not overlap(b.x, a.out) and not overlap(a.out, b.out)
+        assert n % 2 == 0
