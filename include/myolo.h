@@ -291,6 +291,9 @@ typedef struct myolo_tiny_conv_desc {
   float*   dgamma;           /* += (may be NULL) */
   float*   dbeta;
 } myolo_tiny_conv_desc;
+/* 1 when a layer of this shape fits the kernels (pixel / channel limits and the workgroup's LDS, forward and backward), else 0: what a
+ * planner asks before it takes a layer off the myolo_conv / myolo_bn_act_* chain (engine.ConvOp.tiny_ok) */
+int myolo_tiny_conv_ok(int dtype, int pixels, int cin, int cout);
 int myolo_tiny_conv_fwd(const myolo_tiny_conv_desc* d, int n, void* stream);
 int myolo_tiny_conv_bwd(const myolo_tiny_conv_desc* d, int n, void* stream);
 /* FFM gate: out = feat*att + feat, att [n,1,1,c] (common.py:228-229) */

@@ -141,6 +141,7 @@ _PROTOS = {
     'myolo_adaptive_avgpool_fwd': (C.c_int, [TP, TP, P, P]),
     'myolo_adaptive_avgpool_bwd': (C.c_int, [TP, TP, C.c_int, P]),
     'myolo_adaptive_avgpool_fwd_multi': (C.c_int, [TP, P, C.c_int, P, P]),
+    'myolo_tiny_conv_ok': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
     'myolo_tiny_conv_fwd': (C.c_int, [C.POINTER(TinyConvDesc), C.c_int, P]),
     'myolo_tiny_conv_bwd': (C.c_int, [C.POINTER(TinyConvDesc), C.c_int, P]),
     'myolo_gate_fwd': (C.c_int, [TP, TP, TP, P]),

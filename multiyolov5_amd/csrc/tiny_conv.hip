@@ -335,33 +335,37 @@ inline bool tv_ok(const myolo_tensor& t, int dtype, int seg) {
 }
 inline bool same_pix(const myolo_tensor& a, const myolo_tensor& b) { return a.n == b.n && a.h == b.h && a.w == b.w; }
 
+constexpr int TINY_LDS_MAX = 150 * 1024;
+// dynamic LDS bytes of a layer (per-channel tables + weights), -1 when its shape is outside what the kernels hold
+int tiny_lds(int dtype, int64_t P, int Cin, int Cout, bool bwd, bool with_gx) {
+  if (dtype != MYOLO_F16 && dtype != MYOLO_F32) return -1;
+  if (P < 1 || P > MYOLO_TINY_MAX_PIX || Cin < 1 || Cin > 32 * KSMAX || Cout < 1 || Cout > 128) return -1;
+  if (dtype == MYOLO_F16 ? (Cin % 32 || Cout % 16) : (Cin % 4 || Cout % 4)) return -1;
+  int wbytes;
+  if (!bwd) wbytes = dtype == MYOLO_F16 ? Cout * (Cin + 8) * 2 : Cout * Cin * 4;
+  else wbytes = !with_gx ? 0 : (dtype == MYOLO_F16 ? Cin * (((Cout + 31) & ~31) + 8) * 2 : Cout * Cin * 4);
+  const int smem = tab_floats(Cout) * 4 + wbytes;
+  return smem <= TINY_LDS_MAX ? smem : -1;
+}
+
 // 0 = ok; *smem = dynamic LDS bytes of the layer
 int tiny_check(const myolo_tiny_conv_desc& d, bool bwd, int dtype, int* smem) {
   if (dtype != MYOLO_F16 && dtype != MYOLO_F32) return MYOLO_EINVAL;
   const int seg = dtype == MYOLO_F16 ? 8 : 4;
   if (!tv_ok(d.x, dtype, seg) || !tv_ok(d.z, dtype, seg) || !d.w) return MYOLO_EINVAL;
   if (!same_pix(d.x, d.z)) return MYOLO_EINVAL;
-  const int64_t P = (int64_t)d.x.n * d.x.h * d.x.w;
   const int Cin = d.x.c, Cout = d.z.c;
-  if (P < 1 || P > MYOLO_TINY_MAX_PIX || Cin < 1 || Cout < 1 || Cout > 128) return MYOLO_EINVAL;
-  if (dtype == MYOLO_F16 && (Cin % 32 || Cin > 32 * KSMAX || Cout % 16)) return MYOLO_EINVAL;
-  if (dtype == MYOLO_F32 && Cin > 512) return MYOLO_EINVAL;
   if (d.gamma && (!d.beta || !d.saved)) return MYOLO_EINVAL;
   if (d.act != MYOLO_ACT_NONE && d.act != MYOLO_ACT_SILU && d.act != MYOLO_ACT_SIGMOID) return MYOLO_EINVAL;
-  int wbytes;
   if (!bwd) {
     if (!tv_ok(d.out, dtype, seg) || !same_pix(d.out, d.z) || d.out.c != Cout) return MYOLO_EINVAL;
-    wbytes = dtype == MYOLO_F16 ? Cout * (Cin + 8) * 2 : Cout * Cin * 4;
   } else {
     if (!tv_ok(d.gout, dtype, seg) || !tv_ok(d.dy, dtype, seg) || !same_pix(d.gout, d.z) || !same_pix(d.dy, d.z) || d.gout.c != Cout || d.dy.c != Cout)
       return MYOLO_EINVAL;
     if (d.gx.ptr && (!tv_ok(d.gx, dtype, seg) || !same_pix(d.gx, d.x) || d.gx.c != Cin)) return MYOLO_EINVAL;
-    if (dtype == MYOLO_F16 && Cin % 16) return MYOLO_EINVAL;
-    const int KP = (Cout + 31) & ~31;
-    wbytes = !d.gx.ptr ? 0 : (dtype == MYOLO_F16 ? Cin * (KP + 8) * 2 : Cout * Cin * 4);
   }
-  *smem = tab_floats(Cout) * 4 + wbytes;
-  return *smem <= 150 * 1024 ? 0 : MYOLO_EINVAL;
+  *smem = tiny_lds(dtype, (int64_t)d.x.n * d.x.h * d.x.w, Cin, Cout, bwd, d.gx.ptr != nullptr);
+  return *smem >= 0 ? 0 : MYOLO_EINVAL;
 }
 
 template <typename T>
@@ -398,5 +402,8 @@ int tiny_go(const myolo_tiny_conv_desc* d, int n, bool bwd, void* stream) {
 
 }  // namespace
 
+extern "C" int myolo_tiny_conv_ok(int dtype, int pixels, int cin, int cout) {
+  return tiny_lds(dtype, pixels, cin, cout, false, true) >= 0 && tiny_lds(dtype, pixels, cin, cout, true, true) >= 0;
+}
 extern "C" int myolo_tiny_conv_fwd(const myolo_tiny_conv_desc* d, int n, void* stream) { return tiny_go(d, n, false, stream); }
 extern "C" int myolo_tiny_conv_bwd(const myolo_tiny_conv_desc* d, int n, void* stream) { return tiny_go(d, n, true, stream); }

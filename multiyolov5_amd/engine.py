@@ -337,21 +337,10 @@ class ConvOp(Op):
         if self.bias is not None or self.sync_world > 1 or (self.bn is None and self.act == L.ACT_NONE):
             return False
         x, o, w = self.x, self.out, self.weight
-        if x.n * x.h * x.w > L.TINY_MAX_PIX or (x.n, x.h, x.w) != (o.n, o.h, o.w) or x.c != self.cin or o.c != self.cout:
+        if (x.n, x.h, x.w) != (o.n, o.h, o.w) or x.c != self.cin or o.c != self.cout or w.dtype != torch.float32 or not w.is_contiguous():
             return False
-        if w.dtype != torch.float32 or not w.is_contiguous() or self.cout > 128 or self.cin > 512:
-            return False
-        # the workgroup's LDS: 6 floats per output channel + the weights (tiny_check, csrc/tiny_conv.hip): forward [cout][cin + 8] halves /
-        # [cout][cin] floats, backward [cin][cout rounded up to 32, + 8] halves / [cout][cin] floats; <= 150 KB
-        if plan.dtype == torch.float16:
-            if self.cin % 32 or self.cout % 16:
-                return False
-            wb = max(self.cout * (self.cin + 8), self.cin * (rup(self.cout, 32) + 8)) * 2
-        else:
-            if self.cin % 4 or self.cout % 4:
-                return False
-            wb = self.cout * self.cin * 4
-        return 24 * self.cout + wb <= 150 * 1024
+        # pixel / channel limits and the workgroup's LDS budget: the library's own answer (csrc/tiny_conv.hip tiny_lds)
+        return bool(L.lib().myolo_tiny_conv_ok(L.DT[plan.dtype], x.n * x.h * x.w, self.cin, self.cout))
 
     def _build_tiny(self, plan):
         """this layer's descriptor (forward AND backward fields); the group's LAST member (forward order) issues both launches: every
