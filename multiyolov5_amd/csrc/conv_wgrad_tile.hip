@@ -453,6 +453,8 @@ static int g_wgt_min_tiles = -1;   // split-K: at least this many tiles per work
 static int g_wgt_wg = -1;          // workgroups aimed at per layer
 static int g_wgt_dbg = 0;
 static int g_wgt_xcd = -1;         // 1: XCD-aware workgroup order (block_of), 0: linear (default: measured neutral, profiles/r4e_wgrad_xcd_ubench.txt)
+static int g_wgt_ws1 = -1;         // 1: 1x1 layers write split-K partials to the workspace + reduce launch like k x k ones (0, default: fp32 atomics, 11 us of a
+                                   // 30 us layer).  NOT yet run on a GPU (added after the round's GPU budget was spent): scripts/wgrad_ubench.py ws1 checks + times it
 static int g_wgt_nt = -1;          // LDS-DMA cache policy: 0 default, 1 non-temporal for 1x1 layers with one gradient block (every byte read once), 2 always
 int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_off")) { g_wgt_off = value; return 0; }
@@ -463,6 +465,7 @@ int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_dbg")) { g_wgt_dbg = value; return 0; }
   if (!strcmp(name, "wgrad_tile_xcd")) { g_wgt_xcd = value; return 0; }
   if (!strcmp(name, "wgrad_tile_nt")) { g_wgt_nt = value; return 0; }
+  if (!strcmp(name, "wgrad_tile_ws1x1")) { g_wgt_ws1 = value; return 0; }
   return MYOLO_EINVAL;
 }
 
@@ -570,7 +573,8 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int CoP = k.tiles_co * CO_T, CiP = k.tiles_ci * CI_T;
   const int64_t slice_bytes = (int64_t)k.ntaps * CoP * CiP * sizeof(float);
   k.ws = nullptr;
-  if (d->ws && k.ntaps > 1 && d->ws_bytes >= slice_bytes * 2 && ks > 1 && (((uintptr_t)d->ws) & 15) == 0) {
+  if (g_wgt_ws1 < 0) g_wgt_ws1 = getenv("MYOLO_WGRAD_TILE_WS1X1") ? atoi(getenv("MYOLO_WGRAD_TILE_WS1X1")) : 0;
+  if (d->ws && (k.ntaps > 1 || g_wgt_ws1) && d->ws_bytes >= slice_bytes * 2 && ks > 1 && (((uintptr_t)d->ws) & 15) == 0) {
     const int64_t fit = d->ws_bytes / slice_bytes;
     if (ks > fit) ks = (int)fit;
     k.ws = d->ws;

@@ -13,7 +13,7 @@ from tests.gpu_util import check
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-DEFAULTS = {'wgrad_tile_dma': 1, 'wgrad_tile_nst': 0, 'wgrad_tile_xcd': 0, 'wgrad_tile_nt': 1, 'wgrad_tile_min_tiles': 6, 'wgrad_tile_wg': 128,
+DEFAULTS = {'wgrad_tile_ws1x1': 0, 'wgrad_tile_dma': 1, 'wgrad_tile_nst': 0, 'wgrad_tile_xcd': 0, 'wgrad_tile_nt': 1, 'wgrad_tile_min_tiles': 6, 'wgrad_tile_wg': 128,
             'wgrad_tile_dbg': 0, 'wgrad_tile_off': 0}
 
 
