@@ -14,6 +14,7 @@
 //
 // Not a reference interface: the reference's forward is Python (models/yolo.py:293-316); this replaces the interpreter loop around it.
 #include "myolo_dev.h"
+#include <stdlib.h>
 #include <string.h>
 #include <tuple>
 #include <utility>
@@ -114,14 +115,48 @@ extern "C" uint64_t* myolo_prog_slot(void* prog, int op, int arg) {
 
 extern "C" int myolo_prog_last_op(void* prog) { return prog ? static_cast<Prog*>(prog)->last_op : -1; }
 
+// MYOLO_SIDE_BATCH=K (diagnostics, default 1 = off): side-stream calls are held back and forked K at a time -- ONE event record on the
+// main stream and one wait on the side stream per K weight gradients instead of per launch (79 forks per yolov5s+PSP step: each record is a
+// barrier packet between two kernels of the dependent chain).  Safe for the backward: a weight gradient reads its layer's dy and x, which
+// no later launch overwrites, and nothing on the main stream waits for it before the JOIN; a held call is issued at the latest at the next
+// JOIN / the end of the range.  (Not meant for eval programs, whose side calls are the segmentation head: they should start at once.)
+static int side_batch() {
+  static const int k = getenv("MYOLO_SIDE_BATCH") ? atoi(getenv("MYOLO_SIDE_BATCH")) : 1;
+  return k < 1 ? 1 : (k > 16 ? 16 : k);
+}
+
 extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream) {
   Prog* p = static_cast<Prog*>(prog);
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) return MYOLO_EINVAL;
   hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
+  const int batch = ss ? side_batch() : 1;
+  int held[16], nheld = 0;
+  auto flush = [&]() -> int {                         // fork once for every held side call (the newest one's event covers them all)
+    if (!nheld) return 0;
+    const int lastop = held[nheld - 1];
+    hipError_t e = hipEventRecord(p->evs[lastop], ms);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ss, p->evs[lastop], 0);
+    if (e != hipSuccess) { p->last_op = lastop; nheld = 0; return (int)e; }
+    for (int j = 0; j < nheld; ++j) {
+      const myolo_prog_op& h = p->ops[held[j]];
+      const int r = g_table[h.fn].fn(h.a, side_stream);
+      if (r) { p->last_op = held[j]; nheld = 0; return r; }
+    }
+    nheld = 0;
+    return 0;
+  };
   for (int i = first; i < last; ++i) {
     const myolo_prog_op& o = p->ops[i];
     if (o.cond && *reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o.cond)) != o.cond_val) continue;
     int r = 0;
+    if (batch > 1) {
+      if (o.kind == MYOLO_OP_CALL_SIDE) {
+        held[nheld++] = i;
+        if (nheld >= batch) { r = flush(); if (r) return r; }
+        continue;
+      }
+      if (o.kind == MYOLO_OP_JOIN) { r = flush(); if (r) return r; }
+    }
     switch (o.kind) {
       case MYOLO_OP_CALL:
         r = g_table[o.fn].fn(o.a, main_stream);
@@ -152,5 +187,5 @@ extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream
     }
     if (r) { p->last_op = i; return r; }
   }
-  return 0;
+  return flush();
 }
