@@ -565,6 +565,15 @@ uint64_t* myolo_prog_slot(void* prog, int op, int arg);        /* address of one
 int   myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream);  /* 0 or the failing launch's error */
 int   myolo_prog_last_op(void* prog);              /* index of the op the last failing run stopped at */
 
+/* ---- launch trace (test infrastructure; no reference counterpart) ----------------------------------------------------------
+ * The dispatchers behind myolo_conv / myolo_conv_wgrad / ... pick a kernel family and a template variant (tile shape, ring
+ * depth, epilogue flags) from the descriptor.  myolo_trace_start(1) clears the table and makes every launch site record
+ * itself; myolo_trace_read copies "count<TAB>site<NEWLINE>" lines (site = the launcher's signature with its template
+ * arguments) into buf and returns the bytes needed (buf may be NULL).  tests/test_gpu_bench_plan.py uses it to list which
+ * variants the benchmarked plans run, next to a per-launch comparison of those launches with torch fp32. */
+int     myolo_trace_start(int on);
+int64_t myolo_trace_read(char* buf, int64_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -196,6 +196,8 @@ _PROTOS = {
     'myolo_prog_slot': (C.POINTER(C.c_uint64), [C.c_void_p, C.c_int, C.c_int]),
     'myolo_prog_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'myolo_prog_last_op': (C.c_int, [C.c_void_p]),
+    'myolo_trace_start': (C.c_int, [C.c_int]),
+    'myolo_trace_read': (C.c_int64, [C.c_char_p, C.c_int64]),
     'myolo_nms_ws_bytes': (C.c_int64, [C.c_int, C.c_int]),
     'myolo_nms': (C.c_int, [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int,
                             C.c_int, C.c_int, P, P, P, P, P, P, C.c_uint64, P, P, C.c_int64, P]),
@@ -223,6 +225,19 @@ EINVAL = -22
 def check(err, what=''):
     if err != 0:
         raise MyoloError(f'libmyolo {what} failed with error {err}' + (' (invalid argument)' if err == -22 else ''))
+
+
+def launch_trace():
+    """{launch site: count} since myolo_trace_start(1) (include/myolo.h: which kernel variants ran; test infrastructure)"""
+    l = lib()
+    n = l.myolo_trace_read(None, 0)
+    buf = C.create_string_buffer(int(n))
+    l.myolo_trace_read(buf, n)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        c, _, site = line.partition('\t')
+        out[site] = int(c)
+    return out
 
 
 def stream_ptr():

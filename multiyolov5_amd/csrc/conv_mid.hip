@@ -258,6 +258,10 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
           const float dz = fg[i] * silu_grad_f(fmaf(fy[i], sc[i], sh[i]));       // (host: SiLU layers only -- no per-element activation switch)
           o[i] = fmaf(sc[i], dz, fmaf(cb[i], fy[i], cd[i]));
         }
+        if (!(xmask[j] & 1u)) {                     // rows past M: exact zeros in the MFMA operand, as in the two-launch form (the
+#pragma unroll                                      // constant term cd would otherwise reach any epilogue that reduces over unmasked rows)
+          for (int i = 0; i < 8; ++i) o[i] = 0.f;
+        }
         const u32x4_t ov = pack_h8(o);
         asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ga), "v"(ov), "n"(j * RPI * 128) : "memory");
         if (tn == 0 && (xmask[j] & 1u)) stg16(p.bdy + (unsigned)(dybase[j] + kc * 128), uint4{ov.x, ov.y, ov.z, ov.w});

@@ -44,32 +44,18 @@ struct WgT {
   int dbuf_bytes, xbuf_bytes;        // bytes of one dy / x LDS buffer
   int pd, px;                        // LDS pixel-row pitches (bytes) of the dy / x tiles
   int nst, dpieces, xpieces, stage_bytes;   // wgrad_tile_dma_kernel: ring stages, 1 KB pieces of the dy / x area, (dpieces + xpieces) * 1024
-  int map_mode, out_tiles;           // workgroup id -> (gradient block, pixel split): see block_of()
+  int out_tiles;                     // gradient blocks per pixel split: workgroup id -> (block, split), see block_of()
   int nt;                            // LDS-DMA with the non-temporal policy (aux = 2): operands this launch reads once
   int dbg;                           // profiling only (myolo_set_option("wgrad_tile_dbg", bits)): 1 no LDS-DMA, 2 no fragment reads / MFMAs, 4 no result stores
 };
 
 
-// Workgroup id -> (gradient block b, pixel split).  Every block of one split reads the SAME dy / x pixels (x once per co block, dy once
-// per ci block: 2-8 x the operand bytes for the 128+-channel layers), and consecutive workgroup ids go round-robin over the 8 XCDs, each
-// with its own L2: with the plain (block, split) grid the blocks of a split sat on different XCDs and every re-read was an L2 miss
-// (PMC: 5.27 GB fetched per step for 3.25 GB of operands = exactly the issued bytes).  map_mode 2 (ksplit % 8 == 0): XCD x serves the
-// splits x, x + 8, ...; map_mode 1 (ksplit in {1, 2, 4}): XCD x serves split x % ksplit, the blocks dealt over the 8 / ksplit XCDs of
-// that split; map_mode 0: linear.  Returns false for the surplus workgroups of mode 1.
+// Workgroup id -> (gradient block b, pixel split): linear.  Every block of one split reads the SAME dy / x pixels (x once per co block, dy
+// once per ci block: 2-8 x the operand bytes for the 128+-channel layers; PMC: 5.27 GB fetched per step for 3.25 GB of operands = exactly
+// the issued bytes).  An XCD-aware order that put the blocks of a split on one XCD's L2 was built in round 4 and measured neutral standalone
+// (762 vs 737 us over 16 layers, profiles/r4e_wgrad_xcd_ubench.txt) and in the step (7.845 vs 7.858 ms): removed in round 5.
 __device__ __forceinline__ bool block_of(const WgT& p, int& b, int& split) {
   const int id = blockIdx.x;
-  if (p.map_mode == 2) {
-    const int xcd = id & 7, slot = id >> 3;
-    split = xcd + 8 * (slot / p.out_tiles);
-    b = slot % p.out_tiles;
-    return true;
-  }
-  if (p.map_mode == 1) {
-    const int xcd = id & 7, slot = id >> 3;
-    split = xcd % p.ksplit;
-    b = xcd / p.ksplit + (8 / p.ksplit) * slot;
-    return b < p.out_tiles;
-  }
   split = id / p.out_tiles;
   b = id % p.out_tiles;
   return true;
@@ -409,10 +395,7 @@ __global__ __launch_bounds__(THREADS) void wgrad_tile_dma_kernel(const WgT p) {
         }
 }
 
-inline int grid_blocks(const WgT& k) {
-  if (k.map_mode == 1) { const int per = 8 / k.ksplit; return 8 * ((k.out_tiles + per - 1) / per); }
-  return k.out_tiles * k.ksplit;
-}
+inline int grid_blocks(const WgT& k) { return k.out_tiles * k.ksplit; }
 
 template <int NT, int COF, int CIF>
 int launch(const WgT& k, int out_tiles, int smem, hipStream_t st) {
@@ -452,10 +435,9 @@ static int g_wgt_nst = -1;         // ring stages of the LDS-DMA kernel: 3, 4, 0
 static int g_wgt_min_tiles = -1;   // split-K: at least this many tiles per workgroup
 static int g_wgt_wg = -1;          // workgroups aimed at per layer
 static int g_wgt_dbg = 0;
-static int g_wgt_xcd = -1;         // 1: XCD-aware workgroup order (block_of), 0: linear (default: measured neutral, profiles/r4e_wgrad_xcd_ubench.txt)
-static int g_wgt_ws1 = -1;         // 1: 1x1 layers write split-K partials to the workspace + reduce launch like k x k ones (0, default: fp32 atomics, 11 us of a
-                                   // 30 us layer).  NOT yet run on a GPU (added after the round's GPU budget was spent): scripts/wgrad_ubench.py ws1 checks + times it
-static int g_wgt_nt = -1;          // LDS-DMA cache policy: 0 default, 1 non-temporal for 1x1 layers with one gradient block (every byte read once), 2 always
+// (round 5, measured and removed: 1x1 split-K partials through the workspace + reduce launch instead of fp32 atomics -- 857.5 vs 865.9 us over the
+//  16 layer shapes, 7.765 vs 7.773 ms per step, gpurun_out/next_ws1_ubench.txt of the round's first call; the XCD-aware order; the cache-policy
+//  knob: non-temporal LDS-DMA for 1x1 layers with ONE gradient block -- every byte read once -- is simply what the kernel does)
 int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_off")) { g_wgt_off = value; return 0; }
   if (!strcmp(name, "wgrad_tile_dma")) { g_wgt_dma = value; return 0; }
@@ -463,9 +445,6 @@ int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_min_tiles")) { g_wgt_min_tiles = value; return 0; }
   if (!strcmp(name, "wgrad_tile_wg")) { g_wgt_wg = value; return 0; }
   if (!strcmp(name, "wgrad_tile_dbg")) { g_wgt_dbg = value; return 0; }
-  if (!strcmp(name, "wgrad_tile_xcd")) { g_wgt_xcd = value; return 0; }
-  if (!strcmp(name, "wgrad_tile_nt")) { g_wgt_nt = value; return 0; }
-  if (!strcmp(name, "wgrad_tile_ws1x1")) { g_wgt_ws1 = value; return 0; }
   return MYOLO_EINVAL;
 }
 
@@ -563,27 +542,17 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   const int max_ks = (k.ntiles + mt - 1) / mt;
   if (ks > max_ks) ks = max_ks;
   if (ks < 1) ks = 1;
-  if (g_wgt_xcd < 0) g_wgt_xcd = getenv("MYOLO_WGRAD_TILE_XCD") ? atoi(getenv("MYOLO_WGRAD_TILE_XCD")) : 0;
-  const bool xcd_map = g_wgt_xcd && out_tiles > 1 && d->ksplit <= 0;
-  if (xcd_map) {                                      // a split count the XCD-aware order can deal: a multiple of 8, or 1 / 2 / 4
-    if (ks >= 8) ks = ks / 8 * 8;
-    else if (ks > 4) ks = max_ks >= 8 ? 8 : 4;
-    else if (ks == 3) ks = max_ks >= 4 ? 4 : 2;
-  }
   const int CoP = k.tiles_co * CO_T, CiP = k.tiles_ci * CI_T;
   const int64_t slice_bytes = (int64_t)k.ntaps * CoP * CiP * sizeof(float);
   k.ws = nullptr;
-  if (g_wgt_ws1 < 0) g_wgt_ws1 = getenv("MYOLO_WGRAD_TILE_WS1X1") ? atoi(getenv("MYOLO_WGRAD_TILE_WS1X1")) : 0;
-  if (d->ws && (k.ntaps > 1 || g_wgt_ws1) && d->ws_bytes >= slice_bytes * 2 && ks > 1 && (((uintptr_t)d->ws) & 15) == 0) {
+  if (d->ws && k.ntaps > 1 && d->ws_bytes >= slice_bytes * 2 && ks > 1 && (((uintptr_t)d->ws) & 15) == 0) {
     const int64_t fit = d->ws_bytes / slice_bytes;
     if (ks > fit) ks = (int)fit;
     k.ws = d->ws;
   }
   k.ksplit = ks;
   k.out_tiles = out_tiles;
-  if (g_wgt_nt < 0) g_wgt_nt = getenv("MYOLO_WGRAD_TILE_NT") ? atoi(getenv("MYOLO_WGRAD_TILE_NT")) : 1;
-  k.nt = g_wgt_nt == 2 || (g_wgt_nt == 1 && out_tiles == 1 && k.ntaps == 1);
-  k.map_mode = !xcd_map ? 0 : (ks % 8 == 0 ? 2 : ((ks == 1 || ks == 2 || ks == 4) ? 1 : 0));
+  k.nt = out_tiles == 1 && k.ntaps == 1;
   *out_ks = ks; *out_cop = CoP; *out_cip = CiP; *used_ws = k.ws != nullptr;
   hipStream_t st = (hipStream_t)stream;
   if (k.ntaps == 9) return launch_nt<9>(k, cof, cif, out_tiles, smem, st);

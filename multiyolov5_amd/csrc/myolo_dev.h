@@ -10,10 +10,16 @@ typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
 typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef __fp16 fp16x4_t __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+// Launch trace (test infrastructure, myolo_trace_start / myolo_trace_read in plan_exec.hip): when on, every launch site records its
+// __PRETTY_FUNCTION__ -- for the template launchers that is the kernel family WITH its template arguments (tile shape, ring depth,
+// epilogue flags), i.e. exactly which variant the dispatcher picked for a descriptor.  One relaxed load when off.
+extern int g_myolo_trace;
+void myolo_trace_note(const char* site);
 #define MYOLO_CHECK_LAUNCH()                                  \
   do {                                                        \
     hipError_t e__ = hipGetLastError();                       \
     if (e__ != hipSuccess) return (int)e__;                   \
+    if (g_myolo_trace) myolo_trace_note(__PRETTY_FUNCTION__); \
   } while (0)
 
 // hipFuncAttributeMaxDynamicSharedMemorySize once per kernel instantiation and size (the expansion site's static: a template

@@ -115,48 +115,16 @@ extern "C" uint64_t* myolo_prog_slot(void* prog, int op, int arg) {
 
 extern "C" int myolo_prog_last_op(void* prog) { return prog ? static_cast<Prog*>(prog)->last_op : -1; }
 
-// MYOLO_SIDE_BATCH=K (diagnostics, default 1 = off): side-stream calls are held back and forked K at a time -- ONE event record on the
-// main stream and one wait on the side stream per K weight gradients instead of per launch (79 forks per yolov5s+PSP step: each record is a
-// barrier packet between two kernels of the dependent chain).  Safe for the backward: a weight gradient reads its layer's dy and x, which
-// no later launch overwrites, and nothing on the main stream waits for it before the JOIN; a held call is issued at the latest at the next
-// JOIN / the end of the range.  (Not meant for eval programs, whose side calls are the segmentation head: they should start at once.)
-static int side_batch() {
-  static const int k = getenv("MYOLO_SIDE_BATCH") ? atoi(getenv("MYOLO_SIDE_BATCH")) : 1;
-  return k < 1 ? 1 : (k > 16 ? 16 : k);
-}
-
+// (round 5, measured and removed: forking the weight-gradient stream once per K side calls instead of per call -- MYOLO_SIDE_BATCH=2 / 4 / 8:
+//  7.769 / 7.855 / 7.911 ms per step against 7.765; the held-back weight gradients start later and the exposed tail grows)
 extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream) {
   Prog* p = static_cast<Prog*>(prog);
   if (!p || first < 0 || last > (int)p->ops.size() || first > last) return MYOLO_EINVAL;
   hipStream_t ms = (hipStream_t)main_stream, ss = (hipStream_t)side_stream;
-  const int batch = ss ? side_batch() : 1;
-  int held[16], nheld = 0;
-  auto flush = [&]() -> int {                         // fork once for every held side call (the newest one's event covers them all)
-    if (!nheld) return 0;
-    const int lastop = held[nheld - 1];
-    hipError_t e = hipEventRecord(p->evs[lastop], ms);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ss, p->evs[lastop], 0);
-    if (e != hipSuccess) { p->last_op = lastop; nheld = 0; return (int)e; }
-    for (int j = 0; j < nheld; ++j) {
-      const myolo_prog_op& h = p->ops[held[j]];
-      const int r = g_table[h.fn].fn(h.a, side_stream);
-      if (r) { p->last_op = held[j]; nheld = 0; return r; }
-    }
-    nheld = 0;
-    return 0;
-  };
   for (int i = first; i < last; ++i) {
     const myolo_prog_op& o = p->ops[i];
     if (o.cond && *reinterpret_cast<const int32_t*>(static_cast<uintptr_t>(o.cond)) != o.cond_val) continue;
     int r = 0;
-    if (batch > 1) {
-      if (o.kind == MYOLO_OP_CALL_SIDE) {
-        held[nheld++] = i;
-        if (nheld >= batch) { r = flush(); if (r) return r; }
-        continue;
-      }
-      if (o.kind == MYOLO_OP_JOIN) { r = flush(); if (r) return r; }
-    }
     switch (o.kind) {
       case MYOLO_OP_CALL:
         r = g_table[o.fn].fn(o.a, main_stream);
@@ -187,5 +155,34 @@ extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream
     }
     if (r) { p->last_op = i; return r; }
   }
-  return flush();
+  return 0;
+}
+
+// ---- launch trace (test infrastructure; see MYOLO_CHECK_LAUNCH in myolo_dev.h) --------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <string>
+int g_myolo_trace = 0;
+static std::mutex g_trace_mu;
+static std::map<std::string, int> g_trace_sites;      // launch site (kernel family + template arguments) -> launches since myolo_trace_start(1)
+void myolo_trace_note(const char* site) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  ++g_trace_sites[site ? site : "?"];
+}
+extern "C" int myolo_trace_start(int on) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace_sites.clear();
+  g_myolo_trace = on ? 1 : 0;
+  return 0;
+}
+extern "C" int64_t myolo_trace_read(char* buf, int64_t cap) {
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  std::string out;
+  for (const auto& kv : g_trace_sites) { out += std::to_string(kv.second); out += '\t'; out += kv.first; out += '\n'; }
+  if (buf && cap > 0) {
+    const int64_t n = (int64_t)out.size() < cap - 1 ? (int64_t)out.size() : cap - 1;
+    memcpy(buf, out.data(), (size_t)n);
+    buf[n] = 0;
+  }
+  return (int64_t)out.size() + 1;                     // bytes needed (call with buf = NULL to size the buffer)
 }

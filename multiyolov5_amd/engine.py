@@ -23,7 +23,6 @@ PACK_TILED = os.environ.get('MYOLO_PACK_TILED', '1') != '0'        # per-forward
 LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
 LAZY_SEG_EVAL = os.environ.get('MYOLO_LAZY_SEG_EVAL', '1') != '0'  # eval: same (detect.py's resize + argmax reads the low-resolution logits)
 EVAL_BRANCH = os.environ.get('MYOLO_EVAL_BRANCH', '1') != '0'      # eval: the segmentation head runs on the side stream beside neck + Detect
-TRAIN_BRANCH = os.environ.get('MYOLO_TRAIN_BRANCH', '0') != '0'    # training forward: same (the backward keeps one chain)
 BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
@@ -1331,7 +1330,7 @@ class Plan:
         # eval: the launches of a tagged branch go to the side stream (CALL_SIDE: behind everything issued on the main stream so far);
         # the main stream joins before the first op added after the module's own (the output ops read the branch's results)
         self._fwd_side = False
-        if not self.training or (TRAIN_BRANCH and not self.has_sync()):
+        if not self.training:
             for op in self.ops:
                 if getattr(op, 'branch', None):
                     for c in op.fwd_calls:
@@ -1699,7 +1698,14 @@ class Plan:
 
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # experiment switches (round 5): which hardware queue the second stream lands on.  MYOLO_SIDE_SKIP=k takes k streams out of torch's
+            # pool first (HIP hands hardware queues to streams round-robin), MYOLO_SIDE_PRIO=-1 asks for the high-priority pool
+            skip, prio = int(os.environ.get('MYOLO_SIDE_SKIP', '0')), int(os.environ.get('MYOLO_SIDE_PRIO', '0'))
+            self._side_dummies = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(skip)]
+            for s_ in self._side_dummies:
+                with torch.cuda.stream(s_):
+                    torch.zeros(1, device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=prio)
         return self._side
 
     def _bwd_segments(self, reducer):

@@ -244,7 +244,7 @@ class Model(PlannedModule):
         n = len(self.model)
         order, seg_i = list(range(n)), n - 2
         f = self.model[seg_i].f if n >= 3 else None
-        branch = (E.TRAIN_BRANCH if plan.training else E.EVAL_BRANCH) and isinstance(f, (list, tuple)) and all(0 <= j < seg_i for j in f) and \
+        branch = (not plan.training and E.EVAL_BRANCH) and isinstance(f, (list, tuple)) and all(0 <= j < seg_i for j in f) and \
             not any(seg_i in [(g if g >= 0 else i + g) for g in (m.f if isinstance(m.f, (list, tuple)) else [m.f])]      # relative `from`
                     for i, m in enumerate(self.model[seg_i + 1:], seg_i + 1))                                           # indices resolved
         if branch:

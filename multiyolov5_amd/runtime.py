@@ -688,7 +688,7 @@ class PlannedModule(nn.Module):
         plans = self.__dict__.setdefault('_plans', {})
         h = plans.get(key)
         epoch = PlannedModule._EPOCH[0]
-        if h is not None and h.__dict__.get('_sig_epoch') == epoch:
+        if h is not None and h.__dict__.get('_sig_epoch') == epoch and self._sentinels_match(h.sig):
             sig = h.sig                                  # nothing re-allocated since this plan compared the pointers
         else:
             sig = self._sig()
@@ -712,6 +712,19 @@ class PlannedModule(nn.Module):
                 h.__dict__['_graph_warm'] = 0
                 self.__dict__['_prepared_version'] = v
         return h, grad
+
+    def _sentinels_match(self, sig):
+        """a re-allocation that bypasses _apply / load_state_dict (`.half()` on a leaf nn.Conv2d, `p.data = ...`) does not move the
+        epoch; the fast path still compares a handful of data pointers spread over the list (first, last, every 16th: ~1 us) so that a
+        whole-submodule conversion is caught and the plan rebuilt instead of launching on freed storage"""
+        ts = self._tensors()
+        n = len(ts)
+        if n != len(sig):
+            return False
+        for i in range(0, n, 16):
+            if ts[i].data_ptr() != sig[i]:
+                return False
+        return n == 0 or ts[-1].data_ptr() == sig[-1]
 
     def _param_version(self):
         return sum(t._version for t in self._tensors())

@@ -47,6 +47,7 @@ from .. import _lib as _L
 
 
 _NMS_SCRATCH = {}
+_NMS_CACHE_MAX_BYTES = 64 << 20
 
 
 def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=None, agnostic=False, multi_label=False,
@@ -80,7 +81,10 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     # eight torch.empty per frame were ~25 us of host time on the detect.py path).  `out` -- the rows the caller keeps -- is fresh.
     use_ws = bool(multi or conf_thres < 0.05)
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, A, no, multi, use_ws)
-    sc = _NMS_SCRATCH.get(key)
+    # only detect.py-sized sets are kept (<= 64 MB of candidate rows); test.py's conf 0.001 + multi_label workspaces are
+    # gigabytes per geometry and rect validation changes A almost every batch -- those come from (and go back to) torch's caching allocator
+    cacheable = B * cap * 6 * 4 <= _NMS_CACHE_MAX_BYTES
+    sc = _NMS_SCRATCH.get(key) if cacheable else None
     if sc is None:
         if len(_NMS_SCRATCH) > 16:
             _NMS_SCRATCH.clear()
@@ -94,7 +98,8 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
         if sc['ws'] is None and B <= 64:
             sc['mws_bytes'] = int(_L.lib().myolo_nms_ws_bytes(B, cap))
             sc['mws'] = torch.empty(sc['mws_bytes'], dtype=torch.uint8, device=dev)
-        _NMS_SCRATCH[key] = sc
+        if cacheable:
+            _NMS_SCRATCH[key] = sc
     counts, cand, cidx, srt, nkeep, ws, mws, mws_bytes = (sc[k] for k in ('counts', 'cand', 'cidx', 'srt', 'nkeep', 'ws', 'mws', 'mws_bytes'))
     out = torch.empty(B, max_det, 6, dtype=torch.float32, device=dev)
     _L.check(_L.lib().myolo_nms(_L.ptr(pred), _L.DT[pred.dtype], B, A, no, _C.c_float(conf_thres), _C.c_float(iou_thres),

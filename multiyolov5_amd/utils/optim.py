@@ -172,6 +172,7 @@ def _bump_version(t):
         t.add_(0)
 
 
+@torch.no_grad()
 def ema_update(pairs, d, model_sd=None):
     """v = d*v + (1-d)*m for every (ema tensor, model tensor) pair (floating state_dict entries, buffers included), one
     launch.  `pairs` may also be the EMA state_dict with `model_sd` the model's (torch_utils.py:296-300 call shape)."""

@@ -81,18 +81,12 @@ VARIANTS = [('dma', {}), ('reg', {'wgrad_tile_dma': 0})]
 if 'sweep' in sys.argv[1:]:
     VARIANTS += [('dma mt3', {'wgrad_tile_min_tiles': 3}), ('dma mt2', {'wgrad_tile_min_tiles': 2}), ('dma mt4 wg192', {'wgrad_tile_min_tiles': 4, 'wgrad_tile_wg': 192}),
                  ('dma nst3', {'wgrad_tile_nst': 3}), ('dma nst4', {'wgrad_tile_nst': 4})]
-if 'xcd' in sys.argv[1:]:            # XCD-aware workgroup order (all blocks of a pixel split on one XCD) vs the linear order
-    VARIANTS = [('dma xcd', {'wgrad_tile_xcd': 1}), ('dma linear', {}), ('reg xcd', {'wgrad_tile_dma': 0, 'wgrad_tile_xcd': 1}), ('reg linear', {'wgrad_tile_dma': 0})]
-if 'ws1' in sys.argv[1:]:            # 1x1 layers: split-K partials through the workspace + reduce launch instead of fp32 atomics
-    VARIANTS = [('dma atomics', {}), ('dma ws+reduce', {'wgrad_tile_ws1x1': 1})]
-if 'nt' in sys.argv[1:]:             # LDS-DMA cache policy
-    VARIANTS = [('dma', {'wgrad_tile_nt': 0}), ('dma nt 1x1', {}), ('dma nt all', {'wgrad_tile_nt': 2})]
 if 'dbg' in sys.argv[1:]:            # where the time goes: the kernel without its LDS-DMA / without fragment reads + MFMAs / without result stores (err is meaningless there)
     VARIANTS = [('dma', {}), ('no dma', {'wgrad_tile_dbg': 1}), ('no mfma', {'wgrad_tile_dbg': 2}), ('no store', {'wgrad_tile_dbg': 4}), ('dma only', {'wgrad_tile_dbg': 6}),
                 ('mfma only', {'wgrad_tile_dbg': 5}), ('empty', {'wgrad_tile_dbg': 7})]
 if 'r1' in sys.argv[1:]:
     VARIANTS += [('r1 kern', {'wgrad_tile_off': 1})]
-DEFAULTS = {'wgrad_tile_ws1x1': 0, 'wgrad_tile_nt': 1, 'wgrad_tile_xcd': 0, 'wgrad_tile_dbg': 0, 'wgrad_tile_dma': 1, 'wgrad_tile_min_tiles': 6, 'wgrad_tile_wg': 128, 'wgrad_tile_nst': 0, 'wgrad_tile_off': 0}
+DEFAULTS = {'wgrad_tile_dbg': 0, 'wgrad_tile_dma': 1, 'wgrad_tile_min_tiles': 6, 'wgrad_tile_wg': 128, 'wgrad_tile_nst': 0, 'wgrad_tile_off': 0}
 print(f'{"shape":34s} {"MB":>6s} {"GF":>6s} {"roof us":>8s} | ' + ' '.join(f'{v[0]:>13s}' for v in VARIANTS) + ' | best GB/s  frac   err per variant')
 tot = [0.0] * len(VARIANTS)
 for cin, cout, k, d, s, H, W in SHAPES:

@@ -15,3 +15,12 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+@pytest.fixture(autouse=True)
+def _release_plans():
+    """launch plans are reference cycles (plan <-> ops <-> ctypes descriptors) holding every activation buffer: collect them after each
+    test instead of whenever the allocator's generation counters get there (a dry CPU plan at batch 16 is gigabytes of host memory)"""
+    yield
+    import gc
+    gc.collect()

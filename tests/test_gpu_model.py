@@ -296,8 +296,12 @@ def test_full_resolution_joint_train_step_vs_oracle(dtype):
         # product's pool choices, see above)
         gt = tol * 5 if dtype == torch.float32 else max(tol, 2.0 * noise_g[k])
         check(f'fulltrain/{dtype}/grad/{k}', p.grad, params[k].grad, gt, collect=worst)
-        if dtype == torch.float16:      # product-fp16 vs oracle-with-fp16-storage directly (logged; same rounding points, different order)
-            check(f'fulltrain/{dtype}/grad_vs_q16/{k}', p.grad, qparams[k].grad, 1.0, collect=[])
+        if dtype == torch.float16:      # product-fp16 vs oracle-with-fp16-storage directly (same rounding points, different order): GATED since
+            # round 5 at 0.25 -- measured over two runs x 229 tensors (gpurun_out/parity_log.jsonl of the round's first call): median 0.051,
+            # p90 0.119, max 0.164 (BatchNorm gammas of the stem, whose gradients are differences of large sums); the network amplifies one
+            # fp16 rounding of an activation to percents of a gradient tensor whatever the order -- the tight fp16 gate is per launch:
+            # tests/test_gpu_bench_plan.py holds every conv / dgrad / wgrad launch of the benchmarked plan to 3e-3 against torch fp32
+            check(f'fulltrain/{dtype}/grad_vs_q16/{k}', p.grad, qparams[k].grad, 0.25, collect=worst)
     assert not worst, f'{len(worst)} parameter gradients off:\n' + '\n'.join(worst[:20])
     for k, b in m.named_buffers():
         if 'running' in k:
@@ -320,7 +324,9 @@ def test_bench_batch16_step_invariants(dtype):
     identical, ComputeLoss' per-level means are identical, and every parameter gradient of the (loss * bs)-scaled objective is 8x
     the 2-image gradient.  fp32: exact up to summation order.  fp16 (the bench's dtype): two fp16 runs of this random-weight
     network differ by its storage noise (5-20 % per gradient tensor, see the full-resolution oracle test), so the per-tensor bound
-    is that noise and the tight checks are the losses and the global gradient norm."""
+    is that noise and the tight checks are the losses and the global gradient norm.  (What holds the fp16 kernels of the batch-16 plan
+    to the oracle is tests/test_gpu_bench_plan.py: every conv / dgrad / wgrad launch of the bench's own Trainer step against torch fp32
+    on the operands the launch read, 3e-3.)"""
     from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
     tag, HH, WW = 's_psp', 512, 1024
     hyp = loss_ref.scaled_hyp(1024, 10, 3)

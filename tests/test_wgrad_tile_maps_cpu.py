@@ -1,7 +1,7 @@
 """CPU: the index maps of csrc/conv_wgrad_tile.hip restated in Python and checked for the properties the kernels rely on (no GPU needed;
 the kernels themselves are compared with autograd in tests/test_gpu_wgrad_tile.py):
-  * block_of(): every (gradient block, pixel split) pair gets exactly one workgroup id in each map mode, and in the XCD-aware modes all
-    blocks of one split sit on one XCD (consecutive workgroup ids go round-robin over 8 XCDs);
+  * block_of(): every (gradient block, pixel split) pair gets exactly one workgroup id (the XCD-aware orders of round 4 measured neutral
+    and were removed in round 5);
   * the LDS-DMA slot tables of wgrad_tile_dma_kernel: a tile's dy / x area is a sequence of 1 KB pieces, lane l of piece p fills the
     16-byte slot at byte p*1024 + l*16 of the area; slot -> (pixel, 16-byte channel segment) with the padded pixel pitch must reach every
     (pixel, segment) of the tile exactly once, everything else (padding, the round-up of the area) must be a zero-page fetch;
@@ -12,43 +12,19 @@ import itertools
 import pytest
 
 
-def block_of(wid, mode, out_tiles, ksplit):
-    if mode == 2:
-        xcd, slot = wid & 7, wid >> 3
-        return slot % out_tiles, xcd + 8 * (slot // out_tiles)
-    if mode == 1:
-        xcd, slot = wid & 7, wid >> 3
-        b = xcd // ksplit + (8 // ksplit) * slot
-        return (b, xcd % ksplit) if b < out_tiles else None
+def block_of(wid, out_tiles, ksplit):
     return wid % out_tiles, wid // out_tiles
 
 
-def grid_blocks(mode, out_tiles, ksplit):
-    if mode == 1:
-        per = 8 // ksplit
-        return 8 * ((out_tiles + per - 1) // per)
-    return out_tiles * ksplit
-
-
 @pytest.mark.parametrize('out_tiles', [1, 2, 3, 4, 6, 8, 16, 32])
-def test_block_of_is_a_bijection_and_keeps_a_split_on_one_xcd(out_tiles):
-    cases = [(0, ks) for ks in (1, 2, 3, 5, 7, 24, 128)] + [(1, ks) for ks in (1, 2, 4)] + [(2, ks) for ks in (8, 16, 24, 128)]
-    for mode, ks in cases:
-        seen, xcd_of_split = set(), {}
-        for wid in range(grid_blocks(mode, out_tiles, ks)):
-            r = block_of(wid, mode, out_tiles, ks)
-            if r is None:
-                continue
-            b, split = r
+def test_block_of_is_a_bijection(out_tiles):
+    for ks in (1, 2, 3, 5, 7, 24, 128):
+        seen = set()
+        for wid in range(out_tiles * ks):
+            b, split = block_of(wid, out_tiles, ks)
             assert 0 <= b < out_tiles and 0 <= split < ks and (b, split) not in seen
             seen.add((b, split))
-            if mode:
-                xcd_of_split.setdefault(split, set()).add(wid & 7)
-        assert len(seen) == out_tiles * ks, (mode, ks, out_tiles)
-        if mode == 2:
-            assert all(len(v) == 1 for v in xcd_of_split.values())
-        if mode == 1:                                  # a split's blocks are dealt over the 8 / ksplit XCDs that serve only this split
-            assert all(len(v) <= 8 // ks and all(x % ks == s for x in v) for s, v in xcd_of_split.items())
+        assert len(seen) == out_tiles * ks
 
 
 def slot_table(n_pieces, pitch, npix, nseg):
