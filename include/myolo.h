@@ -148,6 +148,14 @@ typedef struct myolo_bn_apply_fold {
 } myolo_bn_apply_fold;
 int myolo_conv_dgrad_bn(const myolo_conv_desc* d, const myolo_bn_apply_fold* f, void* stream);
 
+/* Two convolutions in one launch, eval epilogues (round 5): y_b = conv_b(conv_a(x)) where `a` is a 1x1 stride-1 layer whose output
+ * (a->y == b->x, the same view) has NO other reader and `b` a 3x3 stride-1 dilation-1 layer over the same map -- the fused model's
+ * Bottleneck (reference models/common.py:95-105 `x + cv2(cv1(x))` with Conv.fuseforward, common.py:45-46; the shortcut is b->res).  Each
+ * descriptor keeps the meaning it has for myolo_conv (scale / shift / act / res); the intermediate is rounded to the storage type where
+ * the two-launch form stores it.  When the fused kernel runs (fp16, 64 / 128 / 256 channels in, mid and out ... csrc/conv_pair.hip) a->y
+ * is NOT written; every other pair runs as myolo_conv(a) followed by myolo_conv(b), which is also the definition of the result. */
+int myolo_conv_pair(const myolo_conv_desc* a, const myolo_conv_desc* b, void* stream);
+
 /* dgrad of a STRIDE-2 convolution.  `parity[k]`, k = 2*py + px, is the stride-1 sub-convolution producing the input-gradient pixels
  * (2a+py, 2b+px) from dy and the transposed weights (the taps with (p + pad - k*d) % 2 == 0; y = the strided parity view of gx).  With
  * all n == 4 parities over one dy / one weight tensor the four run as ONE launch (dy staged once, every gx row written whole);

@@ -125,6 +125,7 @@ _PROTOS = {
     'myolo_conv': (C.c_int, [C.POINTER(ConvDesc), P]),
     'myolo_conv_dgrad_s2': (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.c_int, P]),
     'myolo_conv_dgrad_bn': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BnApplyFold), P]),
+    'myolo_conv_pair': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), P]),
     'myolo_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), P]),
     'myolo_bn_act_fwd': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, P]),
     'myolo_bn_act_bwd_reduce': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P]),

@@ -253,6 +253,8 @@ int myolo_conv_small_set(const char* name, int value);
 int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 int myolo_conv_mid_set(const char* name, int value);
 int myolo_conv_mid_mode();
+// conv_pair.hip: "pair_mode" (0: always two launches), "pair_th" (tile height 4 / 8 forced; tests)
+int myolo_conv_pair_set(const char* name, int value);
 // conv_midx.hip: conv_mid with the input of a k x k stride-1 layer resident in LDS as a halo tile; -1 = layer does not qualify
 int myolo_conv_midx_try(const myolo_conv_desc* d, void* stream);
 int myolo_conv_midx_set(const char* name, int value);

@@ -35,7 +35,8 @@ WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
 BN_APPLY_FOLD = os.environ.get('MYOLO_BN_APPLY_FOLD', '1') != '0'
 # 1x1 Conv+BatchNorm+activation layers on maps of <= 1024 pixels (PyramidPooling's branches): one workgroup per layer, the layers of a
 # module in ONE forward and ONE backward launch (csrc/tiny_conv.hip) instead of 2 + 3 launches per layer
-TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '0') != '0'
+CONV_PAIR = os.environ.get('MYOLO_CONV_PAIR', '1') != '0'       # eval: Bottleneck's 1x1 -> 3x3 in one launch (csrc/conv_pair.hip)
+TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '1') != '0'
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -482,6 +483,11 @@ class ConvOp(Op):
                     d.shift = self.shift.data_ptr()
             self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
         self.fdesc = d
+        # eval: a 1x1 layer whose output only this 3x3 layer reads (Bottleneck, models/common.py) runs inside this launch (csrc/conv_pair.hip)
+        first = getattr(self, 'pair_first', None)
+        if first is not None and CONV_PAIR and not training and len(self.fwd_calls) == 1 and len(first.fwd_calls) == 1:
+            first.fwd_calls.clear()
+            self.fwd_calls[0] = Call('myolo_conv_pair', (C.byref(first.fdesc), C.byref(d)))
         if training:
             self._build_bwd(plan, two_pass, has_bn)
 
@@ -1698,14 +1704,9 @@ class Plan:
 
     def _side_stream(self):
         if getattr(self, '_side', None) is None:
-            # experiment switches (round 5): which hardware queue the second stream lands on.  MYOLO_SIDE_SKIP=k takes k streams out of torch's
-            # pool first (HIP hands hardware queues to streams round-robin), MYOLO_SIDE_PRIO=-1 asks for the high-priority pool
-            skip, prio = int(os.environ.get('MYOLO_SIDE_SKIP', '0')), int(os.environ.get('MYOLO_SIDE_PRIO', '0'))
-            self._side_dummies = [torch.cuda.Stream(device=self.device, priority=prio) for _ in range(skip)]
-            for s_ in self._side_dummies:
-                with torch.cuda.stream(s_):
-                    torch.zeros(1, device=self.device)
-            self._side = torch.cuda.Stream(device=self.device, priority=prio)
+            # (round 5: WHICH hardware queue the second stream lands on -- 1-3 streams taken out of torch's pool first, the high-priority
+            #  pool, GPU_MAX_HW_QUEUES=8 -- measured neutral: 961-969 FPS / 7.75-7.81 ms for every placement)
+            self._side = torch.cuda.Stream(device=self.device)
         return self._side
 
     def _bwd_segments(self, reducer):
@@ -2034,12 +2035,12 @@ def conv_call_bytes(call):
         es = 2 if ds[0].x.dtype == L.F16 else 4
         d0 = ds[0]
         return (d0.x.n * d0.x.h * d0.x.w * d0.x.c + sum(d.y.n * d.y.h * d.y.w * d.y.c for d in ds) + d0.y.c * d0.wtaps * d0.x.c) * es
-    d = _conv_desc_of(call)
-    es = 2 if d.x.dtype == L.F16 else 4
-    xin = d.x.n * d.x.h * d.x.w * d.x.c
-    yout = d.y.n * d.y.h * d.y.w * d.y.c
-    w = d.y.c * d.ntaps * d.x.c
-    return (xin + yout + w) * es
+    tot = 0
+    for a in (call.args[:2] if call.name == 'myolo_conv_pair' else call.args[:1]):   # (a fused pair counts both layers' SURVEY 8(d) bytes: no fusion credit)
+        d = a._obj
+        es = 2 if d.x.dtype == L.F16 else 4
+        tot += (d.x.n * d.x.h * d.x.w * d.x.c + d.y.n * d.y.h * d.y.w * d.y.c + d.y.c * d.ntaps * d.x.c) * es
+    return tot
 
 
 def apply_fold_bytes(call):

@@ -117,7 +117,13 @@ class Bottleneck(PlannedModule):
         self.add = shortcut and c1 == c2
 
     def emit(self, plan, x):
-        return self.cv2.emit(plan, self.cv1.emit(plan, x), res=x if self.add else None)
+        bn1 = self.cv1.bn if hasattr(self.cv1, 'bn') else None
+        bn2 = self.cv2.bn if hasattr(self.cv2, 'bn') else None
+        t, op1 = emit_conv(plan, x, self.cv1.conv, bn1, _act_code(self.cv1.act))
+        y, op2 = emit_conv(plan, t, self.cv2.conv, bn2, _act_code(self.cv2.act), res=x if self.add else None)
+        if not plan.training:
+            op2.pair_first = op1          # cv1's output has this one reader: eval plans run both layers in one launch (myolo_conv_pair)
+        return y
 
 
 class C3(PlannedModule):

@@ -195,7 +195,7 @@ def wgrad_ref(wd):
     return out, dyf.double().sum(0).float()
 
 
-CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad')
+CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair')
 
 
 class LaunchChecker:
@@ -275,6 +275,14 @@ class LaunchChecker:
             self.orig(call, st)
             torch.cuda.synchronize()
             self._conv_post(d, pre, self._what('conv', d))
+        elif name == 'myolo_conv_pair':         # myolo.h: b(a(x)), the intermediate rounded to the storage type, a->y not necessarily written
+            a, b = self._desc(call.args[0]), self._desc(call.args[1])
+            t = conv_epilogue(a, conv_acc(a))
+            t = t.half().float() if a.y.dtype == L.F16 else t
+            ref = conv_epilogue(b, conv_acc(b, x=t))
+            self.orig(call, st)
+            torch.cuda.synchronize()
+            self._ck(self._what('pair', b) + '/y', read_out(b), ref, self.tol_out)
         elif name == 'myolo_conv_dgrad_s2':
             arr, n = call.args[0], call.args[1]
             ds = [arr[i].contents for i in range(n)]

@@ -71,7 +71,7 @@ def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32()
     Conv+BatchNorm+SiLU ones with the apply fold) and 79 weight-gradient launches"""
     lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 100, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 5, 'myolo_conv_dgrad_bn': 10})
     fam = ' '.join(sites)
-    for k in ('conv_mid', 'conv_midx', 'conv_halo', 'conv_stream', 'conv_igemm', 'wgt::', 'wgrad'):
+    for k in ('mid::launch', 'midx::launch', 'halo::launch', 'stream::launch', 'launch_conv4', 'wgt::launch'):     # every conv family DESIGN section 3 names
         assert k in fam, (k, sorted(sites))
 
 
@@ -100,7 +100,7 @@ def test_every_conv_launch_of_the_detect_frame_matches_torch_fp32(size):
     sites = _dump_trace(f'frame{W}x{H}')
     assert not lc.bad, f'{len(lc.bad)} of {lc.k} launches differ from torch fp32:\n' + '\n'.join(lc.bad[:40])
     assert lc.n.get('myolo_conv', 0) >= 60 and torch.isfinite(out[0][0].float()).all()
-    assert any('conv_small' in s for s in sites) or H > 512
+    assert any('small::launch' in s for s in sites) and any('mid::launch' in s for s in sites)
     # the graph replays that follow run the same descriptors: same outputs
     ref = [out[0][0].clone(), out[1].float().clone()]
     for _ in range(4):
