@@ -594,8 +594,15 @@ def main():
         exposed_ms = sum(a.elapsed_time(b) for a, b in tr.reducer.exposed) / len(tr.reducer.exposed)
         tr.reducer.exposed = None
     checks = step_checks(tr)                             # finite losses, no skipped optimizer step in the timed region
+    per_rank_ms = None
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        # every rank's own wall time of the timed region (diagnosis of a scaling run from ONE line: a straggler rank, or all ranks slow),
+        # then the MAX over ranks is the job's time
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [float(e.item()) / args.steps * 1e3 for e in every]
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms = dt / args.steps * 1e3
@@ -623,6 +630,13 @@ def main():
         # the main stream's wait for the RCCL slices at the end of the backward (HIP events, mean over the timed steps, this rank):
         # what the overlap with the backward did NOT hide
         out['allreduce_exposed_ms'] = exposed_ms
+        out['per_rank_ms_per_step'] = per_rank_ms
+        try:
+            out['collective_library'] = {'backend': dist.get_backend(), 'rccl_version': '.'.join(str(v) for v in torch.cuda.nccl.version())}
+        except Exception as e:                           # (gloo smoke runs: no RCCL in the process)
+            out['collective_library'] = {'backend': dist.get_backend(), 'rccl_version': None, 'note': repr(e)}
+        if getattr(tr, 'reducer', None) is not None:
+            out['grad_exchange_detail'] = tr.reducer.describe()
     if args.stage != 'train':
         out['metric'] = 'DEV ONLY fwd+bwd images/sec (no loss / optimizer) -- not a bench line'
     if rank == 0 and world == 1:
@@ -678,7 +692,23 @@ def main():
             if sb:
                 out['stock_rocm_baseline']['speedup_train'] = out['value'] / sb
     if rank == 0:
-        print(json.dumps(out))
+        # the secondary figures as short scalars right behind the headline fields (the nested objects at the end of the line did
+        # not survive the driver's stdout truncation): FPS of the detect.py path at both sizes, the yolov5m + Lab share of config 4, the
+        # reference loop body as written, the CPU oracle port
+        def num(path):
+            v = out
+            for k in path:
+                v = v.get(k) if isinstance(v, dict) else None
+            return round(v, 3) if isinstance(v, (int, float)) else None
+        short = {'fps_2048x1024': num(('detect_fps', 'value')), 'fps_1024x512': num(('detect_fps_1024x512', 'value')),
+                 'm_lab_bs8_img_s': num(('train_m_lab', 'value')), 'train_py_pairs_s': num(('train_py_step', 'pairs_per_s')),
+                 'conv_roofline_frac': num(('roofline', 'frac')), 'step_roofline_frac': num(('whole_step_roofline', 'frac')),
+                 'cpu_port_img_s': num(('cpu_baseline', 'value')), 'stock_rocm_img_s': num(('stock_rocm_baseline', 'train', 'images_per_s'))}
+        head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step')
+        line = {k: out[k] for k in head if k in out}
+        line['secondary'] = {k: v for k, v in short.items() if v is not None}
+        line.update({k: v for k, v in out.items() if k not in head})
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
 

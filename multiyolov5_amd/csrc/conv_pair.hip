@@ -244,18 +244,19 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_pair_kernel(const PairK p) 
 #pragma unroll
           for (int h = 0; h < CF / 2; ++h) {
             const int c0 = m * BN + wc * CW + 32 * h + 8 * lq;        // 8 consecutive mid channels of this lane
-            u32x4_t k0, k1, k2, k3;
+            u32x4_t kq[4];                                            // [0..1]: sc1[c0 .. c0+7], [2..3]: sh1[c0 .. c0+7]
             const unsigned ca = cst0 + c0 * 4;
-            asm volatile("ds_read_b128 %0, %1" : "=v"(k0) : "v"(ca) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(k1) : "v"(ca) : "memory");
-            asm volatile("ds_read_b128 %0, %1" : "=v"(k2) : "v"(ca + (unsigned)p.C * 4) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(k3) : "v"(ca + (unsigned)p.C * 4) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kq[0]) : "v"(ca) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(kq[1]) : "v"(ca) : "memory");
+            asm volatile("ds_read_b128 %0, %1" : "=v"(kq[2]) : "v"(ca + (unsigned)p.C * 4) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:16" : "=v"(kq[3]) : "v"(ca + (unsigned)p.C * 4) : "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(k0)); asm volatile("" : "+v"(k1)); asm volatile("" : "+v"(k2)); asm volatile("" : "+v"(k3));
-            const float sc[8] = {__builtin_bit_cast(float, k0.x), __builtin_bit_cast(float, k0.y), __builtin_bit_cast(float, k0.z), __builtin_bit_cast(float, k0.w),
-                                 __builtin_bit_cast(float, k1.x), __builtin_bit_cast(float, k1.y), __builtin_bit_cast(float, k1.z), __builtin_bit_cast(float, k1.w)};
-            const float sh[8] = {__builtin_bit_cast(float, k2.x), __builtin_bit_cast(float, k2.y), __builtin_bit_cast(float, k2.z), __builtin_bit_cast(float, k2.w),
-                                 __builtin_bit_cast(float, k3.x), __builtin_bit_cast(float, k3.y), __builtin_bit_cast(float, k3.z), __builtin_bit_cast(float, k3.w)};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(kq[i]));
+            // (element-wise __builtin_bit_cast(float, k.y) of an ext_vector read element x for every lane here: hipcc 7.2; go through memory
+            //  like conv_mid.hip's apply constants)
+            const float* sc = reinterpret_cast<const float*>(&kq[0]);
+            const float* sh = reinterpret_cast<const float*>(&kq[2]);
             float v[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) { v[r] = acc1[m][2 * h][q][r]; v[4 + r] = acc1[m][2 * h + 1][q][r]; }

@@ -52,7 +52,7 @@ class GradReducer:
         view = flat[lo:hi]
         if flat.is_cuda:
             if self.stream is None:
-                self.stream = torch.cuda.Stream(device=flat.device)
+                self.stream = torch.cuda.Stream(device=flat.device, priority=self._low_priority())
             ev = torch.cuda.Event()
             ev.record()
             self.stream.wait_event(ev)
@@ -85,6 +85,29 @@ class GradReducer:
             self.exposed.append((e0, e1))
             return
         torch.cuda.current_stream().wait_stream(self.stream)
+
+    @staticmethod
+    def _low_priority():
+        """the communication stream only carries the pre-divide and the hand-over to RCCL (ProcessGroupNCCL runs the collective itself on
+        its own stream, ordered behind this one): lowest priority the device offers, so that its two small kernels per slice never
+        pre-empt the dgrad / BatchNorm chain on the launch stream (MYOLO_REDUCER_PRIO overrides).  Ordering against the
+        weight-gradient stream: Plan._bwd_eager / the staged backward make the LAUNCH stream wait for the weight-gradient stream before a
+        slice is handed over (the slice must be final), and the event recorded on the launch stream right here orders this stream behind
+        both -- the exchange never runs beside a weight gradient that still writes into its slice."""
+        import os
+        if 'MYOLO_REDUCER_PRIO' in os.environ:
+            return int(os.environ['MYOLO_REDUCER_PRIO'])
+        try:
+            lo, hi = torch.cuda.Stream.priority_range()          # (least, greatest): numerically larger = lower priority
+            return int(lo)
+        except Exception:                                        # noqa: BLE001 -- older torch: default priority
+            return 0
+
+    def describe(self):
+        """one-line diagnosis data for bench.py's N > 1 line"""
+        return {'buckets': self.nbuckets, 'world': self.world, 'pre_divide_then_sum': True,
+                'comm_stream_priority': getattr(self.stream, 'priority', None) if self.stream is not None else None,
+                'slices_issued_last_step': len(self._works)}
 
     def wait(self):
         """kept for call-site symmetry with DDP's implicit sync: PlanFn.backward already waited before handing out grads."""

@@ -69,7 +69,7 @@ def _train_step_checked(args, tag, expect):
 def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32():
     """BASELINE configs[1]: 79 convolutions -> 70 forward launches (9 merged pairs), their dgrads (stride-2 ones as one fused launch, 1x1
     Conv+BatchNorm+SiLU ones with the apply fold) and 79 weight-gradient launches"""
-    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 100, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 5, 'myolo_conv_dgrad_bn': 10})
+    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 5, 'myolo_conv_dgrad_bn': 10})
     fam = ' '.join(sites)
     for k in ('mid::launch', 'midx::launch', 'halo::launch', 'stream::launch', 'launch_conv4', 'wgt::launch'):     # every conv family DESIGN section 3 names
         assert k in fam, (k, sorted(sites))
@@ -78,7 +78,7 @@ def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32()
 def test_every_conv_launch_of_the_yolov5m_lab_share_matches_torch_fp32():
     """BASELINE configs[3]'s per-GPU share: yolov5m + Lab head (ASPP encoder, FFM), batch 8, fp16: the 48 / 96 / 192 / 384 / 768-channel
     layers and the dilated 3x3 of ASPP at their real tile counts"""
-    _train_step_checked(_args(cfg='yolov5m_city_seg_lab.yaml', batch=8), 'mlab8', {'myolo_conv': 140, 'myolo_conv_wgrad': 99})
+    _train_step_checked(_args(cfg='yolov5m_city_seg_lab.yaml', batch=8), 'mlab8', {'myolo_conv': 130, 'myolo_conv_wgrad': 99})
 
 
 @pytest.mark.parametrize('size', [(1024, 2048), (512, 1024)], ids=['2048x1024', '1024x512'])
@@ -99,7 +99,7 @@ def test_every_conv_launch_of_the_detect_frame_matches_torch_fp32(size):
         torch.cuda.synchronize()
     sites = _dump_trace(f'frame{W}x{H}')
     assert not lc.bad, f'{len(lc.bad)} of {lc.k} launches differ from torch fp32:\n' + '\n'.join(lc.bad[:40])
-    assert lc.n.get('myolo_conv', 0) >= 60 and torch.isfinite(out[0][0].float()).all()
+    assert lc.n.get('myolo_conv', 0) + 2 * lc.n.get('myolo_conv_pair', 0) >= 60 and torch.isfinite(out[0][0].float()).all()
     assert any('small::launch' in s for s in sites) and any('mid::launch' in s for s in sites)
     # the graph replays that follow run the same descriptors: same outputs
     ref = [out[0][0].clone(), out[1].float().clone()]

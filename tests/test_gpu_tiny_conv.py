@@ -202,7 +202,7 @@ def test_tiny_conv_on_and_off_give_the_same_step_at_the_bench_batch(dtype, monke
         torch.cuda.synchronize()
         plan = next(iter(m.__dict__['_plans'].values())).plan
         ntiny = sum(c.name == 'myolo_tiny_conv_fwd' for op in plan.ops for c in op.fwd_calls)
-        assert ntiny == (3 if on else 0), ntiny
+        assert ntiny == ((3 if dtype == torch.float16 else 6) if on else 0), ntiny      # (fp32 weights of the pyramid branches: one layer per launch, LDS)
         res[on] = (float(loss), float(sl), {k: p.grad.detach().float().cpu().clone() for k, p in m.named_parameters()})
         del m, plan
     (l0, s0, g0), (l1, s1, g1) = res[False], res[True]
