@@ -71,13 +71,7 @@ int myolo_pack_weight(const void* w_oihw, int src_dtype, int cout, int cin, int 
  * chunk_elems <= 0: LDS-tiled mode (-chunk_elems = the largest tap count of any job, 0 = up to MYOLO_MAX_TAPS: sizes the LDS
  * tile) -- chunks = {job, tile}; a tile is 16 co x 32 ci (transpose = 0) or 32 co x 16 ci (transpose = 1)
  * over all taps (64 co x 64 ci for 1x1 weights), tiles numbered co-tile major over ceil(cout_all / tco) x ceil(cin / tci); only the valid region is written (the
- * caller keeps the padding of dst zero).
- * transpose = 2 + py (tiled mode only; round 5): src is a 3x3 OIHW weight of a stride-2 pad-1 convolution, dst[2*cin rows (px, ci)][ntaps slots]
- * [cols_pad >= cout] is its dgrad operand for the gradient rows of parity py with both column parities side by side (slots: the 1 x 2 (py 0,
- * ntaps 2) or 2 x 2 (py 1, ntaps 4) neighbourhood of dy; slot (dyi, dxi) holds W[:, :, ky, kx] with ky = 1 | (2, 0)[dyi], kx = (1, none)[dxi] for
- * px 0 and (2, 0)[dxi] for px 1; unused slots are not written) -- the autograd dgrad of nn.Conv2d(k=3, s=2, p=1) (common.py:38) becomes two
- * ordinary stride-1 myolo_conv launches whose output pixels are 2*cin contiguous channels of a dense gradient; chunks = {job, first element of a
- * run of 8192 dst elements}. */
+ * caller keeps the padding of dst zero). */
 int myolo_pack_weights_mt(const int64_t* jobs, const int32_t* chunks, int nchunks, int chunk_elems, void* stream);
 
 /* Focus slicing + cat (common.py:550) fused with the image cast: NCHW [n,3,h,w] (f32|f16|u8, value*mul)

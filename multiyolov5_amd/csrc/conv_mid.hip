@@ -571,20 +571,27 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   const int bn = d->cout_pad % 128 == 0 ? 128 : 64;
   const int ntile_c = d->cout_pad / bn;
   int var = g_mid_var;
+  // round 5, yolov5m's widths (models/yolov5m_city_seg.yaml: 192 / 384 channels): a 192-wide N tile instead of three 64-wide ones that each
+  // stage the same pixel rows again (37 + 23 launches of the yolov5m + Lab step ran <128, 64> tiles); only with at least one tile per CU
+  static const int no192 = getenv("MYOLO_MID_NO_BN192") != nullptr;
+  const bool wide192 = !bf && !no192 && (d->cout_pad == 192 || d->cout_pad == 384 || d->cout_pad == 576) &&
+                       ((M + 127) / 128) * (d->cout_pad / 192) >= 256;
+  if (var == 0 && wide192) var = 6;
+  if (var == 6 && (d->cout_pad % 192 || bf)) var = 0;
   if (var == 0) {
     var = bn == 64 ? 2 : (((M + 127) / 128) * ntile_c < g_mid_min_tiles ? 3 : 1);
     // K-heavy layers with >= 2 tiles of 256 x 128 per CU: 64 x 64 wave tiles (2/3 of the LDS and L2 bytes per MFMA; the segmentation
     // head's 3x3 256 -> 128 at 64x128: 106 -> 94 us, its dgrad 114 -> 103; scripts/conv_train_ubench.py PROBE=mid)
     if (var == 1 && ((M + 255) / 256) * ntile_c >= 512 && d->ntaps * (d->cin_pad / 64) >= 16) var = 4;
   }
-  if (bn == 64) var = 2;
+  if (bn == 64 && var != 6) var = 2;
   const int bm = var == 3 ? 64 : (var == 4 ? 256 : 128);
   k.ntile_p = (int)((M + bm - 1) / bm);
   k.tiles_per_xcd = (k.ntile_p + 7) / 8;
   if (var == 1 && k.nsteps < 3) var = 5;               // (short K loops: the three-stage ring)
   if (bf) var = (var == 2 || var == 3) ? var : 5;      // (two pixel tiles per stage: three stages fill the LDS)
   hipStream_t st = (hipStream_t)stream;
-  const int bn_eff = var == 2 ? 64 : 128, ntc = d->cout_pad / bn_eff;
+  const int bn_eff = var == 2 ? 64 : (var == 6 ? 192 : 128), ntc = d->cout_pad / bn_eff;
   // the BatchNorm-backward sums of the layer(s) below ride in the epilogue when every segment is a whole number of N tiles
   static const int no_fold = getenv("MYOLO_MID_NO_BNB") != nullptr;
   const bool fold = d->bnb && d->nbnb > 0 && d->nbnb <= MYOLO_MAX_BNB && !d->stats && !no_fold && !k.dbg && bnb_aligned(d, bn_eff);
@@ -603,6 +610,7 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   if (var == 4) MID_GO(256, 128, 4, 2, 3, 1);       // 64 x 64 wave tiles
   if (var == 5) MID_GO(128, 128, 4, 2, 3, 1);       // three stages
   if (var == 2) MID_GO(128, 64, 2, 2, 3, 2);
+  if (var == 6) MID_GO(128, 192, 4, 2, 3, 1);       // 192-wide N tile (yolov5m)
   MID_GO(64, 128, 1, 4, 3, 2);
 #undef MID_GO
 }

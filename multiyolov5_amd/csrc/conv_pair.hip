@@ -445,10 +445,18 @@ static int pair_try(const myolo_conv_desc* a, const myolo_conv_desc* b, void* st
   const int bn = (C == 64 || b->cout_pad % 128) ? 64 : 128;
   const int ntc = b->cout_pad / bn, nmt = C / bn;
   if (nmt > 2 || C % bn) return -1;
-  // tile height: 8 rows unless that leaves most CUs without a workgroup (batch-1 frames) or the accumulators of two mid passes get too many
-  const int64_t tiles8 = (int64_t)a->x.n * ((k.W + 15) / 16) * ((k.H + 7) / 8);
-  int th = (tiles8 * ntc < 192 || nmt == 2) ? 4 : 8;
+  // When the fused launch pays (hipGraph-timed per Bottleneck against the two-launch form, scripts/pair_ubench.py -> profiles/r5d_pair_ubench.txt,
+  // us: two launches / fused 4-row tiles / fused 8-row tiles):
+  //   C  64 @128x256  20.3 / 13.0 / 15.7     C 128 @64x128  22.2 / 16.0 / 21.8     C 256 @32x64  23.9 / 28.8 / -
+  //   C  64 @ 64x128  15.0 / 11.3 / 15.2     C 128 @32x64   14.2 / 16.0 / 21.5     C 256 @16x32  14.3 / 28.4 / -
+  //   C  64 @ 32x64    9.1 / 11.1 / 15.0     C 128 @16x32   11.7 / 15.6 / 21.4
+  // -> 4-row tiles always (twice the workgroups; the halo recompute is a ninth of the work), only from 96 such tiles on (below that the split-K
+  // small-map kernels of the two-launch form fill the chip better), never the two-pass 256-channel form (GEMM 1 twice per N tile).
+  // myolo_set_option("pair_th", 4 | 8) forces a tile height and lifts both limits (tests run every variant).
+  const int64_t tiles4 = (int64_t)a->x.n * ((k.W + 15) / 16) * ((k.H + 3) / 4);
+  int th = 4;
   if (g_pair_th == 4 || g_pair_th == 8) th = (g_pair_th == 8 && nmt == 2) ? 4 : g_pair_th;
+  else if (nmt == 2 || tiles4 < 96) return -1;
   k.HW = 18; k.HP = (th + 2) * 18;
   const int hppad = (k.HP + 15) / 16 * 16;
   k.pshift = C == 64 ? 7 : (C == 128 ? 8 : 9);

@@ -115,43 +115,11 @@ __device__ __forceinline__ void pack_tile_body(float* tile, const int64_t* e, in
   }
 }
 
-// transpose = 2 + py (round 5): the dgrad operand of a 3x3 stride-2 pad-1 convolution for the output rows of parity py, BOTH column parities
-// in one tensor -- dst[(px, ci)][slot][co], rows [0, cin) = px 0, [cin, 2 cin) = px 1, slot = (dyi, dxi) of the 1 x 2 (py 0) or 2 x 2 (py 1)
-// neighbourhood of dy the pixel pair (2a+py, 2b), (2a+py, 2b+1) reads:  gx[2a+py, 2b+px] = sum over (ky, kx) with 2 oy + ky - 1 = 2a+py and
-// 2 ox + kx - 1 = 2b+px of dy[oy, ox] . W[:, :, ky, kx]  ->  py 0: ky = 1 (oy = a); py 1: ky = 2 (oy = a), ky = 0 (oy = a+1); px 0: kx = 1
-// (ox = b); px 1: kx = 2 (ox = b), kx = 0 (ox = b+1).  Slots a column parity does not use stay at the zeros the tensor was allocated with.
-// With it the stride-2 dgrad is two ordinary stride-1 convolutions whose output pixels are 2 * cin contiguous channels of the DENSE gradient
-// (engine.ConvOp._build_bwd): chunks = {job, first element of an 8192-element run of dst}.
-__device__ __forceinline__ void pack_s2_dgrad_body(const int64_t* e, int s0) {
-  const void* src = reinterpret_cast<const void*>(e[0]);
-  void* dst = reinterpret_cast<void*>(e[1]);
-  const int cout = (int)e[2], cin = (int)e[3], T = (int)e[4], rows_pad = (int)e[5], cols_pad = (int)e[6], py = (int)e[7] - 2;
-  const bool f16s = (int)e[8] == MYOLO_F16, f16d = (int)e[9] == MYOLO_F16;
-  const int64_t total = (int64_t)rows_pad * T * cols_pad;
-  for (int k = 0; k < 32; ++k) {
-    const int64_t i = (int64_t)s0 + k * 256 + threadIdx.x;
-    if (i >= total) break;
-    const int col = (int)(i % cols_pad);
-    const int t = (int)((i / cols_pad) % T);
-    const int row = (int)(i / ((int64_t)cols_pad * T));
-    if (col >= cout || row >= 2 * cin) continue;
-    const int px = row / cin, ci = row - px * cin;
-    const int dyi = py ? (t >> 1) : 0, dxi = py ? (t & 1) : t;
-    const int ky = py ? (dyi ? 0 : 2) : 1;
-    const int kx = dxi ? (px ? 0 : -1) : (px ? 2 : 1);
-    if (kx < 0) continue;
-    const int64_t si = (((int64_t)col * cin + ci) * 3 + ky) * 3 + kx;
-    const float v = f16s ? (float)((const half_t*)src)[si] : ((const float*)src)[si];
-    if (f16d) ((half_t*)dst)[i] = (half_t)v; else ((float*)dst)[i] = v;
-  }
-}
-
 __global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const int64_t* __restrict__ jobs, const int32_t* __restrict__ chunks) {
   extern __shared__ float tile[];          // [tco][tci * taps]
   const int j = chunks[blockIdx.x * 2], tid_tile = chunks[blockIdx.x * 2 + 1];
   const int64_t* e = jobs + (int64_t)j * 12;
   const int ntaps = (int)e[4], transpose = (int)e[7];
-  if (transpose >= 2) { pack_s2_dgrad_body(e, tid_tile); return; }
   if (ntaps == 1) { if (transpose) pack_tile_body<1, true>(tile, e, tid_tile, 1, 1); else pack_tile_body<1, false>(tile, e, tid_tile, 1, 0); }
   else if (ntaps == 9) { if (transpose) pack_tile_body<9, true>(tile, e, tid_tile, 9, 1); else pack_tile_body<9, false>(tile, e, tid_tile, 9, 0); }
   else pack_tile_body<0, false>(tile, e, tid_tile, ntaps, transpose);

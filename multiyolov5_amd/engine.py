@@ -35,7 +35,6 @@ WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
 BN_APPLY_FOLD = os.environ.get('MYOLO_BN_APPLY_FOLD', '1') != '0'
 # 1x1 Conv+BatchNorm+activation layers on maps of <= 1024 pixels (PyramidPooling's branches): one workgroup per layer, the layers of a
 # module in ONE forward and ONE backward launch (csrc/tiny_conv.hip) instead of 2 + 3 launches per layer
-S2_DENSE = os.environ.get('MYOLO_S2_DENSE', '1') != '0'         # dgrad of a 3x3 stride-2 conv whose input gradient is dense: two stride-1 launches over pixel PAIRS
 CONV_PAIR = os.environ.get('MYOLO_CONV_PAIR', '1') != '0'       # eval: Bottleneck's 1x1 -> 3x3 in one launch (csrc/conv_pair.hip)
 TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '1') != '0'
 
@@ -595,33 +594,10 @@ class ConvOp(Op):
                 self.bnb_arr = bnb
             gx_full = self.x.desc(grad=True)
             es = 2 if dt == torch.float16 else 4
-            # round 5: a 3x3 stride-2 pad-1 layer whose input gradient is a DENSE tensor (pixel pitch == its channels, even map): the gradient
-            # pixels (2a+py, 2b) and (2a+py, 2b+1) are 2*cin contiguous channels of row 2a+py, so each row parity is ONE ordinary stride-1
-            # convolution over dy with 2 (py 0) / 4 (py 1) taps and 2*cin output channels (zero weight slots where a column parity has no tap:
-            # 12 instead of 9 tap-blocks of MACs) -- two conv_mid / conv_midx launches with 16-byte row-contiguous stores instead of the round-2
-            # halo kernel's four strided parity classes (84.9 / 73.7 / 81.9 us for the three layers it still ran, profiles/r4e_conv_layers.txt)
-            dense2 = (S2_DENSE and PACK_TILED and s == 2 and self.k == 3 and self.d == 1 and self.pad == 1 and dt == torch.float16 and
-                      self.weight2 is None and bnb is None and gx_full.sw == gx_full.c == self.cin and self.x.h % 2 == 0 and self.x.w % 2 == 0 and
-                      (2 * self.cin) % 64 == 0 and dy_desc.c % 64 == 0 and dy_desc.c == self.cout and
-                      (self.out.h, self.out.w) == (self.x.h // 2, self.x.w // 2))
-            if dense2:
-                rows_pad, cols_pad = rup(2 * self.cin, 64), rup(dy_desc.c, kc)
-                self.wpack_s2 = []
-                for py in range(2):
-                    T = 4 if py else 2
-                    wp2 = torch.zeros(rows_pad, T, cols_pad, dtype=dt, device=dev)
-                    self.wpack_s2.append(wp2)
-                    plan.add_pack_job(self.weight, wp2, self.cout, self.cin, T, rows_pad, cols_pad, 2 + py)
-                    g = L.ConvDesc()
-                    g.x, g.w = dy_desc, wp2.data_ptr()
-                    g.y = CT(gx_full.ptr + py * gx_full.sh * es, gx_full.n, self.x.h // 2, self.x.w // 2, 2 * self.cin,
-                             gx_full.sn, gx_full.sh * 2, gx_full.sw * 2, gx_full.dtype, 0)
-                    g.cin_pad, g.cout_pad, g.wtaps, g.ntaps, g.stride, g.up_shift = cols_pad, rows_pad, T, T, 1, 0
-                    fill_taps(g, [0, 0, 1, 1][:T], [0, 1, 0, 1][:T], list(range(T)))
-                    g.act, g.accumulate, g.res = L.ACT_NONE, self.acc_x, null_tensor()
-                    self.dg.append(g)
-                    calls.append(Call('myolo_conv', (C.byref(g),), keep='s2dense_py%d' % py))
-            for py in range(0 if dense2 else s):
+            # (round 5, measured and removed: a stride-2 layer with a DENSE input gradient as two stride-1 convolutions over pixel pairs -- zero-slotted
+            #  weight tensors, 2*cin contiguous output channels -- through conv_midx instead of the round-2 parity kernel: 7.682 vs 7.674 ms per step;
+            #  those launches are HBM-bound either way (dy read twice: 268 MB for the stem's layer), profiles/r5d_threshold_sweep.txt)
+            for py in range(s):
                 for px in range(s):
                     tdy, tdx, tw = taps_dgrad(self.k, self.d, self.pad, s, py, px)
                     hh, ww = (self.x.h - py + s - 1) // s, (self.x.w - px + s - 1) // s
@@ -1245,10 +1221,7 @@ class Plan:
         for j, (w, dst, cout, cin, ntaps, rp, cp, tr, w2) in enumerate(self._pack_jobs):
             rows.append((w.data_ptr(), dst.data_ptr(), cout, cin, ntaps, rp, cp, tr, L.DT[w.dtype], L.DT[dst.dtype],
                          w2.data_ptr() if w2 is not None else 0, w2.shape[0] if w2 is not None else 0))
-            if tr >= 2:                   # stride-2 dgrad operand (pack.hip pack_s2_dgrad_body): runs of 8192 destination elements
-                for s0 in range(0, rp * ntaps * cp, CH):
-                    chunks.append((j, s0))
-            elif PACK_TILED:              # LDS-tiled pack: coalesced source reads (the packed tensors are zero-initialised: padding stays)
+            if PACK_TILED:              # LDS-tiled pack: coalesced source reads (the packed tensors are zero-initialised: padding stays)
                 ca = cout + (w2.shape[0] if w2 is not None else 0)
                 tco, tci = (64, 64) if ntaps == 1 else ((32, 16) if tr else (16, 32))
                 for t_ in range(((ca + tco - 1) // tco) * ((cin + tci - 1) // tci)):
@@ -2066,9 +2039,6 @@ def conv_call_bytes(call):
         d0 = ds[0]
         return (d0.x.n * d0.x.h * d0.x.w * d0.x.c + sum(d.y.n * d.y.h * d.y.w * d.y.c for d in ds) + d0.y.c * d0.wtaps * d0.x.c) * es
     tot = 0
-    if call.keep == 's2dense_py1':               # second row parity of a dense stride-2 dgrad: dy is the same operand as in the first launch
-        d = call.args[0]._obj
-        tot -= d.x.n * d.x.h * d.x.w * d.x.c * (2 if d.x.dtype == L.F16 else 4)
     for a in (call.args[:2] if call.name == 'myolo_conv_pair' else call.args[:1]):   # (a fused pair counts both layers' SURVEY 8(d) bytes: no fusion credit)
         d = a._obj
         es = 2 if d.x.dtype == L.F16 else 4

@@ -91,6 +91,30 @@ def test_conv_mid_forward_with_statistics(shape, var):
     _run(*shape, var=var)
 
 
+M_SHAPES = [
+    # yolov5m's widths (models/yolov5m_city_seg.yaml), forced onto the 192-wide N tile of round 5 (var 6; auto takes it from 256 tiles on)
+    (96 * 2, 192, 1, 1, 1, 2, 32, 64),       # 4.cv3-like: 192 -> 192
+    (192, 192, 3, 1, 1, 2, 32, 64),          # 3x3 192 -> 192: K = 1728
+    (192, 384, 1, 1, 1, 2, 32, 64),          # two 192-wide tiles
+    (192, 384, 3, 2, 1, 1, 64, 64),          # 5.conv of yolov5m (stride 2)
+    (128, 192, 1, 1, 1, 1, 31, 37),          # ragged pixel count
+    (384, 192, 1, 1, 1, 8, 64, 128),         # lab reduce at batch 8: 512 tiles (the shape `auto` picks the tile for)
+]
+
+
+@pytest.mark.parametrize('shape', M_SHAPES, ids=[f'{s[0]}-{s[1]}k{s[2]}s{s[3]}_{s[5]}x{s[6]}x{s[7]}' for s in M_SHAPES])
+def test_conv_mid_192_wide_tiles(shape):
+    from multiyolov5_amd import _lib as L
+    _run(*shape, var=6)
+    _run(*shape, var=6, stats=False, accumulate=True, res=True)
+    if shape[5] == 8:                           # auto selection really is the 192-wide tile here
+        L.lib().myolo_trace_start(1)
+        _run(*shape, var=0)
+        sites = L.launch_trace()
+        L.lib().myolo_trace_start(0)
+        assert any('BN = 192' in s_ for s_ in sites), sorted(sites)
+
+
 @pytest.mark.parametrize('var', [1, 2, 3, 4, 5])
 def test_conv_mid_dgrad_epilogues(var):
     """the dgrad call shapes: no statistics, accumulate into y, residual add, both"""
@@ -108,8 +132,8 @@ def test_conv_mid_takes_the_layers_and_is_deterministic():
     _run(128, 128, 3, 1, 1, 2, 32, 64, 0, mode=0)
 
 
-@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5])
-@pytest.mark.parametrize('case', ['1x1', '3x3_acc', 'two_segments', 'narrow_segments', 'slice_end'])
+@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('case', ['1x1', '3x3_acc', 'two_segments', 'narrow_segments', 'slice_end', 'wide192', 'two_192'])
 def test_conv_mid_bn_backward_sums_in_the_epilogue(case, var):
     """myolo_conv_desc.bnb through conv_mid: the sums the conv launch leaves in `dsum` equal what myolo_bn_act_bwd_reduce computes from the
     gradient that launch stored.  'two_segments': 128 + 128 channels (one N tile each); 'narrow_segments': 64 + 192 (not tile aligned for
@@ -119,9 +143,9 @@ def test_conv_mid_bn_backward_sums_in_the_epilogue(case, var):
     torch.manual_seed(1)
     n, H, W, cin = 2, 24, 40, 128
     k = 3 if case == '3x3_acc' else 1
-    cout = {'1x1': 128, '3x3_acc': 128, 'two_segments': 256, 'narrow_segments': 256, 'slice_end': 192}[case]
+    cout = {'1x1': 128, '3x3_acc': 128, 'two_segments': 256, 'narrow_segments': 256, 'slice_end': 192, 'wide192': 192, 'two_192': 384}[case]
     segs = {'1x1': [(0, 128)], '3x3_acc': [(0, 128)], 'two_segments': [(0, 128), (128, 256)], 'narrow_segments': [(0, 64), (64, 256)],
-            'slice_end': [(0, 64), (64, 192)]}[case]
+            'slice_end': [(0, 64), (64, 192)], 'wide192': [(0, 192)], 'two_192': [(0, 192), (192, 384)]}[case]      # (var 6: the 192-wide N tile)
     acc = case == '3x3_acc'
 
     def td(t, c0=0, c=None):
@@ -169,7 +193,7 @@ def test_conv_mid_bn_backward_sums_in_the_epilogue(case, var):
         check(f'mid_bnb/{case}/var{var}/seg{i}', got, want, 2e-4)
 
 
-@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('shape', [(128, 128, 3, 1, 1, 1, 64, 128), (64, 64, 3, 1, 1, 1, 128, 256), (256, 192, 1, 1, 1, 1, 33, 64), (128, 256, 3, 2, 1, 1, 64, 128)],
                          ids=['128-128k3', '64-64k3', '256-192k1_ragged', '128-256k3s2'])
 def test_conv_mid_eval_epilogue(shape, var):

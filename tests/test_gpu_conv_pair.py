@@ -23,7 +23,15 @@ def _view(L, t, c0, c):
     return L.Tensor(t.data_ptr() + c0 * 2, n, h, w, c, sn, sh, sw, L.F16, 0)
 
 
-def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0, expect_fused=True):
+def _gate(C_, B, H, W, th, cout):
+    """csrc/conv_pair.hip pair_try: forced tile heights always fuse; auto only from 96 four-row tiles on and never the two-pass form"""
+    if th:
+        return True
+    bn = 64 if (C_ == 64 or (cout or C_) % 128) else 128
+    return C_ // bn == 1 and B * ((W + 15) // 16) * ((H + 3) // 4) >= 96
+
+
+def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0, expect_fused=None):
     from multiyolov5_amd import _lib as L, engine as E
     lib = L.lib()
     cout = cout or C_
@@ -78,6 +86,8 @@ def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0,
     sites = L.launch_trace()
     lib.myolo_trace_start(0)
     fused = any('cpair' in s for s in sites)
+    if expect_fused is None:
+        expect_fused = _gate(C_, B, H, W, th, cout)
     assert fused == expect_fused, (sorted(sites), expect_fused)
     a2, b2 = descs(yb2, tb2)
     L.check(lib.myolo_conv(C.byref(a2), L.stream_ptr()))
@@ -106,8 +116,9 @@ CASES = [
     (128, 1, 64, 128, 8),
     (128, 3, 19, 70, 8),
     (128, 3, 19, 70, 4),
-    (256, 1, 32, 64, 0),         # 9.m.0: two mid passes, two N tiles
-    (256, 2, 13, 21, 0),
+    (256, 1, 32, 64, 4),         # 9.m.0's shape: two mid passes, two N tiles (forced: the auto gate leaves 256 channels to the two-launch form)
+    (256, 2, 13, 21, 4),
+    (256, 1, 32, 64, 0),         # ... and the auto gate's answer for it (two launches)
     (64, 16, 64, 128, 8),        # batch 16: persistent workgroups walk several tiles
 ]
 
@@ -122,7 +133,7 @@ def test_conv_pair_on_channel_slices_and_narrower_outputs():
     _run(128, 2, 24, 40, 8, sliced=True)
     _run(64, 2, 24, 40, 4, sliced=True)
     _run(128, 1, 32, 48, 0, res=False, cout=64)        # 64 output channels from 128 mid channels: a 64-wide N tile
-    _run(256, 1, 16, 32, 0, res=False, cout=128)
+    _run(256, 1, 16, 32, 4, res=False, cout=128)
 
 
 def test_pairs_that_do_not_qualify_run_as_two_launches():
