@@ -871,28 +871,19 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
       for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int i = 0; i < SEG; ++i) acc[p][j][i] = 0.f;
-    // four pixels' loads in flight per thread (round 5: one dependent 16-byte load per iteration made this pass latency-bound -- 44.8 us for
-    // the 33.5 MB map of the training step, 29 us for the 8 MB map of a detect.py frame); lanes past the range read the zero page
-    const T* rowp = vptr<T>(x, n, y, 0) + cg * SEG;
-    for (int x0 = xa; x0 < xb; x0 += 4) {
-      uint4 v[4];
+    // (round 5: four pixels' loads in flight per thread instead of one dependent 16-byte load per iteration measured NEUTRAL -- 89.7 vs 90.4 us
+    //  for the two launches of a training step, profiles/r5_kernel_stats.csv: the pass is not waiting on its loads -- and was taken out again)
+    for (int xx = xa; xx < xb; ++xx) {
+      float f[SEG];
+      Vec<T>::unpack(ldg16(vptr<T>(x, n, y, xx) + cg * SEG), f);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        v[u] = ldg16(x0 + u < xb ? reinterpret_cast<const char*>(rowp + (int64_t)(x0 + u) * x.sw) : zero_page());
+      for (int p = 0; p < AAP_MAXP; ++p)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int xx = x0 + u;
-        float f[SEG];
-        Vec<T>::unpack(v[u], f);
+        for (int j = 0; j < 3; ++j) {
+          const float m = (xx >= lo[p][j] && xx < hi[p][j]) ? 1.f : 0.f;
 #pragma unroll
-        for (int p = 0; p < AAP_MAXP; ++p)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float m = (xx < xb && xx >= lo[p][j] && xx < hi[p][j]) ? 1.f : 0.f;
-#pragma unroll
-            for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
-          }
-      }
+          for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
+        }
     }
 #pragma unroll
     for (int p = 0; p < AAP_MAXP; ++p) {
