@@ -195,6 +195,48 @@ def wgrad_ref(wd):
     return out, dyf.double().sum(0).float()
 
 
+def _fv(a):
+    return a.value if hasattr(a, 'value') else a
+
+
+def _split_vec(p1, p2, C, cs):
+    """per-channel parameter vector of a (possibly split, myolo_bn_split) BatchNorm launch: set 1 serves channels [0, cs), set 2 the rest"""
+    if not _ptr(p1):
+        return None
+    v = read_f32(p1, cs)
+    if cs < C:
+        v = torch.cat([v, read_f32(p2, C - cs)])
+    return v
+
+
+class _BnArgs:
+    """the common head of the three BatchNorm entry points (include/myolo.h:192-240) out of a Call's argument tuple"""
+
+    def __init__(self, y, split):
+        self.C = y.c
+        self.M = y.n * y.h * y.w
+        self.sp = split
+        self.cs = split.c_split if split is not None else y.c
+        self.scale = max(1, split.count_scale) if split is not None else 1
+
+
+def bn_fwd_ref(y, stats, gamma, beta, eps, act, res):
+    """out = act((y - mean) * invstd * gamma + beta) + res with batch statistics from the conv epilogue's sums (common.py:42-43, train mode)"""
+    C = y.shape[-1]
+    M = y.shape[0] * y.shape[1] * y.shape[2]
+    if stats is None:
+        out = act_fn(y, act)
+        return out + (res if res is not None else 0), None, None
+    mean = (stats[0] / M)
+    var = (stats[1] / M - mean * mean).clamp_min(0)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    z = (y.double() - mean) * invstd * gamma.double() + beta.double()
+    out = act_fn(z.float(), act)
+    return out + (res if res is not None else 0), mean, var
+
+
+BN_NAMES = ('myolo_bn_act_fwd', 'myolo_bn_act_fwd_split', 'myolo_bn_act_bwd_reduce', 'myolo_bn_act_bwd_reduce_split', 'myolo_bn_act_bwd_apply',
+            'myolo_bn_act_bwd_apply_split')
 CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair')
 
 
@@ -202,8 +244,9 @@ class LaunchChecker:
     """with LaunchChecker(check_fn) as lc: run a forward (+ backward) with engine.NATIVE_EXEC off.  lc.n[name] counts the checked launches,
     lc.bad collects failures (check_fn = tests.gpu_util.check with collect=)."""
 
-    def __init__(self, check, tag, tol_out=3e-3, tol_stat=2e-3, tol_w=2e-3, every=1):
+    def __init__(self, check, tag, tol_out=3e-3, tol_stat=2e-3, tol_w=2e-3, every=1, bn=False):
         self.check, self.tag, self.tol_out, self.tol_stat, self.tol_w = check, tag, tol_out, tol_stat, tol_w
+        self.bn = bn                           # also every BatchNorm forward / backward-reduce / backward-apply launch
         self.bad, self.n, self.k, self.every = [], {}, 0, every
 
     def __enter__(self):
@@ -213,7 +256,7 @@ class LaunchChecker:
         me = self
 
         def wrapped(call, st):
-            if call.name not in CONV_NAMES:
+            if call.name not in CONV_NAMES and not (me.bn and call.name in BN_NAMES):
                 return me.orig(call, st)
             me.k += 1
             if me.k % me.every:
@@ -269,6 +312,8 @@ class LaunchChecker:
         torch.cuda.synchronize()
         name = call.name
         self.n[name] = self.n.get(name, 0) + 1
+        if name in BN_NAMES:
+            return self._run_bn(call, st, name)
         if name == 'myolo_conv':
             d = self._desc(call.args[0])
             pre = self._conv_pre(d)
@@ -330,3 +375,90 @@ class LaunchChecker:
             self._ck(what + '/dw', read_f32(wd.dw, n) - w0, ref_w.reshape(-1), self.tol_w)
             if b0 is not None:
                 self._ck(what + '/db', read_f32(wd.db, cout) - b0, ref_b, self.tol_w)
+
+    # ---- BatchNorm family (include/myolo.h:192-240): forward, backward reduce, backward apply; plain and split (two parameter sets) ----
+    def _run_bn(self, call, st, name):
+        a = call.args
+        split = None
+        if name.endswith('_split'):
+            split = self._desc(a[-1])
+            name = name[:-6]
+        if name == 'myolo_bn_act_fwd':
+            yd, res_d, out_d = self._desc(a[0]), self._desc(a[11]), self._desc(a[12])
+            B = _BnArgs(yd, split)
+            C, M = B.C, B.M * B.scale
+            has_bn = bool(_ptr(a[1]))
+            y = read_tensor(yd)
+            res = read_tensor(res_d, channels=C) if res_d.ptr else None
+            eps, mom, act = float(_fv(a[8])), float(_fv(a[9])), int(_fv(a[10]))
+            if has_bn:
+                stats = stat_sums(a[1], C)
+                gamma = _split_vec(a[2], split.gamma2 if split else None, C, B.cs)
+                beta = _split_vec(a[3], split.beta2 if split else None, C, B.cs)
+                rm0 = _split_vec(a[4], split.running_mean2 if split else None, C, B.cs)
+                rv0 = _split_vec(a[5], split.running_var2 if split else None, C, B.cs)
+                mean = stats[0] / M
+                var = (stats[1] / M - mean * mean).clamp_min(0)
+                invstd = 1.0 / torch.sqrt(var + eps)
+                out_ref = act_fn(((y.double() - mean) * invstd * gamma.double() + beta.double()).float(), act)
+            else:
+                out_ref = act_fn(y, act)
+            if res is not None:
+                out_ref = out_ref + res
+            self.orig(call, st)
+            torch.cuda.synchronize()
+            what = f'bn_fwd[{yd.n}x{yd.h}x{yd.w}x{C}' + ('+res' if res is not None else '') + ('+split' if split is not None and B.cs < C else '') + f']#{self.k}'
+            self._ck(what + '/out', read_tensor(out_d), out_ref, self.tol_out)
+            if has_bn:
+                sv = read_f32(a[7], 2 * C)
+                self._ck(what + '/saved_mean', sv[:C], mean.float(), 1e-4)
+                self._ck(what + '/saved_invstd', sv[C:], invstd.float(), 1e-4)
+                if rm0 is not None:
+                    rm1 = _split_vec(a[4], split.running_mean2 if split else None, C, B.cs)
+                    rv1 = _split_vec(a[5], split.running_var2 if split else None, C, B.cs)
+                    self._ck(what + '/running_mean', rm1, ((1 - mom) * rm0.double() + mom * mean).float(), 1e-4)
+                    self._ck(what + '/running_var', rv1, ((1 - mom) * rv0.double() + mom * var * M / max(M - 1, 1)).float(), 1e-4)
+            return
+        god, yd = self._desc(a[0]), self._desc(a[1])
+        B = _BnArgs(yd, split)
+        C, M = B.C, B.M * B.scale
+        act = int(_fv(a[5]))
+        gout, y = read_tensor(god, channels=C), read_tensor(yd)
+        has_bn = bool(_ptr(a[2]))
+        if has_bn:
+            sv = read_f32(a[2], 2 * C)
+            mean, invstd = sv[:C], sv[C:]
+            gamma = _split_vec(a[3], split.gamma2 if split else None, C, B.cs)
+            beta = _split_vec(a[4], split.beta2 if split else None, C, B.cs)
+            xhat = (y - mean) * invstd
+            dz = gout * act_grad(xhat * gamma + beta, act)
+        else:
+            dz = gout * act_grad(y, act)
+        if name == 'myolo_bn_act_bwd_reduce':
+            d0 = stat_sums(a[6], C)
+            self.orig(call, st)
+            torch.cuda.synchronize()
+            ref = torch.stack([dz.double().sum((0, 1, 2)), (dz * xhat).double().sum((0, 1, 2))])
+            self._ck(f'bn_bwd_reduce[{yd.n}x{yd.h}x{yd.w}x{C}]#{self.k}/dsum', (stat_sums(a[6], C) - d0).float(), ref.float(), self.tol_stat)
+            return
+        # apply: dy = gamma * invstd * (dz - dsum0 / M - xhat * dsum1 / M); dgamma += dsum1, dbeta += dsum0 (/ count_scale); gres (+)= gout
+        dyd, grd, racc = self._desc(a[9]), self._desc(a[10]), int(_fv(a[11]))
+        if has_bn:
+            ds = stat_sums(a[6], C)
+            dy_ref = (gamma * invstd) * (dz - (ds[0] / M).float() - xhat * (ds[1] / M).float())
+            g0 = (_split_vec(a[7], split.dgamma2 if split else None, C, B.cs), _split_vec(a[8], split.dbeta2 if split else None, C, B.cs))
+        else:
+            dy_ref, g0 = dz, (None, None)
+        gres0 = read_tensor(grd, channels=C) if (grd.ptr and racc) else None
+        self.orig(call, st)
+        torch.cuda.synchronize()
+        what = f'bn_bwd_apply[{yd.n}x{yd.h}x{yd.w}x{C}' + ('+gres' if grd.ptr else '') + ('+split' if split is not None and B.cs < C else '') + f']#{self.k}'
+        self._ck(what + '/dy', read_tensor(dyd), dy_ref, self.tol_out)
+        if grd.ptr:
+            self._ck(what + '/gres', read_tensor(grd, channels=C), gout + (gres0 if gres0 is not None else 0), self.tol_out)
+        if g0[0] is not None:
+            g1 = _split_vec(a[7], split.dgamma2 if split else None, C, B.cs)
+            self._ck(what + '/dgamma', g1 - g0[0], (ds[1] / B.scale).float(), self.tol_stat)
+        if g0[1] is not None:
+            b1 = _split_vec(a[8], split.dbeta2 if split else None, C, B.cs)
+            self._ck(what + '/dbeta', b1 - g0[1], (ds[0] / B.scale).float(), self.tol_stat)

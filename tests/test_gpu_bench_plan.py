@@ -4,7 +4,7 @@ batch-2 C-ABI / layer tests force).
 
 * `bench.Trainer` itself builds BASELINE configs[1] (yolov5s + PSP, 16x3x512x1024, fp16, loss scale 65536) and runs one joint training
   step with the launch lists issued call by call; `tests.desc_ref.LaunchChecker` evaluates every `myolo_conv` / `myolo_conv_dgrad_s2` /
-  `myolo_conv_dgrad_bn` / `myolo_conv_wgrad` descriptor of that step in torch fp32 on the CPU over the operands the launch actually read
+  `myolo_conv_dgrad_bn` / `myolo_conv_wgrad` descriptor -- and every `myolo_bn_act_*` launch -- of that step in torch fp32 on the CPU over the operands the launch actually read
   and compares everything the launch stored -- outputs (accumulated ones against previous + result), BatchNorm statistics, folded
   BatchNorm-backward sums, the dy / dgamma / dbeta of the apply fold, weight and bias gradients.  Tolerances: 3e-3 relative L2 on
   fp16-rounded outputs (half-ulp rounding alone is ~3e-4), 2e-3 on fp32 sums and weight gradients.
@@ -47,7 +47,7 @@ def _dump_trace(tag):
     return tr
 
 
-def _train_step_checked(args, tag, expect):
+def _train_step_checked(args, tag, expect, bn=False):
     import bench
     from multiyolov5_amd import _lib as L
     from tests.desc_ref import LaunchChecker
@@ -55,7 +55,7 @@ def _train_step_checked(args, tag, expect):
     tr.step()                                   # builds the plan (native executor, as the bench runs it), moves the BatchNorm statistics once
     torch.cuda.synchronize()
     L.lib().myolo_trace_start(1)
-    with LaunchChecker(check, tag) as lc:
+    with LaunchChecker(check, tag, bn=bn) as lc:
         tr.step()
         torch.cuda.synchronize()
     sites = _dump_trace(tag)
@@ -69,7 +69,10 @@ def _train_step_checked(args, tag, expect):
 def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32():
     """BASELINE configs[1]: 79 convolutions -> 70 forward launches (9 merged pairs), their dgrads (stride-2 ones as one fused launch, 1x1
     Conv+BatchNorm+SiLU ones with the apply fold) and 79 weight-gradient launches"""
-    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 6, 'myolo_conv_dgrad_bn': 10})
+    # ... and every BatchNorm launch of that step (forward with its saved / running statistics, backward reduce, backward apply with dgamma /
+    # dbeta and the shortcut's gradient pass-through; plain and split): the other 7.6 GB of the step's traffic
+    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 6, 'myolo_conv_dgrad_bn': 10,
+                                                        'myolo_bn_act_fwd': 40, 'myolo_bn_act_bwd_reduce': 20, 'myolo_bn_act_bwd_apply': 20}, bn=True)
     fam = ' '.join(sites)
     for k in ('mid::launch', 'midx::launch', 'halo::launch', 'stream::launch', 'launch_conv4', 'wgt::launch'):     # every conv family DESIGN section 3 names
         assert k in fam, (k, sorted(sites))
