@@ -1337,7 +1337,11 @@ extern "C" int myolo_adaptive_avgpool_fwd_multi(const myolo_tensor* x, const myo
   if ((x->w + PL - 1) / PL + 2 > x->w / kmax || x->w < PL) return MYOLO_EINVAL;
   const int smem = mp.nbins * x->c * 4;
   if (smem > 60 * 1024) return MYOLO_EINVAL;
-  int rows = (int)(((int64_t)x->h * x->n + 255) / 256);        // ~256 workgroups
+  // ~256 workgroups: the measured optimum (round 5, kernel time inside the step / a 2048x1024 frame, profiles/r5k_aap_wgs.txt, r5l_aap_xsplit.txt):
+  // 64 / 128 / 256 / 512 workgroups 144 / 78 / 44.7 / 45.2 us for the training map (fewer workgroups: the per-row work serialises; more: the
+  // zeroing and flushing of the bin tables, nbins * C words and as many atomics per workgroup, grows with the count); splitting the ROW over
+  // workgroups as well 57.7 us at 1024, 98.6 at 2048; one bin table per wave 46.2 -> 48.0 us; four loads in flight per thread neutral
+  int rows = (int)(((int64_t)x->h * x->n + 255) / 256);
   if (rows < 1) rows = 1;
   const int gx = (x->h + rows - 1) / rows;
   hipStream_t st = (hipStream_t)stream;
