@@ -35,11 +35,24 @@ def hip():
     return _hip
 
 
+_pinned = [None]
+
+
 def dev_read(ptr, nbytes):
-    out = torch.empty(int(nbytes), dtype=torch.uint8)
+    """device bytes -> host uint8 tensor (through one reusable pinned staging buffer: pageable hipMemcpy was most of the checker's time)"""
+    nbytes = int(nbytes)
+    out = torch.empty(nbytes, dtype=torch.uint8)
     if nbytes:
-        e = hip().hipMemcpy(out.data_ptr(), C.c_void_p(int(ptr)), int(nbytes), 2)     # hipMemcpyDeviceToHost
+        try:
+            if _pinned[0] is None or _pinned[0].numel() < nbytes:
+                _pinned[0] = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8).pin_memory()
+            stage = _pinned[0]
+        except RuntimeError:                                 # (no pinned memory available: straight into the pageable tensor)
+            stage = out
+        e = hip().hipMemcpy(stage.data_ptr(), C.c_void_p(int(ptr)), nbytes, 2)     # hipMemcpyDeviceToHost
         assert e == 0, f'hipMemcpy D2H failed: {e}'
+        if stage is not out:
+            out.copy_(stage[:nbytes])
     return out
 
 
@@ -246,7 +259,8 @@ class LaunchChecker:
 
     def __init__(self, check, tag, tol_out=3e-3, tol_stat=2e-3, tol_w=2e-3, every=1, bn=False):
         self.check, self.tag, self.tol_out, self.tol_stat, self.tol_w = check, tag, tol_out, tol_stat, tol_w
-        self.bn = bn                           # also every BatchNorm forward / backward-reduce / backward-apply launch
+        self.bn = bn                           # also the BatchNorm forward / backward-reduce / backward-apply launches: every bn-th of them (True = 1)
+        self.kbn = 0
         self.bad, self.n, self.k, self.every = [], {}, 0, every
 
     def __enter__(self):
@@ -258,6 +272,12 @@ class LaunchChecker:
         def wrapped(call, st):
             if call.name not in CONV_NAMES and not (me.bn and call.name in BN_NAMES):
                 return me.orig(call, st)
+            if call.name in BN_NAMES:
+                me.kbn += 1
+                if me.kbn % int(me.bn):
+                    return me.orig(call, st)
+                me.k += 1
+                return me.run(call, st)
             me.k += 1
             if me.k % me.every:
                 return me.orig(call, st)
