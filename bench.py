@@ -301,11 +301,24 @@ def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
     from multiyolov5_amd import synth
     m = Model(os.path.join(ROOT, 'multiyolov5_amd', 'cfg', 'yolov5s_city_seg.yaml'))
     synth.randomize_(m, seed=0)
-    m = m.to(dev).half().fuse().eval()
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):               # (fuse() prints 'Fusing layers...' like the reference: keep stdout to the JSON line)
+        m = m.to(dev).half().fuse().eval()
     img = synth.images(1, H, W, seed=7).to(dev, torch.float16)
     na = 3 * ((H // 8) * (W // 8) + (H // 16) * (W // 16) + (H // 32) * (W // 32))          # 129 024 at 1024x2048, 32 256 at 512x1024
     pred_syn = synth.nms_pred(1, na, 10, seed=3, img_w=W, img_h=H).to(dev, torch.float16)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+
+    def frame_unchanged():
+        """the statements of detect.py:144-149,191-193 as the reference writes them, under the drop-in: `F.interpolate(seg, ...)[0]` +
+        `.max(axis=0)[1]` on the model's lazy logits reach the same fused kernel (runtime.LazyResized)"""
+        import torch.nn.functional as F
+        with torch.no_grad():
+            out = m(img)
+            det = non_max_suppression(pred_syn, 0.25, 0.45)
+            seg = F.interpolate(out[1], (H, W), mode='bilinear', align_corners=True)[0]
+            lab = seg.max(axis=0)[1]
+        return det, lab
 
     def frame(timed=False):
         with torch.no_grad():
@@ -331,6 +344,15 @@ def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
         frame()
     torch.cuda.synchronize()
     fps = frames / (time.perf_counter() - t0)
+    for _ in range(4):
+        _, lab_u = frame_unchanged()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        frame_unchanged()
+    torch.cuda.synchronize()
+    fps_unchanged = frames / (time.perf_counter() - t0)
+    same_labels = bool(torch.equal(lab_u, frame()[1][0]))
     st = [0.0, 0.0, 0.0]
     k = 10
     for _ in range(k):
@@ -363,6 +385,10 @@ def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
     r = {'value': fps, 'unit': 'frames/s',
          'workload': f'pspv5s fused fp16 1x3x{H}x{W} fwd + NMS({na} rows, {int(det[0].shape[0])} kept) + x8 upsample+argmax (int64 labels)',
          'ms_per_frame': 1e3 / fps,
+         'unchanged_caller': {'value': fps_unchanged, 'unit': 'frames/s', 'same_labels_as_seg_argmax': same_labels,
+                              'what': "the same frame loop with detect.py:191-193's own statements -- F.interpolate(seg, (h0, w0), "
+                                      "mode='bilinear', align_corners=True)[0]; seg.max(axis=0)[1] -- instead of utils.general.seg_argmax: "
+                                      'the lazy logits turn them into the fused resize + arg-max launch (runtime.LazyResized)'},
          'stage_ms': {'forward': st[0], 'nms': st[1], 'argmax': st[2], 'forward_main_chain': fwd_main, 'head_unjoined': unjoined,
                       'what': 'HIP events on the launch stream, 10 frames; nms includes its device->host read of the keep counts; with '
                               'head_unjoined the segmentation head (side stream) overlaps NMS, so the stages add up to more than the frame: '

@@ -223,6 +223,18 @@ typedef struct myolo_bn_split {
   float* dgamma2;
   float* dbeta2;
 } myolo_bn_split;
+/* Round 6: bn_act_bwd_reduce + bn_act_bwd_apply in ONE launch for tensors the resident grid holds in registers (gout and y are read
+ * once; partial sums -> device-wide barrier inside the launch -> dx from the same registers).  Same arguments and results as the two
+ * entry points it replaces (reference: autograd of nn.BatchNorm2d + nn.SiLU, models/common.py:42-43); `dsum` zeroed by the caller;
+ * `barrier`: MYOLO_GRID_BARRIER_BYTES of device memory, 128-byte aligned, zeroed ONCE (the barrier resets itself; launches that may be
+ * in flight at the same time need separate blocks; word 18*32 is a sticky timeout flag: a spin that gave up).  Tensors that do not fit
+ * the resident grid (myolo_bn_act_bwd_fused_ok == 0), strided views and MYOLO_BN_BWD_FUSED=0 run the two launches. */
+#define MYOLO_GRID_BARRIER_BYTES (19 * 32 * 4)
+int myolo_bn_act_bwd_fused_ok(int dtype, int64_t n_pixels, int c);
+int myolo_bn_act_bwd_fused(const myolo_tensor* gout, const myolo_tensor* y, const float* saved, const float* gamma,
+                           const float* beta, int act, float* dsum, float* dgamma, float* dbeta, const myolo_tensor* dy,
+                           const myolo_tensor* gres, int gres_accumulate, const myolo_bn_split* split, uint32_t* barrier,
+                           void* stream);
 int myolo_bn_act_fwd_split(const myolo_tensor* y, const float* stats, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, int64_t* num_batches_tracked,
                            float* saved, float eps, float momentum, int act,

@@ -133,6 +133,8 @@ _PROTOS = {
     'myolo_bn_act_fwd_split': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, C.POINTER(BnSplit), P]),
     'myolo_bn_act_bwd_reduce_split': (C.c_int, [TP, TP, P, P, P, C.c_int, P, C.POINTER(BnSplit), P]),
     'myolo_bn_act_bwd_apply_split': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P, P, TP, TP, C.c_int, C.POINTER(BnSplit), P]),
+    'myolo_bn_act_bwd_fused_ok': (C.c_int, [C.c_int, C.c_int64, C.c_int]),
+    'myolo_bn_act_bwd_fused': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P, P, TP, TP, C.c_int, C.POINTER(BnSplit), P, P]),
     'myolo_spp_pool_fwd': (C.c_int, [TP, TP, TP, TP, P, P]),
     'myolo_spp_pool_bwd': (C.c_int, [TP, TP, TP, P, TP, C.c_int, P]),
     'myolo_copy_up_fwd': (C.c_int, [TP, TP, C.c_int, P]),

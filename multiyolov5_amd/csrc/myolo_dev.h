@@ -216,6 +216,61 @@ __device__ __forceinline__ u32x4_t buf_load_h8(__amdgpu_buffer_rsrc_t rs, int of
   return g;
 }
 
+// ---- device-wide barrier inside a launch (round 6; MI355X_MICROARCH.md row "barrier-xcd", measured here: profiles/r6_grid_barrier_ubench.txt:
+// 4.7 / 6.5 / 10.5 us at 256 / 512 / 1024 workgroups without a release fence, 6.2 / 9.8 / 17.5 with one per workgroup) ----
+// State: MYOLO_GRID_BARRIER_WORDS uint32 zeroed ONCE by the caller (include/myolo.h); every word sits on its own 128-byte line:
+//   [g]*32, g = 0..7: arrival counter of group g = linear block id & 7 (the XCD the block is observed to run on -- a LOGICAL group, nothing
+//   depends on the placement), [8+g]*32: generation word of group g, [16]*32: group-leader counter, [17]*32: top generation,
+//   [18]*32: sticky timeout flag.  The last arriver zeroes the counter before it publishes the generation, so launches on ONE stream
+//   may share a state block without a memset; two launches in flight at once need two blocks.
+// Visibility contract: what crosses the barrier must be written with agent-scope atomics (RETURNING ones whose result the writer has
+// consumed: the RMW has been performed before the arrival) or sc1 stores, and read behind the barrier with __hip_atomic_load(agent)
+// (sc1 loads): then no release / acquire fence is needed (cdna_hip_programming.md Guideline 16, form R1).  Residency: EVERY workgroup
+// of the grid must be co-resident (callers size the grid for one or two workgroups per CU); every spin is bounded, a timeout sets the flag
+// and lets the kernel finish with garbage instead of hanging the device.
+#define MYOLO_GRID_BARRIER_WORDS (19 * 32)
+typedef __attribute__((address_space(1))) unsigned int gbar_u32;
+__device__ __forceinline__ bool gbar_spin(gbar_u32* p, unsigned old, gbar_u32* tmo) {
+  for (unsigned spins = 0; spins < (1u << 19); ++spins) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != old) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+__device__ __forceinline__ void grid_barrier_xcd(unsigned int* state, int bid, int nblocks) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its atomics / sc1 stores have been performed
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    gbar_u32* w = (gbar_u32*)state;
+    const int g = bid & 7;
+    const int ng = (nblocks - g + 7) >> 3;                 // blocks with id & 7 == g
+    const int ngroups = nblocks < 8 ? nblocks : 8;
+    const unsigned gen0 = __hip_atomic_load(w + (8 + g) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(w + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == (unsigned)ng - 1) {                         // group leader = last arriver of the group
+      __hip_atomic_store(w + g * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned tgen0 = __hip_atomic_load(w + 17 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned t = __hip_atomic_fetch_add(w + 16 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (t == (unsigned)ngroups - 1) {
+        __hip_atomic_store(w + 16 * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(w + 17 * 32, tgen0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        gbar_spin(w + 17 * 32, tgen0, w + 18 * 32);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(w + (8 + g) * 32, gen0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      gbar_spin(w + (8 + g) * 32, gen0, w + 18 * 32);
+    }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ float ld_agent_f32(const float* p) {
+  return __hip_atomic_load((const __attribute__((address_space(1))) float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // ---- BatchNorm-backward statistics in a dgrad epilogue (myolo_conv_desc.bnb) ----
 struct BnbSeg {              // device-side copy of one myolo_bn_bwd_seg
   int c0, c1;
@@ -239,6 +294,8 @@ static inline void bnb_fill(BnbArgs* a, const myolo_conv_desc* d) {
 // bn_act.hip: the reduce pass over the STORED gout for every segment of d (fallback when the conv kernel cannot fold it)
 int myolo_bnb_fallback(const myolo_conv_desc* d, const myolo_tensor* gout_full, void* stream);
 
+// bn_act.hip: "bn_fused" (0 off / 1 on), "bn_fused_cap" (largest resident grid of the one-launch BatchNorm backward)
+int myolo_bn_set(const char* name, int value);
 // conv_stream.hip: streaming variant of myolo_conv; -1 = layer does not qualify
 int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 // conv_halo.hip: LDS-staged input tiles for k x k stride-1 convolutions; -1 = layer does not qualify

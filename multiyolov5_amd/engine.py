@@ -37,6 +37,10 @@ BN_APPLY_FOLD = os.environ.get('MYOLO_BN_APPLY_FOLD', '1') != '0'
 # module in ONE forward and ONE backward launch (csrc/tiny_conv.hip) instead of 2 + 3 launches per layer
 CONV_PAIR = os.environ.get('MYOLO_CONV_PAIR', '1') != '0'       # eval: Bottleneck's 1x1 -> 3x3 in one launch (csrc/conv_pair.hip)
 TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '1') != '0'
+# round 6: BatchNorm backward (reduce + apply) of a tensor the resident grid holds in registers as ONE launch with a device-wide barrier
+# inside (csrc/bn_act.hip bn_act_bwd_fused_kernel).  1: layers that run the two passes as launches of their own; 2: also instead of the
+# apply fold of a 1x1 dgrad (myolo_conv_dgrad_bn) where that layer's reduce pass is a launch of its own; 0: off
+BN_BWD_FUSED = int(os.environ.get('MYOLO_BN_BWD_FUSED', '2'))
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -534,6 +538,21 @@ class ConvOp(Op):
                 if self.bn2 is not None:
                     sp = self.split
                     sp.dgamma2, sp.dbeta2 = plan.pgrad(self.bn2.weight).data_ptr(), plan.pgrad(self.bn2.bias).data_ptr()
+                fold_ok = (BN_APPLY_FOLD and dt == torch.float16 and self.k == 1 and self.s == 1 and self.bn2 is None and self.sync_world == 1 and
+                           not grd.ptr and self.x.requires_grad and self.cout % 64 == 0 and self.cout <= 512 and self.out.c == self.cout)
+                # one launch for both passes (round 6): the layer's sums are not produced by a dgrad epilogue, no collective sits between the
+                # passes, every operand is a dense channel slice and the library says the tensor fits the resident grid
+                own_reduce = self.bn2 is not None or self.reduce_by is None
+                dense = all(t.sh == t.w * t.sw and t.sn == t.h * t.sh for t in (self.god, self.yd, self.dyd) + ((grd,) if grd.ptr else ()))
+                self.bwd_fused = bool(BN_BWD_FUSED and own_reduce and self.sync_world == 1 and dense and (BN_BWD_FUSED >= 2 or not fold_ok) and
+                                      L.lib().myolo_bn_act_bwd_fused_ok(L.DT[dt], self.out.n * self.out.h * self.out.w, self.cout))
+                if self.bwd_fused:
+                    bar = plan.grid_barrier()
+                    calls.append(Call('myolo_bn_act_bwd_fused', (
+                        C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum),
+                        L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), C.byref(self.dyd), C.byref(grd), self.res_acc,
+                        C.byref(self.split) if self.bn2 is not None else None, L.ptr(bar))))
+                elif self.bn2 is not None:
                     calls.append(Call('myolo_bn_act_bwd_reduce_split', (C.byref(self.god), C.byref(self.yd), L.ptr(self.saved),
                                                                         L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum),
                                                                         C.byref(sp))))
@@ -542,8 +561,9 @@ class ConvOp(Op):
                                                                   L.ptr(bn.weight), L.ptr(bn.bias), self.act, L.ptr(self.dsum))))
                 calls += sync                    # SyncBatchNorm: the sums of all ranks, before the apply pass reads them
                 self.apply_fold = None
-                if (BN_APPLY_FOLD and dt == torch.float16 and self.k == 1 and self.s == 1 and self.bn2 is None and self.sync_world == 1 and
-                        not grd.ptr and self.x.requires_grad and self.cout % 64 == 0 and self.cout <= 512 and self.out.c == self.cout):
+                if self.bwd_fused:
+                    pass
+                elif fold_ok:
                     f = L.BnApplyFold()
                     f.y, f.dy = self.yd, self.dyd
                     f.saved, f.gamma, f.beta, f.dsum = self.saved.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), self.dsum.data_ptr()
@@ -1277,6 +1297,13 @@ class Plan:
     def f32_bwd_zero(self, n):
         """fp32 scratch zeroed at the start of every backward (BN backward sums, gate partials)."""
         return self._carve(1, n)
+
+    def grid_barrier(self):
+        """state of the in-launch device-wide barrier (include/myolo.h MYOLO_GRID_BARRIER_BYTES; zeroed once, self-resetting; shared by the
+        launches of the plan's MAIN stream: they are stream-ordered)"""
+        if not hasattr(self, '_grid_bar'):
+            self._grid_bar = torch.zeros(19 * 32, dtype=torch.int32, device=self.device)
+        return self._grid_bar
 
     def wgrad_workspace(self):
         """split-K partial tiles of myolo_conv_wgrad (shared by all convs of the plan: launches are stream-ordered)."""
@@ -2097,6 +2124,9 @@ def call_algorithmic_bytes(call):
     if n in ('myolo_bn_act_bwd_apply', 'myolo_bn_act_bwd_apply_split'):
         g, gres = a[0], a[10]
         return _tensor_bytes(g) * 3 + (_tensor_bytes(gres) if gres.ptr else 0)
+    if n == 'myolo_bn_act_bwd_fused':       # (the operand count of the two launches it replaces: the family totals stay comparable across builds)
+        g, gres = a[0], a[10]
+        return _tensor_bytes(g) * 5 + (_tensor_bytes(gres) if gres.ptr else 0)
     return None
 
 
@@ -2105,7 +2135,7 @@ def plan_algorithmic_bytes(plan):
     out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
     fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_dgrad_bn': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
            'myolo_bn_act_bwd_apply': 'batchnorm', 'myolo_bn_act_fwd_split': 'batchnorm', 'myolo_bn_act_bwd_reduce_split': 'batchnorm',
-           'myolo_bn_act_bwd_apply_split': 'batchnorm'}
+           'myolo_bn_act_bwd_apply_split': 'batchnorm', 'myolo_bn_act_bwd_fused': 'batchnorm'}
     for op in plan.ops:
         for c in list(op.fwd_calls) + list(op.bwd_calls):
             b = call_algorithmic_bytes(c)

@@ -111,12 +111,140 @@ class LazySegLogits(torch.Tensor):
         if cls._META is None:
             cls._META = cls._meta_funcs()
         if func not in cls._META:
+            if func is torch.nn.functional.interpolate and LAZY_RESIZE:
+                r = LazyResized.from_interpolate(args, kwargs or {})
+                if r is not None:
+                    return r                              # detect.py:191 / test.py:38: nothing launched until the result is used
             for a in tuple(args) + tuple((kwargs or {}).values()):
                 for t in (a if isinstance(a, (list, tuple)) else (a,)):
                     if isinstance(t, LazySegLogits):
                         materialize(t)
         with torch._C.DisableTorchFunctionSubclass():
             return func(*args, **(kwargs or {}))
+
+
+LAZY_RESIZE = True          # tests flip it to compare against the ATen route
+
+
+class _LazyTensor(torch.Tensor):
+    """A tensor with the reference's metadata and NO storage whose values come from `_thunk()` on first real use.  Every torch function
+    or method other than pure metadata either matches a pattern of the subclass (`_pattern`) or runs on the forced tensor; nothing ever
+    reaches the dispatcher with the wrapper itself (that raises)."""
+
+    @staticmethod
+    def __new__(cls, shape, dtype, device):
+        return torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device)
+
+    def _force(self):
+        v = self.__dict__.get('_forced')
+        if v is None:
+            v = self.__dict__['_forced'] = self.__dict__['_thunk']()
+        return v
+
+    def _pattern(self, func, args, kwargs):
+        return NotImplemented
+
+    @classmethod
+    def _swap(cls, a):
+        if isinstance(a, _LazyTensor):
+            return a._force()
+        if isinstance(a, (list, tuple)):
+            return type(a)(cls._swap(v) for v in a)
+        return a
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if LazySegLogits._META is None:
+            LazySegLogits._META = LazySegLogits._meta_funcs()
+        if func in LazySegLogits._META:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        if args and isinstance(args[0], _LazyTensor):
+            r = args[0]._pattern(func, args, kwargs)
+            if r is not NotImplemented:
+                return r
+        args = tuple(cls._swap(a) for a in args)
+        kwargs = {k: cls._swap(v) for k, v in kwargs.items()}
+        return func(*args, **kwargs)                       # (a forced LazySegLogits among them keeps its own protocol)
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        raise L.MyoloError(f'lazy tensor reached the dispatcher through {func}: it must be forced in __torch_function__')
+
+
+class LazyResized(_LazyTensor):
+    """`F.interpolate(seg, (h0, w0), mode='bilinear', align_corners=True)` of the model's segmentation output (detect.py:191, test.py:38)
+    as a deferred view.  What the reference's callers do with it is `[0]`, `.data`, and a maximum over the class axis of which they keep
+    the INDICES (`seg.max(axis=0)[1]`, detect.py:193; `torch.max(output, 1)`, utils/metrics.py:240,259): those run the fused resize +
+    arg-max kernel (`myolo_seg_argmax`, csrc/seg_out.hip) on the head's logits and never form the h0 x w0 x 19 tensor; the label map is
+    cached, so the two `torch.max` of test.py's metrics launch once.  The maximum VALUES are themselves deferred (nobody reads them);
+    any other use computes the real interpolation (ATen) on the materialised logits, as before round 6."""
+
+    @staticmethod
+    def from_interpolate(args, kw):
+        x = args[0] if args else kw.get('input')
+        size = args[1] if len(args) > 1 else kw.get('size')
+        if not isinstance(x, LazySegLogits) or x.dim() != 4 or size is None or kw.get('scale_factor') is not None:
+            return None
+        if kw.get('mode') != 'bilinear' or kw.get('align_corners') is not True or kw.get('antialias', False):
+            return None
+        if not isinstance(size, (tuple, list, torch.Size)) or len(size) != 2 or x.dtype not in (torch.float16, torch.float32) \
+                or x.shape[1] > 32 or x.requires_grad:
+            return None
+        h0, w0 = int(size[0]), int(size[1])
+        r = LazyResized((x.shape[0], x.shape[1], h0, w0), x.dtype, x.device)
+        r.__dict__.update(_src=x, _hw=(h0, w0), _sel=None, _labels={})
+
+        def real():
+            materialize(x)
+            with torch._C.DisableTorchFunctionSubclass():
+                return torch.nn.functional.interpolate(x, (h0, w0), mode='bilinear', align_corners=True).as_subclass(torch.Tensor)
+        r.__dict__['_thunk'] = real
+        return r
+
+    def _labels_all(self):
+        lab = self._labels.get('all')
+        if lab is None:
+            from .utils.general import seg_argmax
+            src = self._src
+            st = src.__dict__.get('_myolo_lazy_state')
+            if st is not None and not st['done'] and st['holder'].generation != st['generation']:
+                materialize(src)                           # raises: the logits of an older forward are gone
+            lab = self._labels['all'] = seg_argmax(src, *self._hw)
+        return lab
+
+    def _class_dim(self, d):
+        if isinstance(d, bool) or not isinstance(d, int):
+            return False
+        return (d + self.dim() if d < 0 else d) == self.dim() - 3
+
+    def _pattern(self, func, args, kw):
+        T = torch.Tensor
+        if func is T.__getitem__ and self._sel is None and isinstance(args[1], int) and not isinstance(args[1], bool):
+            i = args[1] + (self.shape[0] if args[1] < 0 else 0)
+            if not 0 <= i < self.shape[0]:
+                raise IndexError(f'index {args[1]} is out of bounds for dimension 0 with size {self.shape[0]}')
+            r = LazyResized(tuple(self.shape[1:]), self.dtype, self.device)
+            r.__dict__.update(_src=self._src, _hw=self._hw, _sel=i, _labels=self._labels, _thunk=lambda: self._force()[i])
+            return r
+        if func in (T.detach, getattr(T, 'data').__get__):
+            return self
+        if func in (T.max, torch.max, T.argmax, torch.argmax):
+            rest = dict(kw)
+            d = args[1] if len(args) > 1 else rest.pop('dim', rest.pop('axis', None))
+            keep = args[2] if len(args) > 2 else rest.pop('keepdim', False)
+            if rest or len(args) > 3 or keep or not self._class_dim(d):
+                return NotImplemented
+            lab = self._labels_all()
+            if self._sel is not None:
+                lab = lab[self._sel]
+            if func in (T.argmax, torch.argmax):
+                return lab
+            vals = _LazyTensor(tuple(lab.shape), self.dtype, self.device)
+            vals.__dict__['_thunk'] = lambda: torch.max(self._force(), d)[0]
+            return torch.return_types.max((vals, lab))
+        return NotImplemented
 
 
 def materialize(t):

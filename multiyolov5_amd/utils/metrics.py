@@ -14,6 +14,9 @@ from .general import seg_argmax
 
 
 def _labels(output):
+    from ..runtime import LazyResized
+    if isinstance(output, LazyResized):         # test.py:38's resized prediction: the fused resize + arg-max, cached on the view
+        return output.argmax(1)
     if output.dim() == 4:                       # logits [N,C,H,W]: `_, predict = torch.max(output, 1)` (metrics.py:240,259)
         return seg_argmax(output, out_dtype=torch.uint8)
     L.require_gpu(output)

@@ -70,6 +70,10 @@ def read_f32(ptr, n):
     return dev_read(_ptr(ptr), 4 * n).view(torch.float32).clone()
 
 
+def read_u32(ptr, n):
+    return dev_read(_ptr(ptr), 4 * n).view(torch.int32).clone()
+
+
 def read_tensor(t, channels=None):
     """myolo_tensor (NHWC view with strides in elements) -> fp32 [n,h,w,c] on the CPU"""
     es = 2 if t.dtype == L.F16 else 4
@@ -249,7 +253,7 @@ def bn_fwd_ref(y, stats, gamma, beta, eps, act, res):
 
 
 BN_NAMES = ('myolo_bn_act_fwd', 'myolo_bn_act_fwd_split', 'myolo_bn_act_bwd_reduce', 'myolo_bn_act_bwd_reduce_split', 'myolo_bn_act_bwd_apply',
-            'myolo_bn_act_bwd_apply_split')
+            'myolo_bn_act_bwd_apply_split', 'myolo_bn_act_bwd_fused')
 CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair')
 
 
@@ -403,6 +407,39 @@ class LaunchChecker:
         if name.endswith('_split'):
             split = self._desc(a[-1])
             name = name[:-6]
+        if name == 'myolo_bn_act_bwd_fused':
+            # round 6: reduce + apply in one launch -- everything both passes store, against first principles over the operands
+            # (the sums the apply formula uses are the REFERENCE's, not the kernel's)
+            split = self._desc(a[12]) if a[12] is not None else None
+            god, yd, dyd, grd, racc = self._desc(a[0]), self._desc(a[1]), self._desc(a[9]), self._desc(a[10]), int(_fv(a[11]))
+            B = _BnArgs(yd, split)
+            C, M = B.C, B.M * B.scale
+            act = int(_fv(a[5]))
+            gout, y = read_tensor(god, channels=C), read_tensor(yd)
+            sv = read_f32(a[2], 2 * C)
+            mean, invstd = sv[:C], sv[C:]
+            gamma = _split_vec(a[3], split.gamma2 if split else None, C, B.cs)
+            beta = _split_vec(a[4], split.beta2 if split else None, C, B.cs)
+            xhat = (y - mean) * invstd
+            dz = gout * act_grad(xhat * gamma + beta, act)
+            ds = torch.stack([dz.double().sum((0, 1, 2)), (dz * xhat).double().sum((0, 1, 2))])
+            dy_ref = (gamma * invstd) * (dz - (ds[0] / M).float() - xhat * (ds[1] / M).float())
+            d0 = stat_sums(a[6], C)
+            g0 = (_split_vec(a[7], split.dgamma2 if split else None, C, B.cs), _split_vec(a[8], split.dbeta2 if split else None, C, B.cs))
+            gres0 = read_tensor(grd, channels=C) if (grd.ptr and racc) else None
+            self.orig(call, st)
+            torch.cuda.synchronize()
+            what = f'bn_bwd_fused[{yd.n}x{yd.h}x{yd.w}x{C}' + ('+gres' if grd.ptr else '') + ('+split' if split is not None and B.cs < C else '') + f']#{self.k}'
+            assert int(read_u32(a[13], 19 * 32)[18 * 32]) == 0, what + ': the grid barrier timed out'
+            self._ck(what + '/dsum', (stat_sums(a[6], C) - d0).float(), ds.float(), self.tol_stat)
+            self._ck(what + '/dy', read_tensor(dyd), dy_ref, self.tol_out)
+            if grd.ptr:
+                self._ck(what + '/gres', read_tensor(grd, channels=C), gout + (gres0 if gres0 is not None else 0), self.tol_out)
+            g1 = _split_vec(a[7], split.dgamma2 if split else None, C, B.cs)
+            b1 = _split_vec(a[8], split.dbeta2 if split else None, C, B.cs)
+            self._ck(what + '/dgamma', g1 - g0[0], (ds[1] / B.scale).float(), self.tol_stat)
+            self._ck(what + '/dbeta', b1 - g0[1], (ds[0] / B.scale).float(), self.tol_stat)
+            return
         if name == 'myolo_bn_act_fwd':
             yd, res_d, out_d = self._desc(a[0]), self._desc(a[11]), self._desc(a[12])
             B = _BnArgs(yd, split)

@@ -168,6 +168,107 @@ def test_seg_argmax_fused_matches_oracle_and_model_output():
     assert_argmax_exact_or_near_tie('postproc/seg_argmax_resized', lab2[0].long().cpu(), torch.from_numpy(ref2).long(), r2, eps=1e-5)
 
 
+class _AtenLog(torch.utils._python_dispatch.TorchDispatchMode):
+    """every ATen op that reaches the dispatcher while the mode is active"""
+
+    def __init__(self):
+        super().__init__()
+        self.ops = []
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        self.ops.append(str(func))
+        return func(*args, **(kwargs or {}))
+
+
+@pytest.mark.parametrize('half', [False, True], ids=['f32', 'f16'])
+def test_unchanged_detect_py_and_test_py_statements_run_the_fused_argmax(half, monkeypatch):
+    """detect.py:144-149,191-193 and test.py:34-40 + utils/metrics.py:240,259 AS THE REFERENCE WRITES THEM, under
+    dropin.install(): the resize + arg-max must be the library's fused launch (myolo_seg_argmax in the launch trace, no ATen
+    upsample_bilinear2d / max in the dispatcher log) and the indices must be the reference's"""
+    import torch.nn.functional as F
+    from multiyolov5_amd import _lib as L, dropin, runtime as R
+    from oracle import metrics_ref
+    from tests.test_gpu_model import assert_argmax_exact_or_near_tie
+    with dropin.installed():
+        from models.yolo import Model                              # the reference's import path (train.py:20, detect.py:34)
+        from multiyolov5_amd.utils.general import non_max_suppression
+        model = Model(os.path.join(CFG, TAGS['s_psp']))
+        model.load_state_dict(synth_sd('s_psp'), strict=True)
+        model = model.to(DEV)
+        if half:
+            model.half()
+        model.fuse().eval()
+        img = synth.synth_images(2, 64, 128, seed=1).to(DEV)
+        img = img.half() if half else img
+
+        def trace_names():
+            tr = L.launch_trace()
+            L.lib().myolo_trace_start(0)
+            return [n for n, c in tr.items() for _ in range(c) if 'seg_argmax' in n or 'seg_up' in n]
+
+        # ---- detect.py:144-149 + 191-193 (im0 = a 100 x 180 source frame, then one of the network's own size)
+        for (h0, w0) in ((100, 180), (64, 128)):
+            im0 = np.zeros((h0, w0, 3), np.uint8)
+            with torch.no_grad():
+                out = model(img[:1], augment=False)
+                pred = out[0][0]
+                seg = out[1]
+                pred = non_max_suppression(pred, 0.25, 0.45, classes=None, agnostic=False)
+                L.lib().myolo_trace_start(1)
+                with _AtenLog() as log:
+                    seg = F.interpolate(seg, (im0.shape[0], im0.shape[1]), mode='bilinear', align_corners=True)[0]
+                    mask = seg.max(axis=0)[1].cpu().numpy()
+                names = trace_names()
+            assert mask.shape == (h0, w0) and mask.dtype == np.int64
+            assert not any('upsample' in o or 'aten.max' in o or 'argmax' in o for o in log.ops), log.ops
+            assert sum('seg_argmax' in n for n in names) == 1, names
+            # the ATen route over the same logits (round 5's behaviour) and the oracle's resize + argmax
+            monkeypatch.setattr(R, 'LAZY_RESIZE', False)
+            with torch.no_grad():
+                seg2 = model(img[:1], augment=False)[1]
+                full = F.interpolate(seg2, (h0, w0), mode='bilinear', align_corners=True)[0]
+                ref_aten = full.max(axis=0)[1].cpu().numpy()
+                logits = seg2[0].float().cpu().numpy()
+            monkeypatch.setattr(R, 'LAZY_RESIZE', True)
+            ref = nms_ref.seg_argmax(logits, h0, w0)
+            r2 = torch.from_numpy(nms_ref.bilinear_ac(logits, h0, w0))[None]
+            assert_argmax_exact_or_near_tie(f'unchanged/detect_{h0}x{w0}', torch.from_numpy(mask)[None], torch.from_numpy(ref).long()[None], r2,
+                                            eps=1e-5 if not half else 2e-3)
+            assert (mask != ref_aten).mean() <= (0 if (h0, w0) == (64, 128) else 2e-3)
+
+        # ---- test.py:34-40 + metrics.py:240-249, 259-275 on a batch of two; target at twice the network's resolution
+        target = synth.synth_seg_targets(2, 128, 256, 19, seed=5)
+        with torch.no_grad():
+            outputs = model(img)
+            pred = outputs[1]
+            target = target.to(DEV, non_blocking=True)
+            L.lib().myolo_trace_start(1)
+            with _AtenLog() as log:
+                pred = F.interpolate(pred, (target.shape[1], target.shape[2]), mode='bilinear', align_corners=True)
+                _, predict = torch.max(pred.data, 1)                               # batch_pix_accuracy
+                predict = predict.cpu().numpy().astype('int64') + 1
+                _, predict2 = torch.max(pred.data, 1)                              # batch_intersection_union
+                predict2 = predict2.cpu().numpy().astype('int64') + 1
+            names = trace_names()
+        assert not any('upsample' in o or 'aten.max' in o or 'argmax' in o for o in log.ops), log.ops
+        assert sum('seg_argmax' in n for n in names) == 1, names                  # the second torch.max reuses the label map
+        np.testing.assert_array_equal(predict, predict2)
+        monkeypatch.setattr(R, 'LAZY_RESIZE', False)
+        with torch.no_grad():
+            p2 = F.interpolate(model(img)[1], (128, 256), mode='bilinear', align_corners=True)
+            ref_pred = torch.max(p2.data, 1)[1].cpu().numpy().astype('int64') + 1
+            rc, rl = metrics_ref.batch_pix_accuracy(p2.float().cpu().numpy(), target.cpu().numpy())
+        monkeypatch.setattr(R, 'LAZY_RESIZE', True)
+        assert (predict != ref_pred).mean() <= 2e-3
+        t = target.cpu().numpy().astype('int64') + 1
+        correct, labeled = np.sum((predict == t) * (t > 0)), np.sum(t > 0)
+        assert labeled == rl and abs(int(correct) - int(rc)) <= 2e-3 * predict.size
+        # the mirror's own counters take the cached label map of the view
+        from multiyolov5_amd.utils.metrics import batch_pix_accuracy
+        c3, l3 = batch_pix_accuracy(pred.data, target)
+        assert (int(c3), int(l3)) == (int(correct), int(labeled))
+
+
 def test_seg_metrics_match_reference_golden_and_oracle():
     """test.py:31-65 counters (batch_pix_accuracy / batch_intersection_union) on the device: bit-exact integers."""
     from multiyolov5_amd.utils.metrics import batch_intersection_union, batch_pix_accuracy

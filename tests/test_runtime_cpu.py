@@ -18,11 +18,18 @@ def _plan(tag='s_psp', training=True, dt=torch.float16):
     return R.PlanHolder(m, [torch.zeros(2, 3, 64, 128)], ('t', 0), dt, training).plan
 
 
-def test_training_plan_launch_list_structure():
+def test_training_plan_launch_list_structure(monkeypatch):
     from multiyolov5_amd import engine as E
+    # round 6: at this size every BatchNorm backward whose sums are not produced by a dgrad epilogue is ONE launch (reduce + barrier + apply)
+    plan = _plan()
+    bwd = Counter(c.name for op in plan.ops for c in op.bwd_calls)
+    assert bwd['myolo_bn_act_bwd_fused'] >= 9 and bwd['myolo_bn_act_bwd_reduce_split'] == 0 and bwd['myolo_bn_act_bwd_apply_split'] == 0
+    assert hasattr(plan, '_grid_bar') and plan._grid_bar.numel() == 19 * 32
+    monkeypatch.setattr(E, 'BN_BWD_FUSED', 0)                       # the two-launch form (what the big maps of the benchmarked step still run)
     plan = _plan()
     fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
     bwd = Counter(c.name for op in plan.ops for c in op.bwd_calls)
+    assert bwd['myolo_bn_act_bwd_fused'] == 0
     # 8 C3 blocks + RFB2: two same-input 1x1 Conv+BN+SiLU as one convolution with split BatchNorm parameters (common.py:137,500-501)
     assert fwd['myolo_bn_act_fwd_split'] == 9 and bwd['myolo_bn_act_bwd_apply_split'] == 9 and bwd['myolo_bn_act_bwd_reduce_split'] == 9
     merged = [op for op in plan.ops if isinstance(op, E.ConvOp) and op.weight2 is not None]
@@ -261,6 +268,7 @@ def test_tiny_conv_groups_leave_the_launch_chain(monkeypatch):
     launches; the pruned one-loss schedules remain valid; fp32 plans, whose four upsamples are not one launch, do not group"""
     from multiyolov5_amd import engine as E
     monkeypatch.setattr(E, 'TINY_CONV', True)
+    monkeypatch.setattr(E, 'BN_BWD_FUSED', 0)        # (the launch counts below are those of the two-pass BatchNorm backward)
     from multiyolov5_amd import runtime as R
     from multiyolov5_amd.models.yolo import Model
 
@@ -347,3 +355,93 @@ def test_every_tiny_conv_launch_passes_the_librarys_host_checks(tag, res, monkey
         assert n % 2 == 0
         del plan, op, calls, c, g
         gc.collect()
+
+
+class _AtenLog(torch.utils._python_dispatch.TorchDispatchMode):
+    """every ATen op that reaches the dispatcher while the mode is active"""
+
+    def __init__(self):
+        super().__init__()
+        self.ops = []
+
+    muted = False            # (the stand-in for the library's kernel computes with ATen: not part of what is checked)
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        if not _AtenLog.muted:
+            self.ops.append(str(func))
+        return func(*args, **(kwargs or {}))
+
+
+def _lazy_logits(base, launches):
+    from multiyolov5_amd import runtime as R
+    holder = SimpleNamespace(generation=1, wait_branch=lambda: None)
+    op = SimpleNamespace(lazy_call=lambda st: launches.append('upsample'))
+    t = base.detach().as_subclass(R.LazySegLogits)
+    t._myolo_lazy_state = {'holder': holder, 'op': op, 'generation': 1, 'done': False}
+    return t
+
+
+def test_unchanged_detect_and_test_py_statements_reach_the_fused_argmax(monkeypatch):
+    """detect.py:191-193 and test.py:38 + utils/metrics.py:240,259 as the reference writes them: `F.interpolate(seg, size, mode='bilinear',
+    align_corners=True)` of the model's lazy logits is a deferred view, `[0]`, `.data`, `.max(axis=0)[1]` / `torch.max(output, 1)` on it
+    call the fused resize + arg-max ONCE and never run ATen's upsample / max; any other use computes the reference's values"""
+    import torch.nn.functional as F
+    from multiyolov5_amd import _lib as L
+    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd.utils import general as G
+    calls = []
+
+    def fake_seg_argmax(seg, h0=None, w0=None, out_dtype=torch.int64):
+        calls.append((h0, w0))
+        _AtenLog.muted = True
+        try:
+            with torch._C.DisableTorchFunctionSubclass():
+                return F.interpolate(seg.as_subclass(torch.Tensor), (h0, w0), mode='bilinear', align_corners=True).argmax(1)
+        finally:
+            _AtenLog.muted = False
+    monkeypatch.setattr(G, 'seg_argmax', fake_seg_argmax)
+    monkeypatch.setattr(L, 'stream_ptr', lambda: 'stream')
+    torch.manual_seed(0)
+    base = torch.randn(2, 19, 8, 16)
+    ref = F.interpolate(base, (24, 40), mode='bilinear', align_corners=True)
+    # --- detect.py:191-193
+    launches = []
+    seg = _lazy_logits(base, launches)
+    with _AtenLog() as log:
+        seg = F.interpolate(seg, (24, 40), mode='bilinear', align_corners=True)[0]
+        assert isinstance(seg, R.LazyResized) and tuple(seg.shape) == (19, 24, 40) and seg.dtype == torch.float32
+        lab = seg.max(axis=0)[1]
+    assert type(lab) is torch.Tensor and torch.equal(lab, ref[0].argmax(0)) and calls == [(24, 40)] and launches == []
+    assert not any('upsample' in o or 'max' in o for o in log.ops), log.ops
+    # --- test.py:38 + metrics.py:240,259: two torch.max over the same resized prediction -> one launch
+    calls.clear()
+    pred = F.interpolate(_lazy_logits(base, launches), (24, 40), mode='bilinear', align_corners=True)
+    with _AtenLog() as log:
+        _, p1 = torch.max(pred.data, 1)
+        _, p2 = torch.max(pred.data, 1)
+    assert torch.equal(p1, ref.argmax(1)) and p2 is p1 and calls == [(24, 40)] and launches == []
+    assert not any('upsample' in o or 'max' in o for o in log.ops), log.ops
+    assert torch.equal(pred.argmax(1), p1) and torch.equal(pred[-1].argmax(dim=-3), p1[1])
+    # the deferred maximum VALUES and every other use are the reference's numbers (materialise + ATen)
+    v, i = pred.max(1)
+    assert launches == [] and torch.equal(i, p1)
+    torch.testing.assert_close(v + 0, ref.max(1)[0])
+    assert launches == ['upsample']
+    torch.testing.assert_close(pred * 1.0, ref)
+    torch.testing.assert_close(pred[1].float(), ref[1])
+    torch.testing.assert_close(pred.max(), ref.max())                          # (no dim: not the pattern)
+    torch.testing.assert_close(pred.max(2)[0], ref.max(2)[0])                  # (not the class axis)
+    # not the reference's call: nearest / align_corners=False / a training-mode output take the ATen route at once
+    launches.clear()
+    out = F.interpolate(_lazy_logits(base, launches), (24, 40), mode='bilinear', align_corners=False)
+    assert type(out) is torch.Tensor and launches == ['upsample']
+    # a view of an OLDER forward refuses to serve labels
+    old = _lazy_logits(base, launches)
+    r = F.interpolate(old, (24, 40), mode='bilinear', align_corners=True)
+    old._myolo_lazy_state['holder'].generation = 2
+    with pytest.raises(L.MyoloError):
+        r.max(1)
+    # switched off: the round-5 behaviour
+    monkeypatch.setattr(R, 'LAZY_RESIZE', False)
+    out = F.interpolate(_lazy_logits(base, launches), (24, 40), mode='bilinear', align_corners=True)
+    assert type(out) is torch.Tensor
