@@ -153,7 +153,9 @@ int myolo_conv_dgrad_bn(const myolo_conv_desc* d, const myolo_bn_apply_fold* f, 
  * Bottleneck (reference models/common.py:95-105 `x + cv2(cv1(x))` with Conv.fuseforward, common.py:45-46; the shortcut is b->res).  Each
  * descriptor keeps the meaning it has for myolo_conv (scale / shift / act / res); the intermediate is rounded to the storage type where
  * the two-launch form stores it.  When the fused kernel runs (fp16, 64 / 128 / 256 channels in, mid and out ... csrc/conv_pair.hip) a->y
- * is NOT written; every other pair runs as myolo_conv(a) followed by myolo_conv(b), which is also the definition of the result. */
+ * is NOT written; every other pair runs as myolo_conv(a) followed by myolo_conv(b), which is also the definition of the result.
+ * Aliasing: b->y may overlap a->x or b->res (an in-place Bottleneck) -- such a pair is never fused (neighbouring workgroups would still
+ * read the input halo while others store the output); it runs as the two launches, for which that aliasing is harmless. */
 int myolo_conv_pair(const myolo_conv_desc* a, const myolo_conv_desc* b, void* stream);
 
 /* dgrad of a STRIDE-2 convolution.  `parity[k]`, k = 2*py + px, is the stride-1 sub-convolution producing the input-gradient pixels

@@ -40,6 +40,8 @@ struct MidK {
   int Hi, Wi, Wo, HWo, M, Cout;
   int stride, ntaps, kchunks, nsteps;
   int wrow_bytes;                  // bytes between two output-channel rows of the packed weights (wtaps * cin_pad * 2)
+  int cin_b;                       // bytes of one input pixel's channels (x.c * 2): below kchunks * 128 for yolov5m's 48 / 96-channel layers, whose
+                                   // last K step is ragged -- the lanes whose 16-byte segment lies past it fetch the zero page (round 6)
   int ntile_p, tiles_per_xcd, accumulate;
   // BNA: the BatchNorm-backward APPLY pass of the layer this 1x1 dgrad belongs to, in its operand path: x is the gradient w.r.t. the
   // layer's activation output (gout), `by` its saved raw conv output; dy = sc*dz + cb*y + cd (dz = gout * act'(y*sc + sh)) is formed in LDS
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   int wbase[WR];
 #pragma unroll
   for (int j = 0; j < WR; ++j) wbase[j] = (tn * BN + panel_chan(j * RPI + lrow)) * p.wrow_bytes + lsg * 16;
+  const unsigned klast = (unsigned)((p.kchunks - 1) * 128 + lsg * 16 < p.cin_b);      // this lane's segment of the LAST K chunk holds channels
 
   // fragment reads: row l15 of a 16-row fragment, K segment kk*4 + lq, swizzled
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t*)smem;
@@ -198,9 +201,10 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     auto addresses = [&]() {                       // source addresses of the next stage's LPS pieces (+ cursor advance)
       const int t = i_tap;
       const int xo = n_xt + i_kc * 128, wo = n_wt + i_kc * 128;
+      const unsigned km = (i_kc == p.kchunks - 1) ? klast : 1u;      // (uniform compare: a ragged last chunk costs one AND per load)
 #pragma unroll
-      for (int j = 0; j < XR; ++j)                 // per-lane select: taps outside the image / rows past M fetch the zero page; the load itself is unconditional
-        src[j] = ((xmask[j] >> t) & 1u) ? p.x + (unsigned)(xbase[j] + xo) : zero_page();
+      for (int j = 0; j < XR; ++j)                 // per-lane select: taps outside the image / rows past M / channels past the tensor fetch the zero page; the load itself is unconditional
+        src[j] = ((xmask[j] >> t) & km) ? p.x + (unsigned)(xbase[j] + xo) : zero_page();
 #pragma unroll
       for (int j = 0; j < WR; ++j) src[XR + j] = p.w + (unsigned)(wbase[j] + wo);
       if (BNA) {
@@ -532,13 +536,17 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
     if (!bf->saved || !bf->gamma || !bf->beta || !bf->dsum || bf->act != MYOLO_ACT_SILU) return -1;
     if ((bf->y.sw % 8) || (bf->dy.sw % 8) || ((uintptr_t)bf->y.ptr & 15) || ((uintptr_t)bf->dy.ptr & 15)) return -1;
   }
-  if (d->cin_pad % 64 || d->x.c != d->cin_pad || d->cout_pad % 64 || d->y.c % 8 || d->ntaps > 25) return -1;
+  // (round 6: x.c < cin_pad -- the 48 / 96-channel layers of yolov5m with their weights zero-padded to 64 / 128 input channels -- runs with a
+  //  ragged LAST K chunk; MYOLO_MID_RAGGED=0 leaves those layers to conv_igemm / conv_stream as before)
+  static const int ragged = getenv("MYOLO_MID_RAGGED") ? atoi(getenv("MYOLO_MID_RAGGED")) : 1;
+  if (d->cin_pad % 64 || d->x.c > d->cin_pad || d->cin_pad - d->x.c >= 64 || d->x.c % 8 || (d->x.c != d->cin_pad && !ragged) ||
+      d->cout_pad % 64 || d->y.c % 8 || d->ntaps > 25) return -1;
   if (d->res.ptr && (d->res.c < d->y.c)) return -1;
   const int64_t M = (int64_t)d->y.n * d->y.h * d->y.w;
   if (M < 1024 || M > (1 << 24)) return -1;
   // one-step K loops (1x1, 64 channels) are pure streaming: on the 128x256 maps the streaming kernel wins (39.3 vs 43.6 us at batch 16), on
   // the 64x128 maps this one (18.2 -> 13.7)
-  if (d->ntaps * (d->cin_pad / 64) < 2 && M > 300000) return -1;
+  if (d->ntaps * (d->cin_pad / 64) < 2 && M > 200000) return -1;      // (200 000: batch 8 of the 128x256 maps too; batch 16 has nothing between 131 072 and 524 288)
   auto extent = [](const myolo_tensor& t) { return ((int64_t)t.n * t.sn + (int64_t)t.h * t.sh + (int64_t)t.w * t.sw + t.c) * 2; };
   if (extent(d->x) >= (1ll << 31) || extent(d->y) >= (1ll << 31) || (d->res.ptr && extent(d->res) >= (1ll << 31))) return -1;
   if ((int64_t)d->cout_pad * d->wtaps * d->cin_pad * 2 >= (1ll << 31)) return -1;
@@ -551,6 +559,7 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   k.Hi = d->x.h; k.Wi = d->x.w; k.Wo = d->y.w; k.HWo = d->y.h * d->y.w; k.M = (int)M; k.Cout = d->y.c;
   k.stride = d->stride; k.ntaps = d->ntaps; k.kchunks = d->cin_pad / 64; k.nsteps = k.ntaps * k.kchunks;
   k.wrow_bytes = d->wtaps * d->cin_pad * 2;
+  k.cin_b = d->x.c * 2;
   k.accumulate = d->accumulate; k.dbg = g_mid_dbg;
   k.by = nullptr; k.bdy = nullptr; k.b_K = 0;
   if (bf) {

@@ -434,6 +434,33 @@ static int pair_try(const myolo_conv_desc* a, const myolo_conv_desc* b, void* st
   if (extent(a->x) >= (1ll << 31) || extent(b->y) >= (1ll << 31) || (b->res.ptr && extent(b->res) >= (1ll << 31))) return -1;
   if ((int64_t)b->cout_pad * b->wtaps * C * 2 >= (1ll << 31)) return -1;
   if (((uintptr_t)a->x.ptr & 15) || ((uintptr_t)b->y.ptr & 15) || (a->x.sw % 8) || (b->y.sw % 8) || (b->res.ptr && (b->res.sw % 8))) return -1;
+  // what the kernel's address arithmetic silently assumes -- one weight tap in `a` at slot 0 (w1row_bytes), 16-byte rows
+  // everywhere (sn / sh multiples of 8 halves, an aligned residual of the OUTPUT's shape) -- and NO aliasing of the output with the input
+  // halo or the residual: in the two-launch form an in-place Bottleneck is harmless (every element's residual is read before its output is
+  // written by the same thread), here neighbouring workgroups still read the x halo while others store y
+  if (a->wtaps != 1 || a->tap_w[0] != 0) return -1;
+  if ((a->x.sn % 8) || (a->x.sh % 8) || (b->y.sn % 8) || (b->y.sh % 8)) return -1;
+  if (b->res.ptr && (((uintptr_t)b->res.ptr & 15) || (b->res.sn % 8) || (b->res.sh % 8) || b->res.n != b->y.n || b->res.h != b->y.h || b->res.w != b->y.w))
+    return -1;
+  auto span = [](const myolo_tensor& t) {            // exact: one past the last byte the view touches
+    return (uintptr_t)((((int64_t)t.n - 1) * t.sn + ((int64_t)t.h - 1) * t.sh + ((int64_t)t.w - 1) * t.sw + t.c) * 2);
+  };
+  auto overlap = [&](const myolo_tensor& p, const myolo_tensor& q) {
+    const uintptr_t p0 = (uintptr_t)p.ptr, p1 = p0 + span(p), q0 = (uintptr_t)q.ptr, q1 = q0 + span(q);
+    return p0 < q1 && q0 < p1;
+  };
+  // (channel slices of ONE concat buffer interleave in memory without sharing an element: their byte ranges overlap although the tensors
+  //  do not -- the engine's plans are full of them.  Two views alias only if they also share channels: same pixel pitch and row walk, and the
+  //  channel intervals [ptr, ptr + c) modulo the pixel pitch intersect)
+  auto alias = [&](const myolo_tensor& p, const myolo_tensor& q) {
+    if (!overlap(p, q)) return false;
+    if (p.sw != q.sw || p.sh != q.sh || p.sn != q.sn) return true;                   // different walks over overlapping bytes: assume the worst
+    const int64_t pitch = (int64_t)p.sw * 2;
+    const int64_t d = (((int64_t)((uintptr_t)q.ptr - (uintptr_t)p.ptr)) % pitch + pitch) % pitch;   // q's first channel inside p's pixel, bytes
+    const int64_t pc = (int64_t)p.c * 2, qc = (int64_t)q.c * 2;
+    return d < pc || d + qc > pitch;                                                  // q starts inside p's channels, or wraps around into them
+  };
+  if (alias(a->x, b->y) || (b->res.ptr && alias(b->res, b->y) ) || alias(a->y, b->y)) return -1;
   PairK k;
   k.x = (const char*)a->x.ptr; k.w1 = (const char*)a->w; k.w2 = (const char*)b->w; k.y = (char*)b->y.ptr; k.res = (const char*)b->res.ptr;
   k.sc1 = a->scale; k.sh1 = a->shift; k.sc2 = b->scale; k.sh2 = b->shift; k.act1 = a->act; k.act2 = b->act;

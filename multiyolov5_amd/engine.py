@@ -53,6 +53,19 @@ SEG = {torch.float16: 8, torch.float32: 4}
 KC = {torch.float16: 32, torch.float32: 16}
 
 
+# round 6: fp16 convolutions whose channel count is 32 modulo 64 (yolov5m's 96) get their packed weights zero-padded to the next multiple of
+# 64 in K and in N, so that conv_mid's 128-byte K steps / 64-wide N tiles take the layer (ragged last chunk: the activation lanes past the
+# tensor's channels fetch the zero page); 0: the round-5 padding (multiples of 32: conv_igemm's 96-wide tile / conv_stream run those layers)
+MID_RAGGED = os.environ.get('MYOLO_MID_RAGGED', '1') != '0'
+
+
+def conv_pad(c, m, dt):
+    """padded channel count of a packed weight operand (m: the kernel family's minimum granule)"""
+    if MID_RAGGED and dt == torch.float16 and c >= 96 and c % 64 == 32:
+        return rup(c, 64)
+    return rup(c, m)
+
+
 def rup(x, m):
     return (x + m - 1) // m * m
 
@@ -404,7 +417,7 @@ class ConvOp(Op):
         has_bn = self.bn is not None
         two_pass = training and (has_bn or self.act != L.ACT_NONE)
         ntaps = self.k * self.k
-        cin_pad, cout_pad = rup(self.x.c, kc), rup(self.cout, 32)
+        cin_pad, cout_pad = conv_pad(self.x.c, kc, dt), conv_pad(self.cout, 32, dt)
         self.wpack = torch.zeros(cout_pad, ntaps, cin_pad, dtype=dt, device=dev)
         w = self.weight
         w2 = self.weight2
@@ -489,7 +502,8 @@ class ConvOp(Op):
         self.fdesc = d
         # eval: a 1x1 layer whose output only this 3x3 layer reads (Bottleneck, models/common.py) runs inside this launch (csrc/conv_pair.hip)
         first = getattr(self, 'pair_first', None)
-        if first is not None and CONV_PAIR and not training and len(self.fwd_calls) == 1 and len(first.fwd_calls) == 1:
+        if first is not None and CONV_PAIR and not training and len(self.fwd_calls) == 1 and len(first.fwd_calls) == 1 and \
+                plan.sole_reader(first.out, first, self):      # (the intermediate is never written by the fused launch)
             first.fwd_calls.clear()
             self.fwd_calls[0] = Call('myolo_conv_pair', (C.byref(first.fdesc), C.byref(d)))
         if training:
@@ -596,7 +610,7 @@ class ConvOp(Op):
         self.dy_desc = dy_desc
         # dgrad
         if self.x.requires_grad:
-            cin_pad_t, cout_pad_t = rup(dy_desc.c, kc), rup(self.x.c, 32)
+            cin_pad_t, cout_pad_t = conv_pad(dy_desc.c, kc, dt), conv_pad(self.x.c, 32, dt)
             ntaps = self.k * self.k
             self.wpack_t = torch.zeros(cout_pad_t, ntaps, cin_pad_t, dtype=dt, device=dev)
             w = self.weight
@@ -1297,6 +1311,27 @@ class Plan:
     def f32_bwd_zero(self, n):
         """fp32 scratch zeroed at the start of every backward (BN backward sums, gate partials)."""
         return self._carve(1, n)
+
+    def sole_reader(self, tv, producer, reader):
+        """True when `reader` is the only op of the plan besides `producer` that holds a view overlapping `tv` (any attribute that is a TV, or a
+        list / tuple of them: inputs, residuals, concat members, exported outputs).  Fusions that stop writing an intermediate tensor
+        (myolo_conv_pair) ask this at build time instead of trusting the emitting module's intent."""
+        def views(o):
+            for v in vars(o).values():
+                if isinstance(v, TV):
+                    yield v
+                elif isinstance(v, (list, tuple)):
+                    for u in v:
+                        if isinstance(u, TV):
+                            yield u
+        lo, hi = tv.coff, tv.coff + tv.c
+        for o in self.ops:
+            if o is producer or o is reader:
+                continue
+            for v in views(o):
+                if v.buf is tv.buf and v.coff < hi and v.coff + v.c > lo:
+                    return False
+        return True
 
     def grid_barrier(self):
         """state of the in-launch device-wide barrier (include/myolo.h MYOLO_GRID_BARRIER_BYTES; zeroed once, self-resetting; shared by the

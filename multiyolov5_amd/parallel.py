@@ -21,6 +21,8 @@ class GradReducer:
         self.nbuckets = max(1, int(nbuckets))
         self.stream = None
         self._works = []
+        self.issued = []               # (lo, hi) of the slices handed over since the last finish(), in issue order
+        self.last_issued = []          # ... of the step before (describe(): what a scaling run's bench line reports)
         self.exposed = None            # bench.py: [(event before, event after)] around the main stream's wait for the exchange
         model.__dict__['_grad_reducer'] = self         # consulted by runtime.PlanFn.backward
 
@@ -49,6 +51,7 @@ class GradReducer:
     def reduce_slice(self, flat, lo, hi):
         if self.world == 1:
             return
+        self.issued.append((int(lo), int(hi)))
         view = flat[lo:hi]
         if flat.is_cuda:
             if self.stream is None:
@@ -70,6 +73,7 @@ class GradReducer:
 
     def finish(self, flat):
         """make the current stream wait for every outstanding slice."""
+        self.last_issued, self.issued = self.issued, []
         if self.world == 1 or not flat.is_cuda or self.stream is None:
             self._works = []
             return
@@ -89,8 +93,10 @@ class GradReducer:
     @staticmethod
     def _low_priority():
         """the communication stream only carries the pre-divide and the hand-over to RCCL (ProcessGroupNCCL runs the collective itself on
-        its own stream, ordered behind this one): lowest priority the device offers, so that its two small kernels per slice never
-        pre-empt the dgrad / BatchNorm chain on the launch stream (MYOLO_REDUCER_PRIO overrides).  Ordering against the
+        its own stream, ordered behind this one).  It ASKS for the lowest priority the device offers (MYOLO_REDUCER_PRIO overrides); what
+        it gets is in describe()['comm_stream_priority'] -- ADVICE r5: torch on ROCm may report a one-level priority range and clamp the
+        request to the default pool, in which case this stream simply has the launch stream's priority (its two small kernels per slice are
+        ~10 us of a 7.7 ms step either way; nothing relies on the priority for correctness).  Ordering against the
         weight-gradient stream: Plan._bwd_eager / the staged backward make the LAUNCH stream wait for the weight-gradient stream before a
         slice is handed over (the slice must be final), and the event recorded on the launch stream right here orders this stream behind
         both -- the exchange never runs beside a weight gradient that still writes into its slice."""
@@ -107,7 +113,7 @@ class GradReducer:
         """one-line diagnosis data for bench.py's N > 1 line"""
         return {'buckets': self.nbuckets, 'world': self.world, 'pre_divide_then_sum': True,
                 'comm_stream_priority': getattr(self.stream, 'priority', None) if self.stream is not None else None,
-                'slices_issued_last_step': len(self._works)}
+                'slices_issued_last_step': len(self.last_issued), 'slice_issue_order': list(self.last_issued)}
 
     def wait(self):
         """kept for call-site symmetry with DDP's implicit sync: PlanFn.backward already waited before handing out grads."""

@@ -47,6 +47,7 @@ from .. import _lib as _L
 
 
 _NMS_SCRATCH = {}
+_NMS_TINY = {}
 _NMS_CACHE_MAX_BYTES = 64 << 20
 
 
@@ -83,20 +84,32 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
     key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, A, no, multi, use_ws)
     # only detect.py-sized sets are kept (<= 64 MB of candidate rows); test.py's conf 0.001 + multi_label workspaces are
     # gigabytes per geometry and rect validation changes A almost every batch -- those come from (and go back to) torch's caching allocator
-    cacheable = B * cap * 6 * 4 <= _NMS_CACHE_MAX_BYTES
+    # (the bound counts EVERYTHING a cached set pins -- candidate rows, indices, the sorted rows, the counting-sort workspace and the
+    #  bit-matrix workspace of the short-list path (~9 MB per image) -- not the candidate rows alone)
+    mws_est = int(_L.lib().myolo_nms_ws_bytes(B, cap)) if (not use_ws and B <= 64) else 0
+    set_bytes = B * cap * (6 + 1) * 4 + B * max_nms * 6 * 4 + (B * (3 * 65536 + cap) * 4 if use_ws else 0) + mws_est
+    cacheable = set_bytes <= _NMS_CACHE_MAX_BYTES
     sc = _NMS_SCRATCH.get(key) if cacheable else None
     if sc is None:
         if len(_NMS_SCRATCH) > 16:
             _NMS_SCRATCH.clear()
-        sc = {'counts': torch.empty(B, dtype=torch.int32, device=dev), 'cand': torch.empty(B * cap * 6, dtype=torch.float32, device=dev),
+        # the tiny host-side objects (pinned keep-count buffer, event, the two count vectors) are cached per (device, stream, B) whatever the
+        # geometry: a pin_memory() per call is a synchronous hipHostMalloc on test.py's non-cacheable path
+        tiny = _NMS_TINY.get(key[:3])
+        if tiny is None:
+            if len(_NMS_TINY) > 64:
+                _NMS_TINY.clear()
+            tiny = _NMS_TINY[key[:3]] = {'counts': torch.empty(B, dtype=torch.int32, device=dev), 'nkeep': torch.empty(B, dtype=torch.int32, device=dev),
+                                         'host': torch.empty(B, dtype=torch.int32).pin_memory(), 'ev': torch.cuda.Event()}
+        sc = {'counts': tiny['counts'], 'cand': torch.empty(B * cap * 6, dtype=torch.float32, device=dev),
               'cidx': torch.empty(B * cap, dtype=torch.int32, device=dev), 'srt': torch.empty(B * max_nms * 6, dtype=torch.float32, device=dev),
-              'nkeep': torch.empty(B, dtype=torch.int32, device=dev), 'host': torch.empty(B, dtype=torch.int32).pin_memory(),
-              'ev': torch.cuda.Event(),
+              'nkeep': tiny['nkeep'], 'host': tiny['host'],
+              'ev': tiny['ev'],
               # long candidate lists (test.py: conf 0.001 + multi_label, 1e5 per image): counting sort instead of the O(n^2) rank kernel
               'ws': torch.empty(B * (3 * 65536 + cap), dtype=torch.int32, device=dev) if use_ws else None, 'mws': None, 'mws_bytes': 0}
         # short single-label lists (detect.py): rank / bit matrix on the whole device + a one-wave scan (csrc/nms.hip); 9 MB per image
         if sc['ws'] is None and B <= 64:
-            sc['mws_bytes'] = int(_L.lib().myolo_nms_ws_bytes(B, cap))
+            sc['mws_bytes'] = mws_est
             sc['mws'] = torch.empty(sc['mws_bytes'], dtype=torch.uint8, device=dev)
         if cacheable:
             _NMS_SCRATCH[key] = sc

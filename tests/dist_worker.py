@@ -16,6 +16,10 @@ def main():
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     torch.cuda.set_device(0)
     dist.init_process_group('gloo', init_method='env://')
+    from multiyolov5_amd import engine as E
+    # an exactness test (all-reduce == mean) must not inherit the arrival-order noise of the one-workgroup `tiny` launches
+    # (LDS float atomics: two runs of the same step differ by ~1e-4) -- they are off here and the bound is the round-4 one
+    E.TINY_CONV = False
     from multiyolov5_amd.models.yolo import Model
     from multiyolov5_amd.parallel import GradReducer
     from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
@@ -50,9 +54,9 @@ def main():
         ref = sum(l[k] for l in locals_) / world
         err = float((g_red[k] - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
         worst = max(worst, err)
-    # (5e-5 until round 5: at this test's 64x128 images most layers are one-workgroup `tiny` launches whose batch statistics are LDS float
-    #  atomics in arrival order -- two runs of the same step differ by ~1e-4; measured 1.4e-4 / 1.7e-4)
-    ok = worst < 1e-3 and staged is not None and len(staged) == 3
+    # 5e-5: a dropped bucket slice, a wrong 1 / world factor or a missing contribution is orders of magnitude above it (with the tiny
+    # launches on, two runs of the same step differ by 1.4e-4 / 1.7e-4: that noise belongs to tests/test_gpu_tiny_conv.py, not here)
+    ok = worst < 5e-5 and staged is not None and len(staged) == 3
     print(f'rank {rank}: worst relative deviation of the reduced gradient from the mean of the per-rank gradients {worst:.2e}; '
           f'staged backward: {None if staged is None else [len(s["params"]) for s in staged]} -> {"OK" if ok else "FAIL"}', flush=True)
     dist.barrier()

@@ -54,3 +54,29 @@ def test_single_gpu_form_needs_no_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dry-dist'], env=_env(), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-3000:]
     assert _json_line(r.stdout)['n_gpus'] == 1
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_exchange_the_gradient_slices_in_backward_completion_order():
+    """VERDICT r5 item 9 (code side only: no node with more than one GPU): `python bench.py --gpus 8 --dry-dist` = 8 gloo ranks, each with a
+    dry-built training plan and parallel.GradReducer.  The slices must be handed over in the order the backward completes them (head and
+    neck first, the stem last: descending `ready_after_op`), tile the flat gradient buffer exactly once, reduce to the mean over the
+    8 ranks, and the N > 1 line's diagnosis fields must be populated"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '0', '--dry-dist'],
+                       env=_env(), capture_output=True, text=True, timeout=560)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    rec = _json_line(r.stdout)
+    assert rec['n_gpus'] == 8 and rec['config']['parallelism'] == 'dp8'
+    d = rec['grad_exchange_detail']
+    assert d['world'] == 8 and d['buckets'] == 3 and d['pre_divide_then_sum'] and d['slices_issued_last_step'] == 3
+    order = [tuple(x) for x in d['slice_issue_order']]
+    buckets = [tuple(b) for b in rec['bucket_completion_order']]
+    assert order == [(a, b) for a, b, _ in buckets]                                       # issue order == completion order
+    assert [b[2] for b in buckets] == sorted((b[2] for b in buckets), reverse=True)      # ... which is descending op index (the backward's direction)
+    assert buckets[0][1] == rec['flat_grad_elements'] and buckets[-1][0] == 0             # Detect / head parameters first, the Focus conv last
+    cover = sorted(order)
+    assert cover[0][0] == 0 and cover[-1][1] == rec['flat_grad_elements'] and all(cover[i][1] == cover[i + 1][0] for i in range(len(cover) - 1))
+    segs = rec['backward_segments']
+    assert all(h > l for h, l in segs) and all(segs[i][1] == segs[i + 1][0] for i in range(len(segs) - 1)) and segs[-1][1] == 0
+    assert rec['exchange_max_abs_err_over_ranks'] < 1e-6
+    assert isinstance(rec['allreduce_exposed_ms'], float) and rec['allreduce_exposed_ms'] >= 0.0

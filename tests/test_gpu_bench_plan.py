@@ -69,11 +69,12 @@ def _train_step_checked(args, tag, expect, bn=False, every=1):
 def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32():
     """BASELINE configs[1]: 79 convolutions -> 70 forward launches (9 merged pairs), their dgrads (stride-2 ones as one fused launch, 1x1
     Conv+BatchNorm+SiLU ones with the apply fold) and 79 weight-gradient launches"""
-    # ... and every FOURTH BatchNorm launch of that step (36 of 146: the suite's run time; all 146 were green in profiles/r5h_bench16_parity_summary.md)
-    # (forward with its saved / running statistics, backward reduce, backward apply with dgamma /
-    # dbeta and the shortcut's gradient pass-through; plain and split): the other 7.6 GB of the step's traffic
-    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 6, 'myolo_conv_dgrad_bn': 10,
-                                                        'myolo_bn_act_fwd': 8, 'myolo_bn_act_bwd_reduce': 4, 'myolo_bn_act_bwd_apply': 4}, bn=4)
+    # ... and EVERY BatchNorm launch of that step, unsampled (VERDICT r5 item 7; rounds 5's suite evaluated every fourth): forward with its
+    # saved / running statistics, backward reduce, backward apply with dgamma / dbeta and the shortcut's gradient pass-through, plain and
+    # split, and round 6's one-launch form (reduce + barrier + apply): the other 7.6 GB of the step's traffic
+    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 6, 'myolo_conv_dgrad_bn': 15,
+                                                        'myolo_bn_act_fwd': 40, 'myolo_bn_act_bwd_reduce': 20, 'myolo_bn_act_bwd_apply': 18,
+                                                        'myolo_bn_act_bwd_fused': 4}, bn=1)
     fam = ' '.join(sites)
     for k in ('mid::launch', 'midx::launch', 'halo::launch', 'stream::launch', 'launch_conv4', 'wgt::launch'):     # every conv family DESIGN section 3 names
         assert k in fam, (k, sorted(sites))
@@ -82,7 +83,7 @@ def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32()
 def test_every_conv_launch_of_the_yolov5m_lab_share_matches_torch_fp32():
     """BASELINE configs[3]'s per-GPU share: yolov5m + Lab head (ASPP encoder, FFM), batch 8, fp16: the 48 / 96 / 192 / 384 / 768-channel
     layers and the dilated 3x3 of ASPP at their real tile counts"""
-    _train_step_checked(_args(cfg='yolov5m_city_seg_lab.yaml', batch=8), 'mlab8', {'myolo_conv': 60, 'myolo_conv_wgrad': 40}, every=2)    # (every second launch: run time)
+    _train_step_checked(_args(cfg='yolov5m_city_seg_lab.yaml', batch=8), 'mlab8', {'myolo_conv': 110, 'myolo_conv_wgrad': 75})       # (every launch: VERDICT r5 item 7)
 
 
 @pytest.mark.parametrize('size', [(1024, 2048), (512, 1024)], ids=['2048x1024', '1024x512'])

@@ -37,7 +37,7 @@ def _run(cin, cout, k, s, d, B, H, W, var, stats=True, accumulate=False, res=Fal
     if accumulate:
         ref = ref + y0.float()
     xd, yd, rd = x.to(DEV), y0.to(DEV).clone(), r0.to(DEV)
-    cin_pad, cout_pad = E.rup(cin, 32), E.rup(cout, 32)
+    cin_pad, cout_pad = E.conv_pad(cin, 32, torch.float16), E.conv_pad(cout, 32, torch.float16)
     wp = torch.zeros(cout_pad, k * k, cin_pad, device=DEV, dtype=torch.float16)
     L.check(lib.myolo_pack_weight(L.ptr(w.float().to(DEV)), L.F32, cout, cin, k, k, L.ptr(wp), L.F16, cout_pad, cin_pad, 0, None, L.stream_ptr()))
     st = torch.zeros(L.STAT_COPIES * 2 * cout, device=DEV)
@@ -83,6 +83,31 @@ SHAPES = [
     (64, 64, 1, 1, 1, 2, 64, 128),           # ONE K step: prologue + drain of a ring that is longer than the loop
     (64, 128, 1, 1, 1, 1, 40, 56),
 ]
+
+
+RAGGED_SHAPES = [
+    # round 6: yolov5m's 48 / 96-channel layers (models/yolov5m_city_seg.yaml) -- the last 128-byte K step holds 32 or 48 channels, the rest of
+    # it comes from the zero page; 96 output channels are an N tile of 128 with 32 masked columns
+    (96, 96, 1, 1, 1, 2, 32, 64),            # 2.cv3-like 1x1: ONE ragged K step per tap
+    (96, 96, 3, 1, 1, 2, 32, 64),            # 4.m.*.cv2: 3x3 96 -> 96, K = 9 x (64 + 32)
+    (48, 96, 3, 2, 1, 2, 64, 128),           # 1.conv: 3x3 stride 2, 48 -> 96
+    (96, 192, 3, 2, 1, 1, 64, 64),           # 3.conv
+    (48, 48, 1, 1, 1, 2, 64, 128),           # 2.m.*.cv1: one K step of 48 channels
+    (304, 256, 1, 1, 1, 2, 32, 64),          # Lab head FFM: 4 x 64 + 48
+    (96, 48, 1, 1, 1, 1, 31, 37),            # ragged pixels AND channels
+]
+
+
+@pytest.mark.parametrize('var', [0, 1, 2, 3, 5])
+@pytest.mark.parametrize('shape', RAGGED_SHAPES, ids=[f'{s[0]}-{s[1]}k{s[2]}s{s[3]}d{s[4]}_{s[5]}x{s[6]}x{s[7]}' for s in RAGGED_SHAPES])
+def test_conv_mid_ragged_last_k_chunk(shape, var):
+    from multiyolov5_amd import _lib as L
+    L.lib().myolo_trace_start(1)
+    _run(*shape, var=var)
+    sites = L.launch_trace()
+    L.lib().myolo_trace_start(0)
+    assert any('mid::launch' in s for s in sites), sites          # really conv_mid (not a fallback to conv_igemm / conv_stream)
+    _run(*shape, var=var, stats=False, accumulate=True, res=True, seed=3)
 
 
 @pytest.mark.parametrize('var', [0, 1, 2, 3, 4, 5])

@@ -31,7 +31,7 @@ def _gate(C_, B, H, W, th, cout):
     return C_ // bn == 1 and B * ((W + 15) // 16) * ((H + 3) // 4) >= 96
 
 
-def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0, expect_fused=None):
+def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0, expect_fused=None, inplace=False):
     from multiyolov5_amd import _lib as L, engine as E
     lib = L.lib()
     cout = cout or C_
@@ -55,6 +55,11 @@ def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0,
     yb = torch.full((B, H, W, cout + pad_c), 7.0, dtype=torch.float16, device=DEV)
     tb = torch.full((B, H, W, C_), 3.0, dtype=torch.float16, device=DEV)
     yb2, tb2 = yb.clone(), tb.clone()
+    xb2 = xb
+    if inplace:        # an in-place Bottleneck: the output IS the input buffer (and the shortcut).  Harmless as two launches, a race in one
+        assert cout == C_
+        xb, xb2 = xb.clone(), xb.clone()
+        yb, yb2 = xb, xb2
 
     def pack(w, co, k):
         wp = torch.zeros(E.rup(co, 32), k * k, E.rup(C_, 32), device=DEV, dtype=torch.float16)
@@ -63,7 +68,8 @@ def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0,
     wp1, wp2 = pack(w1, C_, 1), pack(w2, cout, k2)
     k1d = [v.to(DEV).contiguous() for v in (sc1, sh1, sc2, sh2)]
 
-    def descs(yt, tt):
+    def descs(yt, tt, xb=None):
+        xb = xb_fused if xb is None else xb
         a, b = L.ConvDesc(), L.ConvDesc()
         a.x, a.y, a.w = _view(L, xb, pad_c // 2, C_), _view(L, tt, 0, C_), wp1.data_ptr()
         a.cin_pad, a.cout_pad, a.wtaps, a.ntaps, a.stride, a.up_shift = wp1.shape[2], wp1.shape[0], 1, 1, 1, 0
@@ -75,6 +81,7 @@ def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0,
         b.scale, b.shift, b.act = k1d[2].data_ptr(), k1d[3].data_ptr(), L.ACT_SILU
         b.res = _view(L, xb, pad_c // 2, cout) if res else E.null_tensor()
         return a, b
+    xb_fused = xb
     a, b = descs(yb, tb)
     lib.myolo_set_option(b'pair_th', th)
     lib.myolo_trace_start(1)
@@ -89,7 +96,7 @@ def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0,
     if expect_fused is None:
         expect_fused = _gate(C_, B, H, W, th, cout)
     assert fused == expect_fused, (sorted(sites), expect_fused)
-    a2, b2 = descs(yb2, tb2)
+    a2, b2 = descs(yb2, tb2, xb2)
     L.check(lib.myolo_conv(C.byref(a2), L.stream_ptr()))
     L.check(lib.myolo_conv(C.byref(b2), L.stream_ptr()))
     torch.cuda.synchronize()
@@ -99,7 +106,7 @@ def _run(C_, B, H, W, th, res=True, cout=None, sliced=False, k2=3, d2=1, seed=0,
     check(tag + '/vs_torch', yb[..., lo:lo + cout], ref, 2e-3, collect=bad)
     check(tag + '/vs_two_launches', yb[..., lo:lo + cout], yb2[..., lo:lo + cout], 1e-3, collect=bad)
     check(tag + '/two_launches_vs_torch', yb2[..., lo:lo + cout], ref, 2e-3, collect=bad)
-    if sliced:                                 # the neighbours of the output slice are untouched
+    if sliced and not inplace:                 # the neighbours of the output slice are untouched
         assert bool((yb[..., :lo] == 7.0).all()) and bool((yb[..., lo + cout:] == 7.0).all())
     if fused:                                  # (myolo.h: a->y is NOT written by the fused kernel)
         assert bool((tb == 3.0).all())
@@ -140,6 +147,10 @@ def test_pairs_that_do_not_qualify_run_as_two_launches():
     _run(32, 1, 64, 96, 0, expect_fused=False)                      # 32 channels (2.m.0)
     _run(64, 1, 32, 48, 0, d2=2, res=False, expect_fused=False)     # dilated 3x3
     _run(64, 1, 32, 48, 0, k2=1, res=False, expect_fused=False)     # 1x1 -> 1x1
+    # the output aliases the input halo / the shortcut (in-place Bottleneck): refused even with a forced tile height, and the two
+    # launches it falls back to give the reference's numbers
+    _run(64, 1, 64, 128, 8, inplace=True, expect_fused=False)
+    _run(128, 2, 24, 40, 4, inplace=True, sliced=True, expect_fused=False)
     from multiyolov5_amd import _lib as L
     L.lib().myolo_set_option(b'pair_mode', 0)
     try:

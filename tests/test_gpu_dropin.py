@@ -199,11 +199,12 @@ def test_gradient_accumulation_over_two_backward_passes_equals_the_sum(monkeypat
     """train.py:364-401: a detection backward and a segmentation backward accumulate into `.grad` before one optimizer step.  The
     second backward adds its flat gradient buffer into the first one's in ONE kernel (runtime._accumulate_in_place) -- same values
     as autograd's per-parameter accumulation, and any `.grad` the caller replaced switches back to that path"""
-    from multiyolov5_amd import runtime as R
+    from multiyolov5_amd import engine as E, runtime as R
     from multiyolov5_amd.models.yolo import Model
     from multiyolov5_amd.utils.loss import ComputeLoss, SegmentationLosses
     from oracle import loss_ref, synth
     from tests.util import CFG, TAGS, synth_sd
+    monkeypatch.setattr(E, 'TINY_CONV', False)           # (ADVICE r5: accumulation == sum is an exactness statement; the tiny launches' arrival-order noise stays out)
     torch.manual_seed(0)
     m = Model(os.path.join(CFG, TAGS['s_psp']))
     m.load_state_dict(synth_sd('s_psp'), strict=True)
@@ -232,9 +233,8 @@ def test_gradient_accumulation_over_two_backward_passes_equals_the_sum(monkeypat
     slow = two_passes()
     assert calls == [False, False]
     for a, b in zip(fast, slow):
-        # two runs of the same step: bit-equal kernels except for the arrival order of the statistics atomics (the one-workgroup `tiny`
-        # launches that run most of this 64x128-image plan since round 5: measured 7e-5; 1e-5 before)
-        assert float((a - b).abs().max()) <= 5e-4 * (float(b.abs().max()) + 1e-12)
+        # two runs of the same step: bit-equal kernels except for the arrival order of the statistics atomics (tiny launches off: 1e-5)
+        assert float((a - b).abs().max()) <= 2e-5 * (float(b.abs().max()) + 1e-12)
     # a replaced .grad (not a view of the flat buffer) falls back to autograd's accumulation
     monkeypatch.setattr(R, 'FLAT_ACCUMULATE', True)
     for p in m.parameters():
@@ -248,4 +248,4 @@ def test_gradient_accumulation_over_two_backward_passes_equals_the_sum(monkeypat
     (sl(seg, mask) * 2).backward()
     assert calls == [False]
     for a, p in zip(slow, m.parameters()):
-        assert float((a - p.grad).abs().max()) <= 5e-4 * (float(a.abs().max()) + 1e-12)      # (two runs: see above)
+        assert float((a - p.grad).abs().max()) <= 2e-5 * (float(a.abs().max()) + 1e-12)      # (two runs: see above)

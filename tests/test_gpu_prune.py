@@ -49,6 +49,7 @@ def grads_of(m):
 def run_sequence(tag, seq, prune, monkeypatch, dtype=torch.float32, staged=None):
     from multiyolov5_amd import engine as E, runtime as R
     monkeypatch.setattr(E, 'PRUNE_BWD', prune)
+    monkeypatch.setattr(E, 'TINY_CONV', False)           # (pruned == full is an exactness statement; the tiny launches' LDS-atomics noise stays out)
     if staged is not None:
         monkeypatch.setattr(R, 'STAGED_BWD', staged)
     m, sd, hyp = build(tag)
@@ -79,7 +80,7 @@ def test_pruned_backward_equals_the_full_list_in_any_order(tag, monkeypatch):
     assert len({id(v) for v in plan_b.__dict__.get('_nprog_bwd', {}).values() if v}) == 1
     bad = []
     for i, ((la, ga), (lb, gb)) in enumerate(zip(a, b)):
-        assert abs(la - lb) <= 2e-5 * max(1.0, abs(lb))       # (two runs: statistics atomics in arrival order; 1.07e-6 measured with the tiny launches)
+        assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb))       # (two runs: statistics atomics in arrival order; tiny launches off)
         for k in ga:
             if gb[k].abs().max() == 0:
                 assert ga[k].abs().max() == 0, f'step {i} {seq[i]}: {k} must stay zero'
