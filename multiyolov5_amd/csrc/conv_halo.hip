@@ -363,8 +363,8 @@ int myolo_conv_halo_set(const char* name, int value) {
 int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   using namespace halo;
   *bnb_done = 0;
-  if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
-  if (g_halo_min_tiles < 0) g_halo_min_tiles = getenv("MYOLO_HALO_MIN_TILES") ? atoi(getenv("MYOLO_HALO_MIN_TILES")) : 512;
+  if (g_halo_off < 0) g_halo_off = 0;                     // (myolo_set_option("halo_off" / "halo_min_tiles"): tests and sweeps)
+  if (g_halo_min_tiles < 0) g_halo_min_tiles = 512;
   if (g_halo_off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
   if (d->ntaps < 2 || d->stride != 1 || d->up_shift != 0 || d->cin_pad % KCH) return -1;
   if (d->x.h != d->y.h || d->x.w != d->y.w) return -1;
@@ -377,7 +377,7 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   const int K = d->ntaps * d->cin_pad;
   // K > 832 (128-channel 3x3 and up): only a 32-wide N tile of the panel fits beside the halo buffers, the input would be staged
   // Cout/32 times and the LDS-tiled kernel measured faster (27 vs 31 us at 128->128, 32x64)
-  static const int max_k = getenv("MYOLO_HALO_MAX_K") ? atoi(getenv("MYOLO_HALO_MAX_K")) : 832;
+  constexpr int max_k = 832;
   if (K > max_k) return -1;
   const int pitch = halo_panel_pitch(K);
   const int64_t px_total = (int64_t)d->y.n * d->y.h * d->y.w;
@@ -450,8 +450,8 @@ int myolo_conv_halo_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
 static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream, int* bnb_done, myolo_tensor* full) {
   using namespace halo;
   *bnb_done = 0;
-  if (g_halo_off < 0) g_halo_off = getenv("MYOLO_NO_HALO") != nullptr;
-  static const int s2_off = getenv("MYOLO_NO_HALO_S2") != nullptr;
+  if (g_halo_off < 0) g_halo_off = 0;
+  constexpr int s2_off = 0;
   if (g_halo_off || s2_off) return -1;
   const myolo_conv_desc* d0 = d4[0];
   if (!d0 || d0->x.dtype != MYOLO_F16 || d0->y.dtype != MYOLO_F16 || (d0->y.c & 3) || d0->cin_pad % KCH) return -1;
@@ -486,7 +486,7 @@ static int halo_s2_try(const myolo_conv_desc* const* d4, void* stream, int* bnb_
   const int K = d0->wtaps * d0->cin_pad;
   // K = 2304 (256 gradient channels): only a 32-wide N tile of the panel fits, dy is staged Cout/32 times and four LDS-tiled launches
   // measured faster (133 vs 98 us at 16x32x64x256 -> 128, 81 vs 76 us at 16x16x32x256 -> 256; K = 1152: 86 vs 104 us the other way)
-  static const int s2_max_k = getenv("MYOLO_HALO_S2_MAX_K") ? atoi(getenv("MYOLO_HALO_S2_MAX_K")) : 1152;
+  constexpr int s2_max_k = 1152;
   if (K > s2_max_k) return -1;
   const int pitch = halo_panel_pitch(K);
   const int xbuf = hh * hw * 64;

@@ -476,7 +476,7 @@ extern "C" int myolo_conv(const myolo_conv_desc* d, void* stream) {
   //   * in between 64-row tiles (twice the workgroups of the 128-row ones on small maps), beyond it 128-row tiles.
   int bn = (d->cout_pad % 128 == 0) ? 128 : ((d->cout_pad % 64 == 0) ? 64 : 32);
   // 96-wide N tile (fp16): the 96-channel layers of yolov5m are ONE N tile instead of three 32-wide ones that each re-stage the input
-  static const int no96 = getenv("MYOLO_NO_BN96") != nullptr;
+  constexpr int no96 = 0;
   if (bn == 32 && d->cout_pad % 96 == 0 && dt == MYOLO_F16 && !no96) bn = 96;
   const int64_t mt64 = (M + 63) / 64;
   if (bn == 128 && mt64 * (d->cout_pad / 128) <= 256) bn = 64;

@@ -506,30 +506,14 @@ int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) { 
 static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf) {
   using namespace mid;
   *bnb_done = 0;
-  {   // bisecting aid: MYOLO_MID_SKIP bits exclude call classes (1 statistics, 2 no statistics, 4 accumulate, 8 residual, 16 k x k, 32 1 x 1,
-      // 64 strided output view, 128 channel-slice input, 256 bnb)
-    static const int skip = getenv("MYOLO_MID_SKIP") ? atoi(getenv("MYOLO_MID_SKIP")) : 0;
-    if (skip) {
-      if ((skip & 1) && d->stats) return -1;
-      if ((skip & 2) && !d->stats) return -1;
-      if ((skip & 4) && d->accumulate) return -1;
-      if ((skip & 8) && d->res.ptr) return -1;
-      if ((skip & 16) && d->ntaps > 1) return -1;
-      if ((skip & 32) && d->ntaps == 1) return -1;
-      if ((skip & 64) && d->y.sw != d->y.c) return -1;
-      if ((skip & 128) && d->x.sw != d->x.c) return -1;
-      if ((skip & 256) && d->bnb && d->nbnb > 0) return -1;
-    }
-  }
   if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->up_shift != 0) return -1;
   const bool epi = d->scale || d->shift || d->act != MYOLO_ACT_NONE;
-  static const int no_epi = getenv("MYOLO_MID_NO_EPI") != nullptr;
-  if (epi && (d->stats || (d->bnb && d->nbnb > 0) || no_epi || bf)) return -1;          // (statistics are taken from the raw accumulators only)
+  if (epi && (d->stats || (d->bnb && d->nbnb > 0) || bf)) return -1;          // (statistics are taken from the raw accumulators only)
   if (bf) {        // BatchNorm apply in the operand path: 1x1 stride-1 dgrad over dense same-shaped gout / y / dy, <= 512 channels
     auto same = [](const myolo_tensor& a, const myolo_tensor& b) { return a.n == b.n && a.h == b.h && a.w == b.w && a.c == b.c && a.dtype == b.dtype; };
     // (every N tile repeats the transform of its pixel rows: beyond 256 layer channels the two-launch form is faster -- K 512 -> N 512
     //  @16x32x16: 22.5 vs 21.4 us, -> N 1024: 38.1 vs 30.9; profiles/r4_dgrad_bn_ubench.txt)
-    static const int maxk = getenv("MYOLO_BN_APPLY_FOLD_MAXK") ? atoi(getenv("MYOLO_BN_APPLY_FOLD_MAXK")) : 256;
+    constexpr int maxk = 256;        // (round 5 sweep: 128 / 512 measured -0.3 / +0.4 %)
     if (d->ntaps != 1 || d->stride != 1 || d->tap_dy[0] != 0 || d->tap_dx[0] != 0 || d->stats || d->cin_pad > 512 || d->cin_pad > maxk ||
         d->x.c != d->cin_pad) return -1;
     if (!bf->y.ptr || !bf->dy.ptr || !same(d->x, bf->y) || !same(d->x, bf->dy) || d->x.h != d->y.h || d->x.w != d->y.w) return -1;
@@ -582,8 +566,7 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   int var = g_mid_var;
   // round 5, yolov5m's widths (models/yolov5m_city_seg.yaml: 192 / 384 channels): a 192-wide N tile instead of three 64-wide ones that each
   // stage the same pixel rows again (37 + 23 launches of the yolov5m + Lab step ran <128, 64> tiles); only with at least one tile per CU
-  static const int no192 = getenv("MYOLO_MID_NO_BN192") != nullptr;
-  const bool wide192 = !bf && !no192 && (d->cout_pad == 192 || d->cout_pad == 384 || d->cout_pad == 576) &&
+  const bool wide192 = !bf && (d->cout_pad == 192 || d->cout_pad == 384 || d->cout_pad == 576) &&
                        ((M + 127) / 128) * (d->cout_pad / 192) >= 256;
   if (var == 0 && wide192) var = 6;
   if (var == 6 && (d->cout_pad % 192 || bf)) var = 0;
@@ -602,8 +585,7 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   hipStream_t st = (hipStream_t)stream;
   const int bn_eff = var == 2 ? 64 : (var == 6 ? 192 : 128), ntc = d->cout_pad / bn_eff;
   // the BatchNorm-backward sums of the layer(s) below ride in the epilogue when every segment is a whole number of N tiles
-  static const int no_fold = getenv("MYOLO_MID_NO_BNB") != nullptr;
-  const bool fold = d->bnb && d->nbnb > 0 && d->nbnb <= MYOLO_MAX_BNB && !d->stats && !no_fold && !k.dbg && bnb_aligned(d, bn_eff);
+  const bool fold = d->bnb && d->nbnb > 0 && d->nbnb <= MYOLO_MAX_BNB && !d->stats && !k.dbg && bnb_aligned(d, bn_eff);
   k.bnb.n = 0;
   if (fold) { bnb_fill(&k.bnb, d); *bnb_done = 1; }
   if (bf) {

@@ -197,9 +197,9 @@ int myolo_conv_small_set(const char* name, int value) {
 // returns -1 when the layer does not qualify, else a hipError_t / 0
 int myolo_conv_small_try(const myolo_conv_desc* d, void* stream) {
   using namespace small;
-  if (g_small_off < 0) g_small_off = getenv("MYOLO_NO_SMALL") != nullptr;
-  if (g_small_max_tiles < 0) g_small_max_tiles = getenv("MYOLO_SMALL_MAX_TILES") ? atoi(getenv("MYOLO_SMALL_MAX_TILES")) : 128;   // (round 4: 256 -> 128, conv_mid takes the layers in between: 912 -> 955 FPS at 2048x1024, 1325 -> 1406 at 1024x512)
-  if (g_small_raw < 0) g_small_raw = getenv("MYOLO_SMALL_RAW") ? atoi(getenv("MYOLO_SMALL_RAW")) : 0;
+  if (g_small_off < 0) g_small_off = 0;                   // (myolo_set_option("small_off" / "small_max_tiles" / "small_raw"): tests and sweeps)
+  if (g_small_max_tiles < 0) g_small_max_tiles = 128;   // (round 4: 256 -> 128, conv_mid takes the layers in between: 912 -> 955 FPS at 2048x1024, 1325 -> 1406 at 1024x512)
+  if (g_small_raw < 0) g_small_raw = 0;
   if (g_small_off) return -1;
   if (!g_small_raw && !g_small_force && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE) return -1;
   if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->stats || d->accumulate || (d->bnb && d->nbnb > 0) || (d->y.c & 3) || d->cin_pad % 32)

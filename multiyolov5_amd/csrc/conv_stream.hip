@@ -365,6 +365,7 @@ extern "C" int myolo_set_option(const char* name, int value) {
   if (!strcmp(name, "stream_per_cu")) { g_stream_per_cu = value; return 0; }
   if (!strcmp(name, "nms_dbg")) { g_nms_dbg = value; return 0; }
   if (!strncmp(name, "bn_", 3)) return myolo_bn_set(name, value);
+  if (!strncmp(name, "spp_", 4)) return myolo_pool_set(name, value);
   if (!strncmp(name, "igemm_", 6)) return myolo_conv_igemm_set(name, value);
   if (!strncmp(name, "midx_", 5)) return myolo_conv_midx_set(name, value);
   if (!strncmp(name, "pair_", 5)) return myolo_conv_pair_set(name, value);
@@ -376,8 +377,8 @@ extern "C" int myolo_set_option(const char* name, int value) {
 int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done) {
   using namespace stream;
   *bnb_done = 0;
-  if (g_stream_min_tiles < 0) g_stream_min_tiles = getenv("MYOLO_STREAM_MIN_TILES") ? atoi(getenv("MYOLO_STREAM_MIN_TILES")) : 2048;
-  if (g_stream_off < 0) g_stream_off = getenv("MYOLO_NO_STREAM") != nullptr;
+  if (g_stream_min_tiles < 0) g_stream_min_tiles = 2048;   // (myolo_set_option("stream_min_tiles" / "stream_off" / "stream_dbg"): tests and sweeps)
+  if (g_stream_off < 0) g_stream_off = 0;
   const int min_tiles = g_stream_min_tiles;
   const bool off = g_stream_off != 0;
   if (off || d->x.dtype != MYOLO_F16 || d->det_no > 0 || (d->y.c & 3)) return -1;
@@ -387,7 +388,7 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
   int bn = 0;
   // BN = 128 needs > 200 VGPRs with the per-channel statistics: two N tiles instead.  96 (yolov5m: 96 / 192 / 384 / 768 channels)
   // where it means fewer N tiles than 64: every N tile re-streams the activations
-  static const int no96 = getenv("MYOLO_NO_BN96") != nullptr;
+  constexpr int no96 = 0;
   const int cands[3] = {96, 64, 32};
   for (int i = 0; i < 3; ++i) {
     const int b = cands[i];
@@ -431,7 +432,7 @@ int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done)
   k.ydense = dense(k.y_sn, k.y_sh, k.y_sw, k.Ho, k.Wo) && (!k.res || dense(k.r_sn, k.r_sh, k.r_sw, k.Ho, k.Wo));
   k.xdense = d->ntaps == 1 && d->stride == 1 && d->up_shift == 0 && d->tap_dy[0] == 0 && d->tap_dx[0] == 0 &&
              k.Hi == k.Ho && k.Wi == k.Wo && dense(k.x_sn, k.x_sh, k.x_sw, k.Hi, k.Wi);
-  if (g_stream_dbg < 0) g_stream_dbg = getenv("MYOLO_STREAM_DBG") ? atoi(getenv("MYOLO_STREAM_DBG")) : 0;
+  if (g_stream_dbg < 0) g_stream_dbg = 0;
   k.dbg = g_stream_dbg;
   if (k.stats && (k.scale || k.shift || k.act != MYOLO_ACT_NONE)) return -1;   // statistics only with the raw epilogue
   auto span = [](const myolo_tensor& t) -> int64_t {

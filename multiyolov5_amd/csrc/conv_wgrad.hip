@@ -682,7 +682,7 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   const int out_tiles = k.tiles_co * k.tiles_ci * (fused ? 1 : k.ntaps);
   int ks = d->ksplit;
   if (ks <= 0) {
-    static const int tgt_fused = getenv("MYOLO_WGRAD_WG_FUSED") ? atoi(getenv("MYOLO_WGRAD_WG_FUSED")) : 128;
+    constexpr int tgt_fused = 128;
     static const int tgt_tap = getenv("MYOLO_WGRAD_WG") ? atoi(getenv("MYOLO_WGRAD_WG")) : 256;
     // Few, long-lived workgroups: these kernels run on the side stream BESIDE the dgrad / BatchNorm chain, so they need not fill the
     // chip, and every extra split costs a [taps][64][64] fp32 partial tile (written + re-read, or 4096 atomics per tap): measured
@@ -704,9 +704,9 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   }
   // Focus-sized 3x3 (<= 16 -> <= 32 channels): compact [9][32][16] slices, waves split the pixels (wgrad_fused_small_kernel)
   const bool small = fused && !d->db && k.cout_w <= 32 && k.cin_w <= 16 && d->ws && (((uintptr_t)d->ws) & 15) == 0 &&
-                     d->ws_bytes >= (int64_t)2 * 9 * 32 * 16 * (int64_t)sizeof(float) && !getenv("MYOLO_WGRAD_NO_SMALL");
+                     d->ws_bytes >= (int64_t)2 * 9 * 32 * 16 * (int64_t)sizeof(float);
   if (small) {
-    static const int small_ks = getenv("MYOLO_WGRAD_SMALL_KS") ? atoi(getenv("MYOLO_WGRAD_SMALL_KS")) : 768;
+    constexpr int small_ks = 768;
     ks = d->ksplit > 0 ? d->ksplit : small_ks;                // three workgroups per CU (halo kernel, 256x512 map: 256 -> 66 us, 512 -> 52, 768 -> 50, 1024 -> 62)
     const int max_ks = (int)((M + 4 * KPS - 1) / (4 * KPS));
     if (ks > max_ks) ks = max_ks;
@@ -720,13 +720,13 @@ extern "C" int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream) {
   pps = (pps + kstep - 1) / kstep * kstep;
   ks = (int)((M + pps - 1) / pps);
   k.ksplit = ks; k.pix_per_split = pps;
-  static const int dbg = getenv("MYOLO_WGRAD_DBG") ? atoi(getenv("MYOLO_WGRAD_DBG")) : 0;
+  constexpr int dbg = 0;
   k.dbg = dbg;
   hipStream_t st = (hipStream_t)stream;
   if (small) {
     bool tiles = k.stride == 1 && k.up == 0 && k.Hi == k.Ho && k.Wi == k.Wo && k.Ho % FTH == 0 && k.Wo % FTW == 0;
     for (int t = 0; t < 9; ++t) tiles = tiles && k.tap_dy[t] >= -1 && k.tap_dy[t] <= 1 && k.tap_dx[t] >= -1 && k.tap_dx[t] <= 1;
-    static const int no_tiles = getenv("MYOLO_WGRAD_NO_SMALL_HALO") != nullptr;
+    constexpr int no_tiles = 0;
     if (tiles && !no_tiles) {                                 // 8 x 16 pixel tiles, one x halo for all taps (wgrad_small_halo_kernel)
       k.sp_tx = k.Wo / FTW; k.sp_ty = k.Ho / FTH;
       const int ntiles = k.N * k.sp_tx * k.sp_ty;

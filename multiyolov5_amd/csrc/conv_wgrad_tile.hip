@@ -473,9 +473,9 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   int th = 0, hh = 0, smem = 0, dbuf = 0, xbuf = 0;
   // (MYOLO_WGRAD_TILE_LDS_KB: a smaller budget leaves LDS for a main-stream workgroup on the same CU -- the weight gradients run BESIDE the
   // dgrad / BatchNorm chain; A/B knob)
-  static const int lds_cap = (getenv("MYOLO_WGRAD_TILE_LDS_KB") ? atoi(getenv("MYOLO_WGRAD_TILE_LDS_KB")) : 144) * 1024;
+  constexpr int lds_cap = 144 * 1024;      // (round 4: 96 / 64 KB measured 7.79 / 7.81 ms against 7.77, 40 KB 10.0)
   if (g_wgt_dma < 0) g_wgt_dma = getenv("MYOLO_WGRAD_TILE_DMA") ? atoi(getenv("MYOLO_WGRAD_TILE_DMA")) : 1;
-  if (g_wgt_nst < 0) g_wgt_nst = getenv("MYOLO_WGRAD_TILE_NST") ? atoi(getenv("MYOLO_WGRAD_TILE_NST")) : 0;
+  if (g_wgt_nst < 0) g_wgt_nst = 0;                     // (myolo_set_option("wgrad_tile_nst" / "_wg" / "_min_tiles"): tests and sweeps)
   int nst = 0;
   if (g_wgt_dma) {
     // LDS-DMA ring: each area rounded up to whole 1 KB pieces; the tallest tile of a 3- and of a 4-stage ring, then the ring that
@@ -534,8 +534,8 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   k.dbg = g_wgt_dbg;
   k.nst = nst; k.dpieces = nst ? dbuf / 1024 : 0; k.xpieces = nst ? xbuf / 1024 : 0; k.stage_bytes = nst ? dbuf + xbuf : 0;
   // split-K over tiles: one workgroup per CU at most (the buffers take > 80 KB), at least ~6 tiles per workgroup
-  if (g_wgt_wg < 0) g_wgt_wg = getenv("MYOLO_WGRAD_TILE_WG") ? atoi(getenv("MYOLO_WGRAD_TILE_WG")) : 128;
-  if (g_wgt_min_tiles < 0) g_wgt_min_tiles = getenv("MYOLO_WGRAD_TILE_MIN_TILES") ? atoi(getenv("MYOLO_WGRAD_TILE_MIN_TILES")) : 6;
+  if (g_wgt_wg < 0) g_wgt_wg = 128;
+  if (g_wgt_min_tiles < 0) g_wgt_min_tiles = 6;
   const int mt = g_wgt_min_tiles > 0 ? g_wgt_min_tiles : 1;
   const int want = d->wg_hint > 0 ? d->wg_hint : g_wgt_wg;
   int ks = d->ksplit > 0 ? d->ksplit : (want + out_tiles - 1) / out_tiles;

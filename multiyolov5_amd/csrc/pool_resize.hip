@@ -5,6 +5,14 @@
 //   AdaptiveAvgPool2d(k) (common.py:521-524,214)                               fwd / bwd
 //   FFM gate feat*att+feat (common.py:228-229)                                 fwd / bwd
 #include "myolo_dev.h"
+#include <string.h>
+
+// myolo_set_option("spp_naive", 1): the per-output-vector SPP kernels (what planes too large for the LDS take) for every map (tests)
+static int g_spp_naive = 0;
+int myolo_pool_set(const char* name, int value) {
+  if (!strcmp(name, "spp_naive")) { g_spp_naive = value; return 0; }
+  return MYOLO_EINVAL;
+}
 #include <stdlib.h>
 
 namespace {
@@ -1191,7 +1199,7 @@ extern "C" int myolo_spp_pool_fwd(const myolo_tensor* x, const myolo_tensor* o5,
   while (need(band) > 150 * 1024 && band > 4) band = (band + 1) / 2;
   nb = (x->h + band - 1) / band;
   const size_t smem = need(band);
-  if (smem <= 150 * 1024 && !getenv("MYOLO_SPP_NAIVE")) {
+  if (smem <= 150 * 1024 && !g_spp_naive) {
     const dim3 grid(blocks, nb);
     if (x->dtype == MYOLO_F16) {
       if (idx) { auto kern = spp_fwd_plane_kernel<half_t, true>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
@@ -1221,7 +1229,7 @@ extern "C" int myolo_spp_pool_bwd(const myolo_tensor* g5, const myolo_tensor* g9
     return MYOLO_EINVAL;
   const int HW = gx->h * gx->w;
   const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
-  if ((size_t)HW * seg * sizeof(float) <= SPP_PLANE_LDS && !getenv("MYOLO_SPP_NAIVE")) {
+  if ((size_t)HW * seg * sizeof(float) <= SPP_PLANE_LDS && !g_spp_naive) {
     DISPATCH(gx->dtype, spp_bwd_plane_kernel, gx->n * (gx->c / seg), 256, (size_t)HW * seg * sizeof(float), (hipStream_t)stream,
              *g5, *g9, *g13, idx, *gx, accumulate);
     return 0;

@@ -393,7 +393,7 @@ extern "C" int myolo_seg_upsample_fwd(const myolo_tensor* low, void* out, int ou
   if (!low || !low->ptr || !out || H < 1 || W < 1) return MYOLO_EINVAL;
   Strided4 o{out, sn, sc, sh, sw, out_dtype};
   const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
-  if (!getenv("MYOLO_NO_FAST_UPF") && out_dtype == low->dtype && dense_cl(out, out_dtype, low->c, H, W, sn, sc, sh, sw) && (H > low->h || W > low->w)) {
+  if (out_dtype == low->dtype && dense_cl(out, out_dtype, low->c, H, W, sn, sc, sh, sw) && (H > low->h || W > low->w)) {
     const int64_t blocks = (int64_t)low->n * H * ((W + STRIP - 1) / STRIP);
     if (out_dtype == MYOLO_F16)
       hipLaunchKernelGGL(seg_up_fwd_cl_kernel<half_t>, dim3((int)blocks), dim3(STRIP), 0, (hipStream_t)stream, *low, (half_t*)out, H, W, sy, sx);
@@ -412,7 +412,7 @@ extern "C" int myolo_seg_upsample_bwd(const void* g, int g_dtype, int H, int W, 
   if (!glow || !glow->ptr || !g) return MYOLO_EINVAL;
   Strided4 gg{const_cast<void*>(g), sn, sc, sh, sw, g_dtype};
   const float sy = H > 1 ? (float)(glow->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(glow->w - 1) / (float)(W - 1) : 0.f;
-  if (!getenv("MYOLO_NO_FAST_UPB") && g_dtype == glow->dtype && dense_cl(g, g_dtype, glow->c, H, W, sn, sc, sh, sw) && H >= 2 * glow->h && W >= 2 * glow->w &&
+  if (g_dtype == glow->dtype && dense_cl(g, g_dtype, glow->c, H, W, sn, sc, sh, sw) && H >= 2 * glow->h && W >= 2 * glow->w &&
       W <= 8 * glow->w) {
     const int es = g_dtype == MYOLO_F16 ? 2 : 4;
     int gcd = 16, t = glow->c * es;

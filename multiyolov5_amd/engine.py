@@ -19,17 +19,17 @@ from ._lib import Tensor as CT
 # MYOLO_GRAPH_TRAIN=1: training launch lists are replayed as hipGraphs instead of enqueued call by call (see Plan.run_fwd / run_bwd).
 # Opt-in: the step is bound by the main stream'''s kernel time, not by the host (measured r2: eager 10.48 ms, graphs 10.59 ms per step)
 GRAPH_TRAIN = os.environ.get('MYOLO_GRAPH_TRAIN', '0') != '0'
-PACK_TILED = os.environ.get('MYOLO_PACK_TILED', '1') != '0'        # per-forward weight repack through LDS tiles (coalesced OIHW reads)
+PACK_TILED = True            # (module attribute, no environment switch since round 6: measured 84 -> 62 us, round 3) per-forward weight repack through LDS tiles (coalesced OIHW reads)
 LAZY_SEG = os.environ.get('MYOLO_LAZY_SEG', '1') != '0'            # training: materialise the x8-upsampled logits only on demand
-LAZY_SEG_EVAL = os.environ.get('MYOLO_LAZY_SEG_EVAL', '1') != '0'  # eval: same (detect.py's resize + argmax reads the low-resolution logits)
-EVAL_BRANCH = os.environ.get('MYOLO_EVAL_BRANCH', '1') != '0'      # eval: the segmentation head runs on the side stream beside neck + Detect
-BWD_SEGMENTS = int(os.environ.get('MYOLO_BWD_SEGMENTS', '16'))
+LAZY_SEG_EVAL = True         # eval: same (detect.py's resize + argmax reads the low-resolution logits)
+EVAL_BRANCH = True           # eval: the segmentation head runs on the side stream beside neck + Detect
+BWD_SEGMENTS = 16
 # 'seg': the backward is BWD_SEGMENTS pairs of single-stream graphs chained by events between launches; 'fork': ONE graph whose capture
 # forks the weight-gradient stream per launch exactly like the eager loop (finer overlap; not used with a GradReducer: RCCL stays eager)
-GRAPH_BWD = os.environ.get('MYOLO_GRAPH_BWD', 'seg')
-WGRAD_WG = int(os.environ.get('MYOLO_WGRAD_WG_HINT', '0'))                 # 0: library default (128)
-WGRAD_WG_TAIL = int(os.environ.get('MYOLO_WGRAD_WG_TAIL', '0'))
-WGRAD_TAIL_FRAC = float(os.environ.get('MYOLO_WGRAD_TAIL_FRAC', '0.15'))
+GRAPH_BWD = 'seg'            # ('fork': per-launch cross-stream forks inside one graph: 12.1 vs 10.5 ms, round 2)
+WGRAD_WG = 0                 # 0: library default (128)
+WGRAD_WG_TAIL = 0
+WGRAD_TAIL_FRAC = 0.15
 # round 4: the BatchNorm-backward apply pass of a 1x1 stride-1 Conv+BatchNorm layer rides in the operand path of the layer's own dgrad
 # (myolo_conv_dgrad_bn, csrc/conv_mid.hip): one launch instead of two, dy still written for the weight gradient.  =0: the two-launch form
 BN_APPLY_FOLD = os.environ.get('MYOLO_BN_APPLY_FOLD', '1') != '0'
@@ -57,6 +57,8 @@ KC = {torch.float16: 32, torch.float32: 16}
 # 64 in K and in N, so that conv_mid's 128-byte K steps / 64-wide N tiles take the layer (ragged last chunk: the activation lanes past the
 # tensor's channels fetch the zero page); 0: the round-5 padding (multiples of 32: conv_igemm's 96-wide tile / conv_stream run those layers)
 MID_RAGGED = os.environ.get('MYOLO_MID_RAGGED', '1') != '0'
+BN_STATS_IN_DGRAD = True            # fold bn_act_bwd_reduce into the dgrad that completes the layer's output gradient ...
+BN_STATS_MAX_ELEMS = 4 << 20        # ... for maps up to this many elements (round 5 re-measured 9 M / 17 M: +0.2 / +1.1 %)
 
 
 def conv_pad(c, m, dt):
@@ -751,7 +753,7 @@ class BilinearOp(SimpleOp):
 
     def _group_fused(self, plan, training=True):
         g = self.group
-        if g is None or len(g) < 2 or len(g) > 4 or os.environ.get('MYOLO_NO_PYR_FUSE', '0') == '1':
+        if g is None or len(g) < 2 or len(g) > 4 :
             return False
         d0 = g[0].dst
         seg = SEG[plan.dtype]
@@ -825,7 +827,7 @@ class AvgPoolOp(SimpleOp):
     def _fwd_multi(self, plan):
         """PyramidPooling: the pools of one map as ONE pass over it (myolo_adaptive_avgpool_fwd_multi) -- the conditions of that entry point"""
         g = self.group if self.group is not None else [self]            # (a lone pool -- FFM's global average -- takes the same kernel)
-        if len(g) > 4 or os.environ.get('MYOLO_NO_AAP_MULTI', '0') == '1':
+        if len(g) > 4:
             return False
         s0, seg = g[0].src, SEG[plan.dtype]
         G = s0.c // seg
@@ -1225,7 +1227,7 @@ class Plan:
         self.det_grads = []
         self.params, self._pgrad = [], {}
         self._pack_jobs, self._pack_call = [], None
-        self.use_side_stream = os.environ.get('MYOLO_NO_SIDE', '0') != '1'
+        self.use_side_stream = True
         self.built = False
 
     # ---- graph construction -------------------------------------------------------------------------
@@ -1448,10 +1450,10 @@ class Plan:
     def _plan_bn_stats(self):
         """fold `bn_act_bwd_reduce` of a Conv+BatchNorm layer into the dgrad launch that writes the LAST contribution to its output
         gradient (the values are final in that launch's epilogue): possible when that last writer is a convolution's dgrad covering
-        the layer's whole channel range, over the same pixels.  MYOLO_BN_STATS_IN_DGRAD=0 keeps the separate reduce launches."""
-        if os.environ.get('MYOLO_BN_STATS_IN_DGRAD', '1') == '0':      # default on: 9.40 -> 9.29 ms on the final build of round 2 (it was neutral,
-            return                                                     # 10.34 vs 10.41 ms, before the chain lost ~70 launches); =0 keeps every reduce launch
-        max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
+        the layer's whole channel range, over the same pixels.  engine.BN_STATS_IN_DGRAD = False keeps the separate reduce launches."""
+        if not BN_STATS_IN_DGRAD:      # default on: 9.40 -> 9.29 ms on the final build of round 2
+            return
+        max_elems = BN_STATS_MAX_ELEMS
         for op in self.ops:
             if not isinstance(op, ConvOp) or op.bn is None or op.det or op.bn2 is not None or op.group:
                 continue

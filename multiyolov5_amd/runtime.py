@@ -81,11 +81,6 @@ class _OutSpec:
         return [_OutSpec.rebuild(s, vals) for s in v]
 
 
-def _os_env_flag(name, default):
-    import os
-    return os.environ.get(name, '1' if default else '0') != '0'
-
-
 class LazySegLogits(torch.Tensor):
     """The training-mode segmentation output `pred[1]` (models/yolo.py:163: the x8 bilinear upsample of the class logits).  The fused
     loss reads the LOW-resolution logits (utils/loss._SegCE) and never needs these 38 bytes per pixel; everything else --
@@ -546,7 +541,7 @@ class PlanStageFn(torch.autograd.Function):
         return (None, None, None, None, *lead, *pg)
 
 
-FLAT_ACCUMULATE = _os_env_flag('MYOLO_FLAT_ACCUMULATE', True)
+FLAT_ACCUMULATE = True
 
 
 def _accumulate_in_place(holder, plan):
@@ -590,12 +585,12 @@ def _accumulate_in_place(holder, plan):
 # MYOLO_GRAPH=0 disables it; any capture failure falls back to the eager launch list.
 import os as _os
 GRAPH_EVAL = _os.environ.get('MYOLO_GRAPH', '1') != '0'
-SPLIT_EVAL = _os.environ.get('MYOLO_SPLIT_EVAL', '1') != '0'      # eval graphs: the side-stream branch is not joined inside the forward
+SPLIT_EVAL = True            # eval graphs: the side-stream branch is not joined inside the forward
 # how the three pieces of a split eval forward are issued (r3k trace: the main queue sat idle ~140 us between graph A's last kernel and
 # graph B's first one although B had been enqueued long before): 'g' = hipGraph replay, 'e' = the native launch program, eagerly
-EVAL_TAIL = _os.environ.get('MYOLO_EVAL_TAIL', 'g')                # graph B (neck tail + Detect, main stream)
-EVAL_HEAD = _os.environ.get('MYOLO_EVAL_HEAD', 'g')                # graph C (segmentation head, side stream)
-EVAL_ORDER = _os.environ.get('MYOLO_EVAL_ORDER', 'cb')             # host order of the two launches behind graph A
+EVAL_TAIL = 'g'              # (round 5 sweep: every other placement measured slower) graph B (neck tail + Detect, main stream)
+EVAL_HEAD = 'g'              # graph C (segmentation head, side stream)
+EVAL_ORDER = 'cb'            # host order of the two launches behind graph A
 
 
 class PlanHolder:

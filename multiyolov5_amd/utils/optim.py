@@ -14,7 +14,7 @@ import torch
 
 from .. import _lib as L
 
-CHUNK = int(os.environ.get('MYOLO_OPTIM_CHUNK', '8192'))     # elements per workgroup (yolov5s: 1109 workgroups; scripts/optim_ubench.py)
+CHUNK = 8192     # elements per workgroup (yolov5s: 1109 workgroups; scripts/optim_ubench.py)
 
 
 class _Table:

@@ -13,7 +13,8 @@ B, H, W = 16, 512, 1024
 m = Model(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'multiyolov5_amd', 'cfg', 'yolov5s_city_seg.yaml')).train()
 names = {id(mod): n for n, mod in m.named_modules()}
 plan = R.PlanHolder(m, [torch.zeros(B, 3, H, W)], ('t', 0), torch.float16, True).plan
-max_elems = int(os.environ.get('MYOLO_BN_STATS_MAX_ELEMS', str(4 << 20)))
+from multiyolov5_amd import engine as _E
+max_elems = _E.BN_STATS_MAX_ELEMS
 rows, tally = [], {}
 for op in plan.ops:
     if not isinstance(op, E.ConvOp) or op.bn is None:

@@ -21,7 +21,7 @@ SHAPES = [
     (64, 64, 1, 1, 1, 64, 128), (128, 128, 1, 1, 1, 64, 128), (256, 128, 1, 1, 1, 64, 128), (384, 64, 1, 1, 1, 64, 128),
     (64, 32, 1, 1, 1, 128, 256), (256, 128, 1, 1, 1, 32, 64), (512, 256, 1, 1, 1, 16, 32), (1024, 512, 1, 1, 1, 16, 32),
 ]
-if 'focus' in sys.argv[1:]:          # the Focus layer's 3x3 (compact kernels of conv_wgrad.hip; MYOLO_WGRAD_NO_SMALL_HALO=1: the per-tap-load one)
+if 'focus' in sys.argv[1:]:          # the Focus layer's 3x3 (compact kernels of conv_wgrad.hip)
     SHAPES = [(16, 32, 3, 1, 1, 256, 512), (16, 32, 3, 1, 1, 64, 128)]
 if 'quick' in sys.argv[1:]:
     SHAPES = SHAPES[:3] + SHAPES[8:10]

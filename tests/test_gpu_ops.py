@@ -163,8 +163,12 @@ def test_block_streaming_kernel(name, training, force_stream_kernel):
 @pytest.mark.parametrize('name', ['spp', 'c3spp'])
 def test_block_spp_large_map_kernels(name, dtype, monkeypatch):
     """maps whose plane does not fit in LDS take the per-output-vector SPP kernels: same parity cases with that path forced"""
-    monkeypatch.setenv('MYOLO_SPP_NAIVE', '1')
-    test_block(name, True, dtype)
+    from multiyolov5_amd import _lib as L
+    L.lib().myolo_set_option(b'spp_naive', 1)
+    try:
+        test_block(name, True, dtype)
+    finally:
+        L.lib().myolo_set_option(b'spp_naive', 0)
 
 
 def test_pyramid_bilinear_bwd_paths_agree():
