@@ -219,6 +219,12 @@ def lib():
             f = getattr(l, name)
             f.restype, f.argtypes = res, args
         _lib = l
+        # MYOLO_SET="name=value,name=value": myolo_set_option pairs applied at load (A/B of the library's run-time options -- tile variants,
+        # thresholds -- from the command line of bench.py; every option keeps its default otherwise)
+        for kv in filter(None, os.environ.get('MYOLO_SET', '').replace('+', ',').split(',')):
+            k, _, v = kv.partition('=')
+            if l.myolo_set_option(k.strip().encode(), int(v)) != 0:
+                raise MyoloError(f'MYOLO_SET: unknown option {k!r}')
     return _lib
 
 

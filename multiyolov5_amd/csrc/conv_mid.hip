@@ -485,12 +485,14 @@ static int g_mid_var = 0;          // 0 auto, 1: 128x128 (8 waves), 2: 128x64 (4
 static int g_mid_dbg = 0;
 static int g_mid_bna_strict = 0;   // tests: myolo_conv_dgrad_bn fails instead of running the two-launch form
 static int g_mid_min_tiles = 192;  // 128x128 tiles below this: 64-pixel tiles (twice the workgroups)
+static int g_mid_bwd_var = 0;      // experiments: tile variant of the launches WITHOUT forward statistics / eval epilogue (= the dgrads of a training step)
 int myolo_conv_mid_set(const char* name, int value) {
   if (!strcmp(name, "mid_mode")) { g_mid_mode = value; return 0; }
   if (!strcmp(name, "mid_var")) { g_mid_var = value; return 0; }
   if (!strcmp(name, "mid_dbg")) { g_mid_dbg = value; return 0; }
   if (!strcmp(name, "mid_bna_strict")) { g_mid_bna_strict = value; return 0; }
   if (!strcmp(name, "mid_min_tiles")) { g_mid_min_tiles = value; return 0; }
+  if (!strcmp(name, "mid_bwd_var")) { g_mid_bwd_var = value; return 0; }
   return MYOLO_EINVAL;
 }
 int myolo_conv_mid_mode() {
@@ -564,6 +566,7 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
   const int bn = d->cout_pad % 128 == 0 ? 128 : 64;
   const int ntile_c = d->cout_pad / bn;
   int var = g_mid_var;
+  if (!var && g_mid_bwd_var && !d->stats && !epi && bn == 128) var = g_mid_bwd_var;
   // round 5, yolov5m's widths (models/yolov5m_city_seg.yaml: 192 / 384 channels): a 192-wide N tile instead of three 64-wide ones that each
   // stage the same pixel rows again (37 + 23 launches of the yolov5m + Lab step ran <128, 64> tiles); only with at least one tile per CU
   const bool wide192 = !bf && (d->cout_pad == 192 || d->cout_pad == 384 || d->cout_pad == 576) &&

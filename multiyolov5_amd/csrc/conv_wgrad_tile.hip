@@ -430,6 +430,7 @@ int launch_nt(const WgT& k, int cof, int cif, int out_tiles, int smem, hipStream
 }  // namespace wgt
 
 static int g_wgt_off = -1;
+static int g_wgt_lds_kb = -1;      // LDS budget of a workgroup (KB)
 static int g_wgt_dma = -1;         // 1: LDS-DMA loaders (wgrad_tile_dma_kernel), 0: the register loaders of round 2
 static int g_wgt_nst = -1;         // ring stages of the LDS-DMA kernel: 3, 4, 0 = whichever keeps more bytes in flight
 static int g_wgt_min_tiles = -1;   // split-K: at least this many tiles per workgroup
@@ -440,6 +441,7 @@ static int g_wgt_dbg = 0;
 //  knob: non-temporal LDS-DMA for 1x1 layers with ONE gradient block -- every byte read once -- is simply what the kernel does)
 int myolo_wgrad_tile_set(const char* name, int value) {
   if (!strcmp(name, "wgrad_tile_off")) { g_wgt_off = value; return 0; }
+  if (!strcmp(name, "wgrad_tile_lds_kb")) { g_wgt_lds_kb = value; return 0; }
   if (!strcmp(name, "wgrad_tile_dma")) { g_wgt_dma = value; return 0; }
   if (!strcmp(name, "wgrad_tile_nst")) { g_wgt_nst = value; return 0; }
   if (!strcmp(name, "wgrad_tile_min_tiles")) { g_wgt_min_tiles = value; return 0; }
@@ -473,7 +475,8 @@ int myolo_wgrad_tile_try(const myolo_wgrad_desc* d, void* stream, int* out_ks, i
   int th = 0, hh = 0, smem = 0, dbuf = 0, xbuf = 0;
   // (MYOLO_WGRAD_TILE_LDS_KB: a smaller budget leaves LDS for a main-stream workgroup on the same CU -- the weight gradients run BESIDE the
   // dgrad / BatchNorm chain; A/B knob)
-  constexpr int lds_cap = 144 * 1024;      // (round 4: 96 / 64 KB measured 7.79 / 7.81 ms against 7.77, 40 KB 10.0)
+  if (g_wgt_lds_kb < 0) g_wgt_lds_kb = 144;            // (round 4: 96 / 64 KB measured 7.79 / 7.81 ms against 7.77, 40 KB 10.0; myolo_set_option("wgrad_tile_lds_kb", n))
+  const int lds_cap = g_wgt_lds_kb * 1024;
   if (g_wgt_dma < 0) g_wgt_dma = getenv("MYOLO_WGRAD_TILE_DMA") ? atoi(getenv("MYOLO_WGRAD_TILE_DMA")) : 1;
   if (g_wgt_nst < 0) g_wgt_nst = 0;                     // (myolo_set_option("wgrad_tile_nst" / "_wg" / "_min_tiles"): tests and sweeps)
   int nst = 0;
