@@ -266,7 +266,7 @@ def conv_kernel_timing(trainer, nsteps=3):
     orig = E.Call.__call__
 
     def timed(self, st):
-        if self.name not in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
+        if self.name not in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_bn_act'):
             return orig(self, st)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

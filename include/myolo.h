@@ -148,6 +148,33 @@ typedef struct myolo_bn_apply_fold {
 } myolo_bn_apply_fold;
 int myolo_conv_dgrad_bn(const myolo_conv_desc* d, const myolo_bn_apply_fold* f, void* stream);
 
+/* Round 6 -- north_star's "fused Conv+BN+SiLU" in TRAINING mode: myolo_conv(d) (raw output + batch statistics, d->stats != NULL) and
+ * myolo_bn_act_fwd_split(d->y, d->stats, ...) in ONE launch: every output tile of the layer is resident with its accumulators held, the
+ * per-channel sums cross a device-wide barrier inside the launch (csrc/myolo_dev.h grid_barrier_xcd), then each workgroup stores the raw
+ * output (the backward needs it) AND out = act((y - mean) * invstd * gamma + beta) (+ res) from the same registers.  Results as the two
+ * launches (reference models/common.py:42-43 `self.act(self.bn(self.conv(x)))`, Bottleneck add common.py:105): y rounded to the storage type
+ * before it is normalised, statistics from the fp32 accumulators, `saved` / running statistics / num_batches_tracked updated.
+ * `barrier`: MYOLO_GRID_BARRIER_BYTES, zeroed once (see myolo_bn_act_bwd_fused).  myolo_conv_bn_act_ok(d): the fused kernel will run (fp16,
+ * conv_mid's layer classes, at most one 8-wave tile per CU: the 32x64 / 16x32 maps at batch 16); otherwise myolo_conv_bn_act runs the two
+ * launches, which is also the definition of the result. */
+typedef struct myolo_bn_fwd_fuse {
+  const float* gamma;            /* first parameter set (channels [0, split->c_split) when split != NULL) */
+  const float* beta;
+  float* running_mean;           /* may be NULL */
+  float* running_var;
+  int64_t* nbt;
+  float* saved;                  /* fp32[2*cout]: mean, invstd */
+  float eps, momentum;
+  int32_t act;
+  int32_t reserved;
+  myolo_tensor res;              /* added AFTER the activation (ptr NULL: none) */
+  myolo_tensor out;
+  const struct myolo_bn_split* split;   /* second parameter set (merged cv1 | cv2; declared below), may be NULL */
+  uint32_t* barrier;
+} myolo_bn_fwd_fuse;
+int myolo_conv_bn_act_ok(const myolo_conv_desc* d);
+int myolo_conv_bn_act(const myolo_conv_desc* d, const myolo_bn_fwd_fuse* f, void* stream);
+
 /* Two convolutions in one launch, eval epilogues (round 5): y_b = conv_b(conv_a(x)) where `a` is a 1x1 stride-1 layer whose output
  * (a->y == b->x, the same view) has NO other reader and `b` a 3x3 stride-1 dilation-1 layer over the same map -- the fused model's
  * Bottleneck (reference models/common.py:95-105 `x + cv2(cv1(x))` with Conv.fuseforward, common.py:45-46; the shortcut is b->res).  Each

@@ -37,6 +37,13 @@ class BnSplit(C.Structure):
                 ('dbeta2', C.c_void_p)]
 
 
+class BnFwdFuse(C.Structure):
+    """myolo_bn_fwd_fuse (include/myolo.h): the BatchNorm + activation half of myolo_conv_bn_act"""
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('nbt', C.c_void_p),
+                ('saved', C.c_void_p), ('eps', C.c_float), ('momentum', C.c_float), ('act', C.c_int32), ('reserved', C.c_int32),
+                ('res', Tensor), ('out', Tensor), ('split', C.POINTER(BnSplit)), ('barrier', C.c_void_p)]
+
+
 class SegSyncDesc(C.Structure):
     _fields_ = [('img', C.c_void_p), ('mask', C.c_void_p), ('H0', C.c_int32), ('W0', C.c_int32), ('flip', C.c_int32), ('ow', C.c_int32),
                 ('oh', C.c_int32), ('ksh', C.c_int32), ('ksv', C.c_int32), ('x1', C.c_int32), ('y1', C.c_int32), ('wc', C.c_int32),
@@ -126,6 +133,8 @@ _PROTOS = {
     'myolo_conv_dgrad_s2': (C.c_int, [C.POINTER(C.POINTER(ConvDesc)), C.c_int, P]),
     'myolo_conv_dgrad_bn': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BnApplyFold), P]),
     'myolo_conv_pair': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), P]),
+    'myolo_conv_bn_act_ok': (C.c_int, [C.POINTER(ConvDesc)]),
+    'myolo_conv_bn_act': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BnFwdFuse), P]),
     'myolo_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), P]),
     'myolo_bn_act_fwd': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, P]),
     'myolo_bn_act_bwd_reduce': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P]),

@@ -50,6 +50,12 @@ struct MidK {
   const char* by; char* bdy; int by_sn, by_sh, by_sw, dy_sn, dy_sh, dy_sw;
   const float* b_saved; const float* b_gamma; const float* b_beta; const float* b_dsum; float* b_dgamma; float* b_dbeta;
   int b_act, b_K; float b_rM;      // channels of the layer (= this conv's K), 1 / pixels
+  // FUS (round 6, myolo_conv_bn_act): training-mode Conv + BatchNorm + activation in one launch.  Every workgroup owns ONE tile and keeps its
+  // accumulators across a device-wide barrier: statistics -> atomics -> barrier -> totals -> scale / shift -> y (raw) and out (activation)
+  char* f_out; const char* f_res; int fo_sn, fo_sh, fo_sw, fr_sn, fr_sh, fr_sw;
+  const float* f_gamma; const float* f_beta; const float* f_gamma2; const float* f_beta2;
+  float* f_rm; float* f_rv; float* f_rm2; float* f_rv2; int64_t* f_nbt; int64_t* f_nbt2; float* f_saved;
+  float f_eps, f_mom; int f_act, f_cs, f_world; unsigned int* f_bar;
   BnbArgs bnb;                     // BNS: BatchNorm-backward statistics of the layer(s) whose output gradient this launch completes
   int dbg;                         // profiling only: 1 no steady-state loads, 2 no fragment reads, 4 no MFMAs, 8 no stores
   int tap_dy[MYOLO_MAX_TAPS], tap_dx[MYOLO_MAX_TAPS];
@@ -69,9 +75,10 @@ __device__ __forceinline__ float row_sum16(float v) {
 // BNS: the stored gradient completes gout of a BatchNorm layer -> its backward sums (myolo_conv_desc.bnb; conv_igemm.hip has the same fold):
 //   dsum0 += dz, dsum1 += dz * xhat with dz = gout * act'(bn(y)) on the final, storage-rounded values, per channel
 // EPI (exclusive with BNS): per-channel scale / shift and activation ahead of the residual add (the eval epilogue of conv_igemm.hip)
-template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false, bool EPI = false, bool BNA = false>
+template <int BM, int BN, int WP, int WC, int NST, bool DBG, bool BNS = false, bool EPI = false, bool BNA = false, bool FUS = false>
 __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   static_assert(!(BNS && EPI) && !(BNA && EPI), "one epilogue table");
+  static_assert(!FUS || (!BNS && !EPI && !BNA && !DBG), "the fused forward is the plain statistics kernel plus its tail");
   constexpr int NT = 64 * WP * WC;
   constexpr int PW = BM / WP, CW = BN / WC;       // wave tile
   constexpr int PF = PW / 16, CF = CW / 16;       // 16 x 16 fragments per wave
@@ -159,6 +166,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     __syncthreads();
   }
 
+  bool fus_done = false;
   for (int tslot = bslot; tslot < p.tiles_per_xcd; tslot += bstride) {
     const int tp = xcd * p.tiles_per_xcd + tslot;
     if (tp >= p.ntile_p) break;
@@ -358,6 +366,131 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
     }
     __builtin_amdgcn_s_barrier();                  // (the next tile's prologue overwrites buffers the slowest wave may still be reading)
 
+    if (FUS) {
+      // ---- fused forward tail (this workgroup's ONLY tile: host) ----
+      // (1) per-channel sum / sum of squares of the raw fp32 accumulators (rows past M hold zeros: their operand rows were the zero page)
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+#pragma unroll
+        for (int h = 0; h < CF / 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float a = acc[2 * h][q][r], b = acc[2 * h + 1][q][r];
+            st_s[h][r] += a; st_q[h][r] += a * a; st_s[h][4 + r] += b; st_q[h][4 + r] += b * b;
+          }
+      float* red = reinterpret_cast<float*>(smem);       // [WP][2][BN] (the ring is idle: the tile ended with a barrier)
+#pragma unroll
+      for (int h = 0; h < CF / 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float s_ = row_sum16(st_s[h][i]), q_ = row_sum16(st_q[h][i]);
+          if (l15 == 15) {
+            const int cl = wc * CW + 32 * h + 8 * lq + i;
+            red[(wp * 2) * BN + cl] = s_; red[(wp * 2 + 1) * BN + cl] = q_;
+          }
+        }
+      __syncthreads();
+      float keep = 0.f;
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int which = t / BN, cl = t - which * BN;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < WP; ++k) a += red[(k * 2 + which) * BN + cl];
+        const int c = tn * BN + cl;
+        // RETURNING atomics: the add has been performed when the value is back (the barrier's arrival must not overtake it)
+        if (c < p.Cout) keep += atomicAdd(p.stats + (blockIdx.x % MYOLO_STAT_COPIES) * 2 * p.Cout + which * p.Cout + c, a);
+      }
+      asm volatile("" ::"v"(keep));
+      // (2) every tile of the layer has added its sums
+      grid_barrier_xcd(p.f_bar, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+      // (3) totals of this N tile's channels (all copies in flight, sc1 loads: written by other CUs' atomics) -> scale / shift
+      float* tot = sBN + 2 * BN;                       // [2][BN]
+      for (int t = tid; t < 2 * BN; t += NT) {
+        const int which = t / BN, cl = t - which * BN;
+        const int c = tn * BN + cl;
+        const unsigned voff = (unsigned)(which * p.Cout + (c < p.Cout ? c : 0)) * 4u;
+        float v[MYOLO_STAT_COPIES];
+#pragma unroll
+        for (int k = 0; k < MYOLO_STAT_COPIES; ++k) {
+          const float* base = p.stats + (size_t)k * 2 * p.Cout;
+          asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(v[k]) : "v"(voff), "s"(base) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < MYOLO_STAT_COPIES; ++k) asm volatile("" : "+v"(v[k]));
+        float d4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < MYOLO_STAT_COPIES; ++k) d4[k & 3] += v[k];
+        tot[t] = (d4[0] + d4[1]) + (d4[2] + d4[3]);      // (bn_act_fwd forms the same four chains; it adds them in double)
+      }
+      __syncthreads();
+      for (int cl = tid; cl < BN; cl += NT) {
+        const int c = tn * BN + cl;
+        float sc = 0.f, sh = 0.f;
+        if (c < p.Cout) {
+          const int64_t Mg = (int64_t)p.M * p.f_world;
+          const double meand = (double)tot[cl] / (double)Mg;
+          const double vard = (double)tot[BN + cl] / (double)Mg - meand * meand;
+          const float mean = (float)meand, var = vard > 0.0 ? (float)vard : 0.f;
+          const float invstd = rsqrtf(var + p.f_eps);
+          const bool lo = c < p.f_cs;
+          const int cc = lo ? c : c - p.f_cs;
+          sc = (lo ? p.f_gamma : p.f_gamma2)[cc] * invstd;
+          sh = (lo ? p.f_beta : p.f_beta2)[cc] - mean * sc;
+          if (blockIdx.x == 0) {                         // one workgroup per N tile publishes the layer's statistics
+            if (p.f_saved) { p.f_saved[c] = mean; p.f_saved[p.Cout + c] = invstd; }
+            float* rmp = lo ? p.f_rm : p.f_rm2; float* rvp = lo ? p.f_rv : p.f_rv2;
+            if (rmp) {
+              rmp[cc] = (1.f - p.f_mom) * rmp[cc] + p.f_mom * mean;
+              const float unb = Mg > 1 ? var * (float)Mg / (float)(Mg - 1) : var;
+              rvp[cc] = (1.f - p.f_mom) * rvp[cc] + p.f_mom * unb;
+            }
+          }
+        }
+        sBN[cl] = sc; sBN[BN + cl] = sh;
+      }
+      if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && p.f_nbt) *p.f_nbt += 1;
+      if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 1 && p.f_nbt2 && p.f_cs < p.Cout) *p.f_nbt2 += 1;
+      __syncthreads();
+      // (4) raw output and activation from the same accumulators: the normalisation reads the STORED (fp16-rounded) value, as bn_act_fwd does
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int m = m0 + wp * PW + q * 16 + l15;
+        const bool mvalid = m < p.M;
+        const int mm = mvalid ? m : 0;
+        const int n = mm / p.HWo; const int rem = mm - n * p.HWo;
+        const int oy = rem / p.Wo; const int ox = rem - oy * p.Wo;
+        const unsigned yoff = (unsigned)(n * p.y_sn + oy * p.y_sh + ox * p.y_sw);
+        const unsigned ooff = (unsigned)(n * p.fo_sn + oy * p.fo_sh + ox * p.fo_sw);
+        const unsigned roff = (unsigned)(n * p.fr_sn + oy * p.fr_sh + ox * p.fr_sw);
+        uint4 rv[CF / 2];
+#pragma unroll
+        for (int h = 0; h < CF / 2; ++h) {
+          const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
+          if (p.f_res) rv[h] = ldg16((mvalid && c0 < p.Cout) ? p.f_res + roff + c0 * 2 : zero_page());
+        }
+#pragma unroll
+        for (int h = 0; h < CF / 2; ++h) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { v[r] = acc[2 * h][q][r]; v[4 + r] = acc[2 * h + 1][q][r]; }
+          const int c0 = tn * BN + wc * CW + 32 * h + 8 * lq;
+          const int cl = wc * CW + 32 * h + 8 * lq;
+          if (mvalid && c0 < p.Cout) {
+            const u32x4_t y16 = pack_h8(v);
+            stg16(p.y + yoff + c0 * 2, uint4{y16.x, y16.y, y16.z, y16.w});
+            float z[8];
+            Vec<half_t>::unpack(uint4{y16.x, y16.y, y16.z, y16.w}, z);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = act_f(fmaf(z[i], sBN[cl + i], sBN[BN + cl + i]), p.f_act);
+            if (p.f_res) add_h8(z, u32x4_t{rv[h].x, rv[h].y, rv[h].z, rv[h].w});
+            const u32x4_t o = pack_h8(z);
+            stg16(p.f_out + ooff + c0 * 2, uint4{o.x, o.y, o.z, o.w});
+          }
+        }
+      }
+      fus_done = true;
+    } else {
     // ---- epilogue: lane = pixel l15 of fragment q, channels 32*h + 8*lq .. +7 of the wave's channel range (h = fragment pair) ----
 #pragma unroll
     for (int q = 0; q < PF; ++q) {
@@ -429,6 +562,12 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
         }
       }
     }
+    }   // !FUS
+  }
+  if (FUS) {
+    // a workgroup without a tile (the grid is a multiple of eight) still takes part in the barrier; nothing else is left to do
+    if (!fus_done) grid_barrier_xcd(p.f_bar, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    return;
   }
 
   if (BNS ? sgi >= 0 : p.stats != nullptr) {
@@ -462,16 +601,20 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
   }
 }
 
-template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false, bool EPI = false, bool BNA = false>
+template <int BM, int BN, int WP, int WC, int NST, bool DBG = false, bool BNS = false, bool EPI = false, bool BNA = false, bool FUS = false>
 int launch(const MidK& k, int per_cu, int ntile_c, hipStream_t st) {
   constexpr int NT = 64 * WP * WC;
-  constexpr int SMEM = NST * (BM * (BNA ? 2 : 1) + BN) * 128 + (BNS ? 4 * BN * 4 : (EPI ? 2 * BN * 4 : 0)) + (BNA ? 4 * 512 * 4 : 0);
+  constexpr int SMEM = NST * (BM * (BNA ? 2 : 1) + BN) * 128 + ((BNS || FUS) ? 4 * BN * 4 : (EPI ? 2 * BN * 4 : 0)) + (BNA ? 4 * 512 * 4 : 0);
   static_assert(SMEM <= 160 * 1024, "LDS");
   static_assert(SMEM >= WP * 2 * BN * 4, "statistics reduction area");
   int per_xcd = (256 * per_cu / ntile_c + 7) / 8;
   if (per_xcd < 1) per_xcd = 1;
   if (per_xcd > k.tiles_per_xcd) per_xcd = k.tiles_per_xcd;
-  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS, EPI, BNA>;
+  if (FUS) {                        // one tile per workgroup, every workgroup resident (host: tiles_per_xcd * 8 * ntile_c <= 256)
+    per_xcd = k.tiles_per_xcd;
+    if (per_xcd * 8 * ntile_c > 256) return MYOLO_EINVAL;
+  }
+  auto kern = conv_mid_kernel<BM, BN, WP, WC, NST, DBG, BNS, EPI, BNA, FUS>;
   MYOLO_ENSURE_DYN_SMEM(kern, SMEM);
   hipLaunchKernelGGL(kern, dim3(per_xcd * 8, ntile_c), dim3(NT), SMEM, st, k);
   MYOLO_CHECK_LAUNCH();
@@ -502,10 +645,12 @@ int myolo_conv_mid_mode() {
 
 // -1: the layer does not qualify (caller goes on to the next kernel family), else 0 / hipError_t.  *bnb_done = 1: the BatchNorm-backward
 // sums (myolo_conv_desc.bnb) were produced in the epilogue; 0: the caller runs the reduce pass itself.
-static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf);
+// ff != nullptr: the fused forward (myolo_conv_bn_act); dry: only answer whether the fused kernel would run (0) or not (-1)
+static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf, const myolo_bn_fwd_fuse* ff = nullptr,
+                      bool dry = false);
 int myolo_conv_mid_try(const myolo_conv_desc* d, void* stream, int* bnb_done) { return mid_launch(d, stream, bnb_done, nullptr); }
 
-static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf) {
+static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, const myolo_bn_apply_fold* bf, const myolo_bn_fwd_fuse* ff, bool dry) {
   using namespace mid;
   *bnb_done = 0;
   if (d->x.dtype != MYOLO_F16 || d->det_no > 0 || d->up_shift != 0) return -1;
@@ -580,6 +725,21 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
     if (var == 1 && ((M + 255) / 256) * ntile_c >= 512 && d->ntaps * (d->cin_pad / 64) >= 16) var = 4;
   }
   if (bn == 64 && var != 6) var = 2;
+  if (ff || dry) {
+    // fused forward: every tile of the layer resident at ONE workgroup per CU with its accumulators held -> at most 256 tiles (padded to
+    // a multiple of eight per N tile).  The variant the plain launch would take if that fits, else the 256-row tile, else not fused
+    auto wgs = [&](int v) {
+      const int bm_ = v == 3 ? 64 : (v == 4 ? 256 : 128);
+      const int bn_ = v == 2 ? 64 : 128;
+      return (int64_t)(((M + bm_ - 1) / bm_ + 7) / 8) * 8 * (d->cout_pad / bn_);
+    };
+    if (var == 6) return -1;
+    if (wgs(var) > 256) {
+      if (bn == 128 && wgs(4) <= 256) var = 4;
+      else return -1;
+    }
+    if (dry) return 0;
+  }
   const int bm = var == 3 ? 64 : (var == 4 ? 256 : 128);
   k.ntile_p = (int)((M + bm - 1) / bm);
   k.tiles_per_xcd = (k.ntile_p + 7) / 8;
@@ -595,6 +755,24 @@ static int mid_launch(const myolo_conv_desc* d, void* stream, int* bnb_done, con
     if (var == 5) return fold ? launch<128, 128, 4, 2, 3, false, true, false, true>(k, 1, ntc, st) : launch<128, 128, 4, 2, 3, false, false, false, true>(k, 1, ntc, st);
     if (var == 2) return fold ? launch<128, 64, 2, 2, 3, false, true, false, true>(k, 1, ntc, st) : launch<128, 64, 2, 2, 3, false, false, false, true>(k, 1, ntc, st);
     return fold ? launch<64, 128, 1, 4, 3, false, true, false, true>(k, 1, ntc, st) : launch<64, 128, 1, 4, 3, false, false, false, true>(k, 1, ntc, st);
+  }
+  if (ff) {
+    const myolo_bn_split* sp = ff->split;
+    k.f_out = (char*)ff->out.ptr; k.f_res = (const char*)ff->res.ptr;
+    k.fo_sn = (int)ff->out.sn * 2; k.fo_sh = (int)ff->out.sh * 2; k.fo_sw = (int)ff->out.sw * 2;
+    k.fr_sn = (int)ff->res.sn * 2; k.fr_sh = (int)ff->res.sh * 2; k.fr_sw = (int)ff->res.sw * 2;
+    k.f_gamma = ff->gamma; k.f_beta = ff->beta; k.f_rm = ff->running_mean; k.f_rv = ff->running_var; k.f_nbt = ff->nbt; k.f_saved = ff->saved;
+    k.f_eps = ff->eps; k.f_mom = ff->momentum; k.f_act = ff->act; k.f_bar = ff->barrier;
+    k.f_cs = sp ? sp->c_split : d->y.c;
+    k.f_world = (sp && sp->count_scale > 1) ? sp->count_scale : 1;
+    const bool two = sp && sp->c_split < d->y.c;
+    k.f_gamma2 = two ? sp->gamma2 : ff->gamma; k.f_beta2 = two ? sp->beta2 : ff->beta;
+    k.f_rm2 = two ? sp->running_mean2 : nullptr; k.f_rv2 = two ? sp->running_var2 : nullptr; k.f_nbt2 = two ? sp->nbt2 : nullptr;
+    if (var == 1) return launch<128, 128, 4, 2, 4, false, false, false, false, true>(k, 1, ntc, st);
+    if (var == 4) return launch<256, 128, 4, 2, 3, false, false, false, false, true>(k, 1, ntc, st);
+    if (var == 5) return launch<128, 128, 4, 2, 3, false, false, false, false, true>(k, 1, ntc, st);
+    if (var == 2) return launch<128, 64, 2, 2, 3, false, false, false, false, true>(k, 1, ntc, st);
+    return launch<64, 128, 1, 4, 3, false, false, false, false, true>(k, 1, ntc, st);
   }
   if (var == 1 && k.dbg) return launch<128, 128, 4, 2, 4, true>(k, 1, ntc, st);     // profiling switches (myolo_set_option("mid_dbg", bits))
 #define MID_GO(BM_, BN_, WP_, WC_, NST_, PCU_)                                                   \
@@ -630,4 +808,40 @@ extern "C" int myolo_conv_dgrad_bn(const myolo_conv_desc* d, const myolo_bn_appl
   myolo_conv_desc d2 = *d;
   d2.x = f->dy;
   return myolo_conv(&d2, stream);
+}
+
+// ---- training-mode Conv + BatchNorm + activation in ONE launch (myolo.h, round 6) ----
+static int g_conv_bn_act = -1;         // MYOLO_CONV_BN_ACT=0: always the two launches
+static bool conv_bn_act_pre(const myolo_conv_desc* d) {
+  if (g_conv_bn_act < 0) g_conv_bn_act = getenv("MYOLO_CONV_BN_ACT") ? atoi(getenv("MYOLO_CONV_BN_ACT")) : 1;
+  return g_conv_bn_act && d && d->x.ptr && d->y.ptr && d->w && d->x.dtype == MYOLO_F16 && d->y.dtype == MYOLO_F16 && d->stats && !d->res.ptr &&
+         !d->accumulate && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && !(d->bnb && d->nbnb > 0) && d->det_no == 0 &&
+         myolo_conv_mid_mode() >= 2 && !g_mid_var && !g_mid_dbg;
+}
+extern "C" int myolo_conv_bn_act_ok(const myolo_conv_desc* d) {
+  if (!conv_bn_act_pre(d)) return 0;
+  int done = 0;
+  return mid_launch(d, nullptr, &done, nullptr, nullptr, true) == 0;
+}
+extern "C" int myolo_conv_bn_act(const myolo_conv_desc* d, const myolo_bn_fwd_fuse* f, void* stream) {
+  if (!d || !f || !d->stats || !f->gamma || !f->beta || !f->out.ptr || !f->barrier || ((uintptr_t)f->barrier & 127)) return MYOLO_EINVAL;
+  auto same = [](const myolo_tensor& a, const myolo_tensor& b) { return a.n == b.n && a.h == b.h && a.w == b.w && a.c == b.c && a.dtype == b.dtype; };
+  auto extent = [](const myolo_tensor& t) { return ((int64_t)t.n * t.sn + (int64_t)t.h * t.sh + (int64_t)t.w * t.sw + t.c) * 2; };
+  if (!same(f->out, d->y) || (f->res.ptr && (f->res.n != d->y.n || f->res.h != d->y.h || f->res.w != d->y.w || f->res.c < d->y.c || f->res.dtype != d->y.dtype)))
+    return MYOLO_EINVAL;
+  const bool vec = !(f->out.sw % 8) && !(f->out.sh % 8) && !(f->out.sn % 8) && !((uintptr_t)f->out.ptr & 15) && extent(f->out) < (1ll << 31) &&
+                   (!f->res.ptr || (!(f->res.sw % 8) && !(f->res.sh % 8) && !(f->res.sn % 8) && !((uintptr_t)f->res.ptr & 15) && extent(f->res) < (1ll << 31)));
+  const bool split_ok_ = !f->split || (f->split->c_split > 0 && f->split->c_split <= d->y.c && !(f->split->c_split % 8) &&
+                                       (f->split->c_split == d->y.c || (f->split->gamma2 && f->split->beta2)));
+  if (!split_ok_) return MYOLO_EINVAL;
+  if (vec && conv_bn_act_pre(d)) {
+    int done = 0;
+    const int r = mid_launch(d, stream, &done, nullptr, f, false);
+    if (r != -1) return r;
+  }
+  // the definition of the result: the two launches
+  int r = myolo_conv(d, stream);
+  if (r) return r;
+  return myolo_bn_act_fwd_split(&d->y, d->stats, f->gamma, f->beta, f->running_mean, f->running_var, f->nbt, f->saved, f->eps, f->momentum, f->act,
+                                f->res.ptr ? &f->res : nullptr, &f->out, f->split, stream);
 }

@@ -41,6 +41,8 @@ TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '1') != '0'
 # inside (csrc/bn_act.hip bn_act_bwd_fused_kernel).  1: layers that run the two passes as launches of their own; 2: also instead of the
 # apply fold of a 1x1 dgrad (myolo_conv_dgrad_bn) where that layer's reduce pass is a launch of its own; 0: off
 BN_BWD_FUSED = int(os.environ.get('MYOLO_BN_BWD_FUSED', '2'))
+# round 6: training-mode Conv + BatchNorm + activation as ONE launch (myolo_conv_bn_act) for the layers whose tiles are all resident
+CONV_BN_ACT = os.environ.get('MYOLO_CONV_BN_ACT', '1') != '0'
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -452,11 +454,32 @@ class ConvOp(Op):
                 self.stats = plan.f32_fwd_zero(L.STAT_COPIES * 2 * self.cout)
                 self.saved = torch.zeros(2 * self.cout, dtype=torch.float32, device=dev)
                 d.stats = self.stats.data_ptr()
-            self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
             self.yd, self.od = yv.desc(), self.out.desc()
             self.rd = self.res.desc() if self.res is not None else null_tensor()
             bn = self.bn
-            if has_bn and (self.bn2 is not None or self.sync_world > 1):
+            # round 6 (north_star's "fused Conv+BN+SiLU", training mode): conv + batch statistics + device-wide barrier + BatchNorm +
+            # activation (+ shortcut) in ONE launch where the library says every tile of the layer is resident (csrc/conv_mid.hip FUS)
+            self.fwd_fused = bool(CONV_BN_ACT and has_bn and dt == torch.float16 and self.sync_world == 1 and
+                                  L.lib().myolo_conv_bn_act_ok(C.byref(d)))
+            if self.fwd_fused:
+                ff = self.ffuse = L.BnFwdFuse()
+                ff.gamma, ff.beta, ff.running_mean, ff.running_var = bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr()
+                ff.nbt, ff.saved, ff.eps, ff.momentum, ff.act = bn.num_batches_tracked.data_ptr(), self.saved.data_ptr(), bn.eps, bn.momentum, self.act
+                ff.res, ff.out, ff.barrier = self.rd, self.od, plan.grid_barrier().data_ptr()
+                if self.bn2 is not None:
+                    b2 = self.bn2
+                    assert (b2.eps, b2.momentum) == (bn.eps, bn.momentum)
+                    sp = self.split = L.BnSplit()
+                    sp.c_split, sp.count_scale = self.c1out, 1
+                    sp.gamma2, sp.beta2, sp.running_mean2 = b2.weight.data_ptr(), b2.bias.data_ptr(), b2.running_mean.data_ptr()
+                    sp.running_var2, sp.nbt2 = b2.running_var.data_ptr(), b2.num_batches_tracked.data_ptr()
+                    ff.split = C.pointer(sp)
+                self.fwd_calls.append(Call('myolo_conv_bn_act', (C.byref(d), C.byref(ff)), keep=(bn, self.bn2)))
+            else:
+                self.fwd_calls.append(Call('myolo_conv', (C.byref(d),)))
+            if self.fwd_fused:
+                pass
+            elif has_bn and (self.bn2 is not None or self.sync_world > 1):
                 b2 = self.bn2
                 sp = self.split = L.BnSplit()
                 sp.c_split, sp.count_scale = self.cout, self.sync_world          # (c_split == c: no second parameter set)
@@ -2147,7 +2170,7 @@ def call_algorithmic_bytes(call):
     result written once -- conv / dgrad: input + weights + output; wgrad: x + dy + fp32 gradient; BatchNorm forward: raw + out
     (+ residual); backward reduce: gout + raw; backward apply: gout + raw + dy (+ residual gradient).  None for other launches."""
     n = call.name
-    if n in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
+    if n in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_bn_act'):
         return conv_call_bytes(call)
     if n == 'myolo_conv_wgrad':
         d = call.args[0]._obj
@@ -2170,7 +2193,7 @@ def call_algorithmic_bytes(call):
 def plan_algorithmic_bytes(plan):
     """{family: bytes} over the forward + backward launch lists of a training plan"""
     out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
-    fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_dgrad_bn': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
+    fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_dgrad_bn': 'conv', 'myolo_conv_bn_act': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
            'myolo_bn_act_bwd_apply': 'batchnorm', 'myolo_bn_act_fwd_split': 'batchnorm', 'myolo_bn_act_bwd_reduce_split': 'batchnorm',
            'myolo_bn_act_bwd_apply_split': 'batchnorm', 'myolo_bn_act_bwd_fused': 'batchnorm'}
     for op in plan.ops:
@@ -2178,6 +2201,9 @@ def plan_algorithmic_bytes(plan):
             b = call_algorithmic_bytes(c)
             if b is not None:
                 out[fam[c.name]] += b
+            if c.name == 'myolo_conv_bn_act':              # (the BatchNorm forward pass the launch carries keeps its unfused byte count: raw + out (+ residual))
+                f = c.args[1]._obj
+                out['batchnorm'] += _tensor_bytes(f.out) * 2 + (_tensor_bytes(f.res, f.out.c) if f.res.ptr else 0)
             if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn'):
                 out['batchnorm'] += bnb_call_bytes(c) + apply_fold_bytes(c)    # (reduce / apply passes folded into dgrad launches keep their unfused byte count)
     return out

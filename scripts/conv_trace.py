@@ -10,7 +10,7 @@ m = Model(os.path.join(CFG, TAGS['s_psp'])); m.train(True)
 h = R.PlanHolder(m, [torch.zeros(16, 3, 512, 1024)], ('t', 0), torch.float16, True)
 calls = []
 for o in h.plan.ops:
-    calls += [('f', c) for c in o.fwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2')]
+    calls += [('f', c) for c in o.fwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_bn_act')]
 for o in reversed(h.plan.ops):
     calls += [('b', c) for c in o.bwd_calls if c.name in ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn')]
 rows = list(csv.DictReader(open(sys.argv[1])))

@@ -254,7 +254,7 @@ def bn_fwd_ref(y, stats, gamma, beta, eps, act, res):
 
 BN_NAMES = ('myolo_bn_act_fwd', 'myolo_bn_act_fwd_split', 'myolo_bn_act_bwd_reduce', 'myolo_bn_act_bwd_reduce_split', 'myolo_bn_act_bwd_apply',
             'myolo_bn_act_bwd_apply_split', 'myolo_bn_act_bwd_fused')
-CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair')
+CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair', 'myolo_conv_bn_act')
 
 
 class LaunchChecker:
@@ -344,6 +344,42 @@ class LaunchChecker:
             self.orig(call, st)
             torch.cuda.synchronize()
             self._conv_post(d, pre, self._what('conv', d))
+        elif name == 'myolo_conv_bn_act':
+            # round 6: conv (raw output + statistics) AND the BatchNorm forward pass in one launch.  The conv half against the descriptor's
+            # formula as for myolo_conv; the BatchNorm half against first principles over the y and the sums the launch stored
+            d, f = self._desc(call.args[0]), self._desc(call.args[1])
+            split = f.split.contents if f.split else None
+            pre = self._conv_pre(d)
+            B = _BnArgs(d.y, split)
+            C, M = B.C, B.M * B.scale
+            rm0 = _split_vec(f.running_mean, split.running_mean2 if split else None, C, B.cs)
+            rv0 = _split_vec(f.running_var, split.running_var2 if split else None, C, B.cs)
+            res = read_tensor(f.res, channels=C) if f.res.ptr else None
+            self.orig(call, st)
+            torch.cuda.synchronize()
+            what = self._what('conv_bn_act', d) + ('+res' if res is not None else '') + ('+split' if split is not None and B.cs < C else '')
+            assert int(read_u32(f.barrier, 19 * 32)[18 * 32]) == 0, what + ': the grid barrier timed out'
+            self._conv_post(d, pre, what)
+            y = read_out(d)
+            stats = stat_sums(d.stats, C) - pre['s0']
+            gamma = _split_vec(f.gamma, split.gamma2 if split else None, C, B.cs)
+            beta = _split_vec(f.beta, split.beta2 if split else None, C, B.cs)
+            mean = stats[0] / M
+            var = (stats[1] / M - mean * mean).clamp_min(0)
+            invstd = 1.0 / torch.sqrt(var + float(f.eps))
+            out_ref = act_fn(((y.double() - mean) * invstd * gamma.double() + beta.double()).float(), int(f.act))
+            if res is not None:
+                out_ref = out_ref + res
+            self._ck(what + '/out', read_tensor(f.out), out_ref, self.tol_out)
+            sv = read_f32(f.saved, 2 * C)
+            self._ck(what + '/saved_mean', sv[:C], mean.float(), 1e-4)
+            self._ck(what + '/saved_invstd', sv[C:], invstd.float(), 1e-4)
+            if rm0 is not None:
+                mom = float(f.momentum)
+                rm1 = _split_vec(f.running_mean, split.running_mean2 if split else None, C, B.cs)
+                rv1 = _split_vec(f.running_var, split.running_var2 if split else None, C, B.cs)
+                self._ck(what + '/running_mean', rm1, ((1 - mom) * rm0.double() + mom * mean).float(), 1e-4)
+                self._ck(what + '/running_var', rv1, ((1 - mom) * rv0.double() + mom * var * M / max(M - 1, 1)).float(), 1e-4)
         elif name == 'myolo_conv_pair':         # myolo.h: b(a(x)), the intermediate rounded to the storage type, a->y not necessarily written
             a, b = self._desc(call.args[0]), self._desc(call.args[1])
             t = conv_epilogue(a, conv_acc(a))

@@ -1,0 +1,153 @@
+"""-m gpu: training-mode Conv + BatchNorm + activation (+ shortcut) in ONE launch (`myolo_conv_bn_act`, csrc/conv_mid.hip FUS: statistics ->
+device-wide barrier -> scale / shift -> raw output and activation from the same accumulators; round 6, north_star's "fused Conv+BN+SiLU")
+through the raw C ABI against
+  * torch fp32 on the CPU over the same fp16-rounded operands: F.conv2d -> batch statistics -> (y16 - mean) * invstd * gamma + beta -> SiLU
+    (+ residual) (reference models/common.py:42-43,105; eps 1e-3 / momentum 0.03 from utils/torch_utils.py:150-151), and
+  * the two launches it replaces (`myolo_conv` + `myolo_bn_act_fwd_split`) on the same inputs,
+for every tile variant the dispatcher can pick (128x128 with 4 / 3 stages, 256x128, 128x64, 64x128), 1x1 / 3x3 / stride 2, ragged pixel
+counts, a split parameter set (C3's merged cv1 | cv2), the shortcut, and a layer with more tiles than CUs (must run the two launches)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.gpu_util import check
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _td(L, t, c=None):
+    n, h, w, cc = t.shape
+    sn, sh, sw, _ = t.stride()
+    return L.Tensor(t.data_ptr(), n, h, w, cc if c is None else c, sn, sh, sw, L.F16, 0)
+
+
+def _run(cin, cout, k, s, B, H, W, res=False, split=0, act=1, seed=0, expect_fused=True, bar=None):
+    from multiyolov5_amd import _lib as L, engine as E
+    lib = L.lib()
+    g = torch.Generator().manual_seed(seed)
+    Ho, Wo = (H + s - 1) // s, (W + s - 1) // s
+    x = (torch.randn(B, H, W, cin, generator=g) * 0.5).half()
+    w = (torch.randn(cout, cin, k, k, generator=g) * (1.0 / (cin * k * k) ** 0.5)).half()
+    gamma, beta = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    rm0, rv0 = torch.randn(cout, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5
+    r0 = (torch.randn(B, Ho, Wo, cout, generator=g) * 0.3).half()
+    eps, mom = 1e-3, 0.03
+    yref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), None, s, k // 2).permute(0, 2, 3, 1).contiguous()
+    flat = yref.reshape(-1, cout).double()
+    M = flat.shape[0]
+    mean, var = flat.mean(0), flat.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + eps)
+    z = (yref.half().double() - mean) * invstd * gamma.double() + beta.double()
+    oref = (z * torch.sigmoid(z) if act == 1 else torch.sigmoid(z)).float()
+    if res:
+        oref = oref + r0.float()
+    cin_pad, cout_pad = E.conv_pad(cin, 32, torch.float16), E.conv_pad(cout, 32, torch.float16)
+    wp = torch.zeros(cout_pad, k * k, cin_pad, device=DEV, dtype=torch.float16)
+    L.check(lib.myolo_pack_weight(L.ptr(w.float().to(DEV)), L.F32, cout, cin, k, k, L.ptr(wp), L.F16, cout_pad, cin_pad, 0, None, L.stream_ptr()))
+
+    def run(fused):
+        xd, rd = x.to(DEV), r0.to(DEV)
+        yd = torch.full((B, Ho, Wo, cout), float('nan'), device=DEV, dtype=torch.float16)
+        od = torch.full((B, Ho, Wo, cout), float('nan'), device=DEV, dtype=torch.float16)
+        st = torch.zeros(L.STAT_COPIES * 2 * cout, device=DEV)
+        saved = torch.zeros(2 * cout, device=DEV)
+        cs = split if split else cout
+        ga, be, rm, rv = (v[:cs].contiguous().to(DEV) for v in (gamma, beta, rm0, rv0))
+        ga2, be2, rm2, rv2 = (v[cs:].contiguous().to(DEV) if split else torch.zeros(1, device=DEV) for v in (gamma, beta, rm0, rv0))
+        nbt, nbt2 = torch.zeros(1, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        dd = L.ConvDesc()
+        dd.x, dd.y, dd.w = _td(L, xd), _td(L, yd), wp.data_ptr()
+        dd.cin_pad, dd.cout_pad, dd.wtaps, dd.ntaps, dd.stride, dd.up_shift = cin_pad, cout_pad, k * k, k * k, s, 0
+        E.fill_taps(dd, *E.taps_fwd(k, 1, k // 2))
+        dd.res, dd.act, dd.stats, dd.accumulate = E.null_tensor(), L.ACT_NONE, st.data_ptr(), 0
+        sp = L.BnSplit()
+        sp.c_split, sp.count_scale = cs, 1
+        sp.gamma2, sp.beta2, sp.running_mean2, sp.running_var2, sp.nbt2 = ga2.data_ptr(), be2.data_ptr(), rm2.data_ptr(), rv2.data_ptr(), nbt2.data_ptr()
+        none = E.null_tensor()
+        stp = L.stream_ptr()
+        if fused:
+            ff = L.BnFwdFuse()
+            ff.gamma, ff.beta, ff.running_mean, ff.running_var, ff.nbt, ff.saved = ga.data_ptr(), be.data_ptr(), rm.data_ptr(), rv.data_ptr(), nbt.data_ptr(), saved.data_ptr()
+            ff.eps, ff.momentum, ff.act = eps, mom, act
+            ff.res, ff.out, ff.barrier = (_td(L, rd) if res else none), _td(L, od), bar.data_ptr()
+            if split:
+                ff.split = C.pointer(sp)
+            assert bool(lib.myolo_conv_bn_act_ok(C.byref(dd))) == expect_fused
+            lib.myolo_trace_start(1)
+            L.check(lib.myolo_conv_bn_act(C.byref(dd), C.byref(ff), stp), 'conv_bn_act')
+            torch.cuda.synchronize()
+            sites = L.launch_trace()
+            lib.myolo_trace_start(0)
+            one = not any('bn_act_fwd' in s_ for s_ in sites)
+            assert one == expect_fused, sorted(sites)
+        else:
+            L.check(lib.myolo_conv(C.byref(dd), stp))
+            ot, rt = _td(L, od), (_td(L, rd) if res else none)
+            L.check(lib.myolo_bn_act_fwd_split(C.byref(dd.y), L.ptr(st), L.ptr(ga), L.ptr(be), L.ptr(rm), L.ptr(rv), L.ptr(nbt), L.ptr(saved), C.c_float(eps),
+                                               C.c_float(mom), act, C.byref(rt), C.byref(ot), C.byref(sp) if split else None, stp))
+            torch.cuda.synchronize()
+        ss = st.view(L.STAT_COPIES, 2, cout).sum(0).cpu()
+        rmc = torch.cat([rm.cpu(), rm2.cpu()[:cout - cs]]) if split else rm.cpu()
+        rvc = torch.cat([rv.cpu(), rv2.cpu()[:cout - cs]]) if split else rv.cpu()
+        return yd.float().cpu(), od.float().cpu(), ss, saved.cpu(), rmc, rvc, int(nbt), int(nbt2)
+
+    bad = []
+    tag = f'conv_bn_act/{cin}->{cout} k{k}s{s} {B}x{H}x{W}' + ('+res' if res else '') + (f'+split{split}' if split else '') + f'/act{act}'
+    y1, o1, s1, sv1, rm1, rv1, n1, n12 = run(True)
+    assert int(bar[18 * 32]) == 0, tag + ': the grid barrier timed out'
+    check(tag + '/y', y1, yref, 2e-3, collect=bad)
+    check(tag + '/out', o1, oref, 3e-3, collect=bad)
+    check(tag + '/sum', s1[0], flat.sum(0).float(), 1e-3, collect=bad)
+    check(tag + '/sumsq', s1[1], (flat * flat).sum(0).float(), 1e-4, collect=bad)
+    check(tag + '/saved_mean', sv1[:cout], mean.float(), 1e-4, collect=bad)
+    check(tag + '/saved_invstd', sv1[cout:], invstd.float(), 1e-4, collect=bad)
+    check(tag + '/running_mean', rm1, ((1 - mom) * rm0.double() + mom * mean).float(), 1e-4, collect=bad)
+    check(tag + '/running_var', rv1, ((1 - mom) * rv0.double() + mom * var * M / (M - 1)).float(), 1e-4, collect=bad)
+    assert n1 == 1 and n12 == (1 if split else 0), (n1, n12)
+    y2, o2, s2, sv2, rm2_, rv2_, _, _ = run(False)
+    check(tag + '/y_vs_two_launches', y1, y2, 1e-3, collect=bad)              # (myolo_conv may pick another kernel family / tile: summation order)
+    check(tag + '/out_vs_two_launches', o1, o2, 2e-3, collect=bad)
+    check(tag + '/saved_vs_two_launches', sv1, sv2, 1e-5, collect=bad)
+    assert not bad, '\n'.join(bad)
+
+
+@pytest.fixture(scope='module')
+def bar():
+    return torch.zeros(19 * 32, dtype=torch.int32, device=DEV)
+
+
+CASES = [
+    # cin, cout, k, s, B, H, W                      variant the dispatcher picks (csrc/conv_mid.hip mid_launch)
+    (128, 128, 1, 1, 16, 32, 64),                   # 6.m.*.cv1 at batch 16: 256 tiles of 128x128, four stages
+    (128, 128, 3, 1, 16, 32, 64),                   # 6.m.*.cv2: 3x3
+    (256, 256, 1, 1, 16, 32, 64),                   # 6.cv3: 512 tiles of 128x128 -> 256 tiles of 256x128
+    (128, 256, 3, 2, 16, 64, 128),                  # 5.conv: stride 2, 256x128 tiles
+    (512, 512, 1, 1, 16, 16, 32),                   # 9.cv3: 64 pixel tiles x 4 N tiles
+    (256, 256, 3, 1, 16, 16, 32),                   # 9.m.0.cv2: 64x128 tiles (fewer than 192 tiles of 128x128)
+    (512, 128, 1, 1, 16, 16, 32),                   # 24.m32.0: 64 tiles -> 64x128, 128 workgroups
+    (128, 64, 1, 1, 4, 32, 64),                     # 64 output channels: the 128x64 (4-wave) tile
+    (64, 64, 1, 1, 2, 31, 37),                      # ragged: 2294 pixels, ONE K step (three-stage ring)
+    (96, 96, 3, 1, 2, 32, 64),                      # yolov5m: ragged last K chunk + masked N columns, fused
+]
+
+
+@pytest.mark.parametrize('case', CASES, ids=[f'{c[0]}-{c[1]}k{c[2]}s{c[3]}_{c[4]}x{c[5]}x{c[6]}' for c in CASES])
+def test_fused_conv_bn_silu_matches_torch_and_the_two_launches(case, bar):
+    _run(*case, bar=bar)
+
+
+def test_fused_conv_bn_act_variants(bar):
+    _run(128, 128, 3, 1, 16, 32, 64, res=True, seed=1, bar=bar)                  # Bottleneck: x + cv2(cv1(x))
+    _run(256, 256, 1, 1, 16, 32, 64, split=128, seed=2, bar=bar)                 # C3's merged cv1 | cv2: two parameter sets, two nbt counters
+    _run(512, 256, 1, 1, 8, 16, 32, split=128, res=False, act=2, seed=3, bar=bar)   # Sigmoid, uneven split
+    _run(128, 128, 1, 1, 2, 32, 64, res=True, seed=4, bar=bar)                   # 32 tiles: most workgroups of the padded grid have no tile
+
+
+def test_layers_with_more_tiles_than_cus_run_the_two_launches(bar):
+    _run(64, 64, 1, 1, 16, 64, 128, expect_fused=False, bar=bar)                # 1024 tiles of 128 pixels
+    _run(128, 128, 1, 1, 16, 64, 128, seed=5, expect_fused=False, bar=bar)
+    st = bar.cpu()
+    assert int(st[18 * 32]) == 0 and all(int(st[g * 32]) == 0 for g in range(8)) and int(st[16 * 32]) == 0

@@ -26,6 +26,7 @@ def test_training_plan_launch_list_structure(monkeypatch):
     assert bwd['myolo_bn_act_bwd_fused'] >= 9 and bwd['myolo_bn_act_bwd_reduce_split'] == 0 and bwd['myolo_bn_act_bwd_apply_split'] == 0
     assert hasattr(plan, '_grid_bar') and plan._grid_bar.numel() == 19 * 32
     monkeypatch.setattr(E, 'BN_BWD_FUSED', 0)                       # the two-launch form (what the big maps of the benchmarked step still run)
+    monkeypatch.setattr(E, 'CONV_BN_ACT', False)                    # ... and conv / BatchNorm forward as two launches
     plan = _plan()
     fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
     bwd = Counter(c.name for op in plan.ops for c in op.bwd_calls)
@@ -269,6 +270,7 @@ def test_tiny_conv_groups_leave_the_launch_chain(monkeypatch):
     from multiyolov5_amd import engine as E
     monkeypatch.setattr(E, 'TINY_CONV', True)
     monkeypatch.setattr(E, 'BN_BWD_FUSED', 0)        # (the launch counts below are those of the two-pass BatchNorm backward)
+    monkeypatch.setattr(E, 'CONV_BN_ACT', False)     # (... and of the two-launch Conv + BatchNorm forward)
     from multiyolov5_amd import runtime as R
     from multiyolov5_amd.models.yolo import Model
 
@@ -445,3 +447,26 @@ def test_unchanged_detect_and_test_py_statements_reach_the_fused_argmax(monkeypa
     monkeypatch.setattr(R, 'LAZY_RESIZE', False)
     out = F.interpolate(_lazy_logits(base, launches), (24, 40), mode='bilinear', align_corners=True)
     assert type(out) is torch.Tensor
+
+
+def test_benchmarked_plan_fuses_conv_bn_act_where_every_tile_is_resident():
+    """round 6: the dry-built plan of BASELINE configs[1] (16x3x512x1024, fp16).  Conv + batch statistics + BatchNorm + SiLU
+    (+ shortcut) is ONE launch (myolo_conv_bn_act: device-wide barrier inside) for every Conv layer of the 32x64 and 16x32 maps -- the layers
+    whose tiles are all resident at one 8-wave workgroup per CU; the larger maps keep conv + bn_act_fwd.  The BatchNorm backward is one launch
+    (reduce + barrier + apply) for the tensors of at most 256 register-resident workgroups."""
+    from multiyolov5_amd import engine as E, runtime as R
+    from multiyolov5_amd.models.yolo import Model
+    m = Model(os.path.join(CFG, TAGS['s_psp']))
+    m.train()
+    plan = R.PlanHolder(m, [torch.zeros(16, 3, 512, 1024)], ('t', 0), torch.float16, True).plan
+    fwd = Counter(c.name for op in plan.ops for c in op.fwd_calls)
+    bwd = Counter(c.name for op in plan.ops for c in op.bwd_calls)
+    fused = [op for op in plan.ops if getattr(op, 'fwd_fused', False)]
+    assert fwd['myolo_conv_bn_act'] == len(fused) == 34
+    assert all(op.out.h * op.out.w <= 32 * 64 for op in fused) and {(op.out.h, op.out.w) for op in fused} == {(32, 64), (16, 32)}
+    assert fwd['myolo_bn_act_fwd'] + fwd['myolo_bn_act_fwd_split'] == 26          # (60 before round 6)
+    assert all(not any(c.name.startswith('myolo_bn_act_fwd') for c in op.fwd_calls) for op in fused)
+    merged = [op for op in fused if op.weight2 is not None]
+    assert len(merged) == 5 and all(op.ffuse.split.contents.c_split == op.c1out for op in merged)      # C3's cv1 | cv2 pairs: two parameter sets
+    assert bwd['myolo_bn_act_bwd_fused'] == 7
+    del plan, m
