@@ -365,6 +365,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(myolo_tensor gout
   float* tab = red;                      // [4][CW]
   for (int j = threadIdx.x; j < 2 * CW; j += blockDim.x) {       // thread j: statistic j / CW of channel j % CW, summed over the copies
     const int which = j / CW, cl = j - which * CW;
+    // (inline-asm rules learnt here: the destination is early-clobber -- the load lands LATER, its register must not double as an address --
+    //  and `s_nop 4` precedes the load: hipcc keeps spilled scalar bases in VGPR lanes and restores them with v_readlane right in front of
+    //  the asm; a VALU write of an SGPR needs 5 wait states before a VMEM instruction reads it, and the hazard pass does not look inside
+    //  inline asm -- without the nops some copies were fetched from the PREVIOUS copy's base: totals off by a few tiles' worth)
     // all copies in flight at once, ONE vector offset + a scalar base per copy (`global_load_dword v, v_off, s[base] sc1`): as plain C++
     // hipcc kept a 64-bit vector address per copy alive (255 VGPRs at NP = 8); inline asm loads are invisible to its waitcnt pass, so the
     // wait is explicit and the results are tied behind it
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_fused_kernel(myolo_tensor gout
 #pragma unroll
     for (int k = 0; k < MYOLO_STAT_COPIES; ++k) {
       const float* base = dsum + (size_t)k * 2 * C;          // uniform
-      asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(v[k]) : "v"(voff), "s"(base) : "memory");
+      asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=&v"(v[k]) : "v"(voff), "s"(base) : "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll

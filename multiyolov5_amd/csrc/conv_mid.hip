@@ -413,7 +413,7 @@ __global__ __launch_bounds__(64 * WP * WC) void conv_mid_kernel(const MidK p) {
 #pragma unroll
         for (int k = 0; k < MYOLO_STAT_COPIES; ++k) {
           const float* base = p.stats + (size_t)k * 2 * p.Cout;
-          asm volatile("global_load_dword %0, %1, %2 sc1" : "=v"(v[k]) : "v"(voff), "s"(base) : "memory");
+          asm volatile("s_nop 4\n\tglobal_load_dword %0, %1, %2 sc1" : "=&v"(v[k]) : "v"(voff), "s"(base) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -816,7 +816,8 @@ static bool conv_bn_act_pre(const myolo_conv_desc* d) {
   if (g_conv_bn_act < 0) g_conv_bn_act = getenv("MYOLO_CONV_BN_ACT") ? atoi(getenv("MYOLO_CONV_BN_ACT")) : 1;
   return g_conv_bn_act && d && d->x.ptr && d->y.ptr && d->w && d->x.dtype == MYOLO_F16 && d->y.dtype == MYOLO_F16 && d->stats && !d->res.ptr &&
          !d->accumulate && !d->scale && !d->shift && d->act == MYOLO_ACT_NONE && !(d->bnb && d->nbnb > 0) && d->det_no == 0 &&
-         myolo_conv_mid_mode() >= 2 && !g_mid_var && !g_mid_dbg;
+         myolo_conv_mid_mode() >= 2 && !g_mid_var && !g_mid_dbg &&
+         !(d->ntaps > 1 && d->stride == 1);      // (k x k stride-1 layers: conv_midx's resident-input kernel runs them as the first of two launches)
 }
 extern "C" int myolo_conv_bn_act_ok(const myolo_conv_desc* d) {
   if (!conv_bn_act_pre(d)) return 0;

@@ -238,6 +238,10 @@ __device__ __forceinline__ bool gbar_spin(gbar_u32* p, unsigned old, gbar_u32* t
   __hip_atomic_store(tmo, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return false;
 }
+// FENCED: lane 0 also issues an agent-scope release before it arrives and an acquire after the wait (plain stores / plain loads may then cross
+// the barrier; +1.5 us at 256 workgroups, profiles/r6_grid_barrier_ubench.txt rows `xcd` vs `xcd_lead`).  The library's two users publish
+// through returning atomics and read back with sc1 loads, which needs neither.
+template <bool FENCED = false>
 __device__ __forceinline__ void grid_barrier_xcd(unsigned int* state, int bid, int nblocks) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its atomics / sc1 stores have been performed
   __syncthreads();
@@ -247,6 +251,10 @@ __device__ __forceinline__ void grid_barrier_xcd(unsigned int* state, int bid, i
     const int ng = (nblocks - g + 7) >> 3;                 // blocks with id & 7 == g
     const int ngroups = nblocks < 8 ? nblocks : 8;
     const unsigned gen0 = __hip_atomic_load(w + (8 + g) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (FENCED) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");    // (buffer_wbl2 sc1: what this workgroup wrote leaves its XCD's L2)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (ROCm 7.2 may drop the wait behind the write-back: restated where the compiler cannot)
+    }
     const unsigned old = __hip_atomic_fetch_add(w + g * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (old == (unsigned)ng - 1) {                         // group leader = last arriver of the group
       __hip_atomic_store(w + g * 32, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -264,6 +272,7 @@ __device__ __forceinline__ void grid_barrier_xcd(unsigned int* state, int bid, i
     } else {
       gbar_spin(w + (8 + g) * 32, gen0, w + 18 * 32);
     }
+    if (FENCED) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // (buffer_inv sc1: nothing this CU cached before the barrier is served afterwards)
   }
   __syncthreads();
 }
