@@ -211,7 +211,16 @@ def step_checks(tr):
     found = float(tr.scaler._found) if (tr.scaler.is_enabled() and tr.scaler._found is not None) else 0.0
     if not ok or found != 0.0 or (scale is not None and scale < 65536.0):
         raise RuntimeError(f'invalid bench step: losses {vals}, loss scale {scale}, found_inf {found}')
-    return {'det_loss': vals[0], 'seg_loss_x_batch': vals[1], 'loss_scale': scale, 'optimizer_steps_skipped': 0}
+    # round 6: the launches with a device-wide barrier inside (myolo_conv_bn_act, myolo_bn_act_bwd_fused) bound every spin; a spin that gave
+    # up sets a sticky word in the plan's barrier block -- a step measured with it set would be garbage computed quickly
+    timeouts = 0
+    for h in getattr(tr, 'raw_model', tr.model).__dict__.get('_plans', {}).values():
+        bar = h.plan.__dict__.get('_grid_bar')
+        if bar is not None:
+            timeouts += int(bar[18 * 32])
+    if timeouts:
+        raise RuntimeError('invalid bench step: a grid barrier inside a fused launch timed out')
+    return {'det_loss': vals[0], 'seg_loss_x_batch': vals[1], 'loss_scale': scale, 'optimizer_steps_skipped': 0, 'grid_barrier_timeouts': 0}
 
 
 def train_py_step(tr):
