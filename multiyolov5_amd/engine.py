@@ -41,8 +41,10 @@ TINY_CONV = os.environ.get('MYOLO_TINY_CONV', '1') != '0'
 # inside (csrc/bn_act.hip bn_act_bwd_fused_kernel).  1: layers that run the two passes as launches of their own; 2: also instead of the
 # apply fold of a 1x1 dgrad (myolo_conv_dgrad_bn) where that layer's reduce pass is a launch of its own; 0: off
 BN_BWD_FUSED = int(os.environ.get('MYOLO_BN_BWD_FUSED', '2'))
-# round 6: training-mode Conv + BatchNorm + activation as ONE launch (myolo_conv_bn_act) for the layers whose tiles are all resident
-CONV_BN_ACT = os.environ.get('MYOLO_CONV_BN_ACT', '1') != '0'
+# round 6: training-mode Conv + BatchNorm + activation as ONE launch (myolo_conv_bn_act) for the layers whose tiles are all resident.  OPT-IN
+# (MYOLO_CONV_BN_ACT=1): in the step it measures neutral (7.72-7.735 against 7.71-7.72 ms, profiles/r6_conv_bn_act_step_ab.txt) -- the barrier costs
+# what the 6.4 us bn_act_fwd launch it replaces costs -- and a launch that needs every workgroup resident is the more fragile form
+CONV_BN_ACT = os.environ.get('MYOLO_CONV_BN_ACT', '0') != '0'
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -61,6 +63,15 @@ KC = {torch.float16: 32, torch.float32: 16}
 MID_RAGGED = os.environ.get('MYOLO_MID_RAGGED', '1') != '0'
 BN_STATS_IN_DGRAD = True            # fold bn_act_bwd_reduce into the dgrad that completes the layer's output gradient ...
 BN_STATS_MAX_ELEMS = 4 << 20        # ... for maps up to this many elements (round 5 re-measured 9 M / 17 M: +0.2 / +1.1 %)
+
+
+def barrier_launches_ok():
+    """the one-launch forms with a device-wide barrier inside (myolo_conv_bn_act, myolo_bn_act_bwd_fused) need their whole grid resident.  With
+    more than one rank RCCL's persistent collective kernels share the CUs during the backward (and their first call can sit in connection
+    set-up for seconds): a barrier launch would wait for them, possibly past its spin bound.  Nothing with more than one GPU could be measured
+    here, the forms are worth <= 0.3 % on one GPU -- so plans built under a process group of more than one rank use the two-launch forms."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
 
 
 def conv_pad(c, m, dt):
@@ -459,7 +470,7 @@ class ConvOp(Op):
             bn = self.bn
             # round 6 (north_star's "fused Conv+BN+SiLU", training mode): conv + batch statistics + device-wide barrier + BatchNorm +
             # activation (+ shortcut) in ONE launch where the library says every tile of the layer is resident (csrc/conv_mid.hip FUS)
-            self.fwd_fused = bool(CONV_BN_ACT and has_bn and dt == torch.float16 and self.sync_world == 1 and
+            self.fwd_fused = bool(CONV_BN_ACT and barrier_launches_ok() and has_bn and dt == torch.float16 and self.sync_world == 1 and
                                   L.lib().myolo_conv_bn_act_ok(C.byref(d)))
             if self.fwd_fused:
                 ff = self.ffuse = L.BnFwdFuse()
@@ -583,7 +594,7 @@ class ConvOp(Op):
                 # passes, every operand is a dense channel slice and the library says the tensor fits the resident grid
                 own_reduce = self.bn2 is not None or self.reduce_by is None
                 dense = all(t.sh == t.w * t.sw and t.sn == t.h * t.sh for t in (self.god, self.yd, self.dyd) + ((grd,) if grd.ptr else ()))
-                self.bwd_fused = bool(BN_BWD_FUSED and own_reduce and self.sync_world == 1 and dense and (BN_BWD_FUSED >= 2 or not fold_ok) and
+                self.bwd_fused = bool(BN_BWD_FUSED and barrier_launches_ok() and own_reduce and self.sync_world == 1 and dense and (BN_BWD_FUSED >= 2 or not fold_ok) and
                                       L.lib().myolo_bn_act_bwd_fused_ok(L.DT[dt], self.out.n * self.out.h * self.out.w, self.cout))
                 if self.bwd_fused:
                     bar = plan.grid_barrier()

@@ -261,8 +261,9 @@ class LaunchChecker:
     """with LaunchChecker(check_fn) as lc: run a forward (+ backward) with engine.NATIVE_EXEC off.  lc.n[name] counts the checked launches,
     lc.bad collects failures (check_fn = tests.gpu_util.check with collect=)."""
 
-    def __init__(self, check, tag, tol_out=3e-3, tol_stat=2e-3, tol_w=2e-3, every=1, bn=False):
+    def __init__(self, check, tag, tol_out=3e-3, tol_stat=2e-3, tol_w=2e-3, every=1, bn=False, only=None):
         self.check, self.tag, self.tol_out, self.tol_stat, self.tol_w = check, tag, tol_out, tol_stat, tol_w
+        self.only = only                       # names: evaluate only these launches (everything else just runs)
         self.bn = bn                           # also the BatchNorm forward / backward-reduce / backward-apply launches: every bn-th of them (True = 1)
         self.kbn = 0
         self.bad, self.n, self.k, self.every = [], {}, 0, every
@@ -274,6 +275,8 @@ class LaunchChecker:
         me = self
 
         def wrapped(call, st):
+            if me.only is not None and call.name not in me.only:
+                return me.orig(call, st)
             if call.name not in CONV_NAMES and not (me.bn and call.name in BN_NAMES):
                 return me.orig(call, st)
             if call.name in BN_NAMES:

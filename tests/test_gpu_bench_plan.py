@@ -47,7 +47,7 @@ def _dump_trace(tag):
     return tr
 
 
-def _train_step_checked(args, tag, expect, bn=False, every=1):
+def _train_step_checked(args, tag, expect, bn=False, every=1, only=None):
     import bench
     from multiyolov5_amd import _lib as L
     from tests.desc_ref import LaunchChecker
@@ -55,7 +55,7 @@ def _train_step_checked(args, tag, expect, bn=False, every=1):
     tr.step()                                   # builds the plan (native executor, as the bench runs it), moves the BatchNorm statistics once
     torch.cuda.synchronize()
     L.lib().myolo_trace_start(1)
-    with LaunchChecker(check, tag, bn=bn, every=every) as lc:
+    with LaunchChecker(check, tag, bn=bn, every=every, only=only) as lc:
         tr.step()
         torch.cuda.synchronize()
     sites = _dump_trace(tag)
@@ -78,6 +78,15 @@ def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32()
     fam = ' '.join(sites)
     for k in ('mid::launch', 'midx::launch', 'halo::launch', 'stream::launch', 'launch_conv4', 'wgt::launch'):     # every conv family DESIGN section 3 names
         assert k in fam, (k, sorted(sites))
+
+
+def test_the_opt_in_fused_conv_bn_silu_launches_of_the_benchmarked_step_match_torch_fp32(monkeypatch):
+    """engine.CONV_BN_ACT (MYOLO_CONV_BN_ACT=1, north_star's "fused Conv+BN+SiLU" in training mode): the 27 one-launch layers of BASELINE
+    configs[1] at their real tile counts -- raw output, statistics, saved / running statistics and the activation of every one of them against
+    torch fp32 over the operands the launch read, and the barrier's timeout word; the step's losses stay finite"""
+    from multiyolov5_amd import engine as E
+    monkeypatch.setattr(E, 'CONV_BN_ACT', True)
+    _train_step_checked(_args(), 'bench16_fused_fwd', {'myolo_conv_bn_act': 27}, only=('myolo_conv_bn_act',))
 
 
 def test_every_conv_launch_of_the_yolov5m_lab_share_matches_torch_fp32():

@@ -31,6 +31,10 @@ def _worker(rank, world, port, q):
         plan = h.plan
         buckets = plan.grad_buckets(red)
         total = plan.flat_grad.numel()
+        # round 6: plans built under a process group of more than one rank carry no launch with a device-wide barrier inside (RCCL's persistent
+        # kernels share the CUs: engine.barrier_launches_ok)
+        names = {c.name for op in plan.ops for c in list(op.fwd_calls) + list(op.bwd_calls) if hasattr(c, 'name')}
+        assert 'myolo_conv_bn_act' not in names and 'myolo_bn_act_bwd_fused' not in names
         # buckets tile the flat buffer exactly, and arrive in backward completion order (descending op index)
         assert sorted((lo, hi) for lo, hi, _ in buckets)[0][0] == 0
         cover = sorted((lo, hi) for lo, hi, _ in buckets)

@@ -449,14 +449,16 @@ def test_unchanged_detect_and_test_py_statements_reach_the_fused_argmax(monkeypa
     assert type(out) is torch.Tensor
 
 
-def test_benchmarked_plan_fuses_conv_bn_act_where_every_tile_is_resident():
+def test_benchmarked_plan_fuses_conv_bn_act_where_every_tile_is_resident(monkeypatch):
     """round 6: the dry-built plan of BASELINE configs[1] (16x3x512x1024, fp16).  Conv + batch statistics + BatchNorm + SiLU
-    (+ shortcut) is ONE launch (myolo_conv_bn_act: device-wide barrier inside) for the 1x1 and stride-2 Conv layers of the 32x64 and 16x32
+    (+ shortcut) is -- with engine.CONV_BN_ACT on -- ONE launch (myolo_conv_bn_act: device-wide barrier inside) for the 1x1 and stride-2 Conv layers of the 32x64 and 16x32
     maps -- the layers whose tiles are all resident at one 8-wave workgroup per CU; the larger maps and the 3x3 stride-1 layers (conv_midx) keep
     conv + bn_act_fwd.  The BatchNorm backward is one launch
     (reduce + barrier + apply) for the tensors of at most 256 register-resident workgroups."""
     from multiyolov5_amd import engine as E, runtime as R
     from multiyolov5_amd.models.yolo import Model
+    assert E.CONV_BN_ACT is False                      # opt-in (measured neutral in the step): MYOLO_CONV_BN_ACT=1
+    monkeypatch.setattr(E, 'CONV_BN_ACT', True)
     m = Model(os.path.join(CFG, TAGS['s_psp']))
     m.train()
     plan = R.PlanHolder(m, [torch.zeros(16, 3, 512, 1024)], ('t', 0), torch.float16, True).plan
