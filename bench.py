@@ -778,7 +778,8 @@ def main():
             return round(v, 3) if isinstance(v, (int, float)) else None
         short = {'fps_2048x1024': num(('detect_fps', 'value')), 'fps_1024x512': num(('detect_fps_1024x512', 'value')),
                  'm_lab_bs8_img_s': num(('train_m_lab', 'value')), 'train_py_pairs_s': num(('train_py_step', 'pairs_per_s')),
-                 'conv_roofline_frac': num(('roofline', 'frac')), 'step_roofline_frac': num(('whole_step_roofline', 'frac')),
+                 'conv_roofline_frac': num(('roofline', 'frac')), 'conv_roofline_frac_r5_convention': num(('roofline', 'with_batchnorm_riders', 'frac')),
+                 'step_roofline_frac': num(('whole_step_roofline', 'frac')),
                  'cpu_port_img_s': num(('cpu_baseline', 'value')), 'stock_rocm_img_s': num(('stock_rocm_baseline', 'train', 'images_per_s'))}
         head = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step')
         line = {k: out[k] for k in head if k in out}
