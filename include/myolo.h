@@ -211,6 +211,20 @@ typedef struct myolo_wgrad_desc {
 } myolo_wgrad_desc;
 int myolo_conv_wgrad(const myolo_wgrad_desc* d, void* stream);
 
+/* Round 6: the STEM layer's BatchNorm backward and weight gradient in one pass (csrc/stem_wgrad.hip).  A Conv + BatchNorm + SiLU layer whose
+ * input needs no gradient (the network's first layer, reference models/common.py:540-551 Focus.conv) has ONE reader of its dy: its own weight
+ * gradient.  dy is linear in sums that need no second pass over the tensors -- dW = sc * (sum g(x)x - k0 * sum x - k1 * sum xhat(x)x), g = gout *
+ * silu'(z), xhat = (y - mean) * invstd, k0 / k1 = the BatchNorm-backward means -- so bn_act_bwd_reduce + bn_act_bwd_apply + myolo_conv_wgrad
+ * (three launches over the step's largest tensors, at the very end of the backward) become one pass over gout, y, x plus two tiny launches:
+ *   dw (+)= autograd's weight gradient of conv -> BatchNorm(train) -> SiLU for the output gradient `gout`;  dgamma += sum g * xhat;  dbeta += sum g.
+ * d: x, dw, the nine taps, cout / cin, ksplit (0: 768 workgroups); d->dy is NOT read (dy never exists), d->db must be NULL.  3x3, stride 1,
+ * fp16, <= 32 output and <= 16 input channels, map height % 8 == 0 and width % 16 == 0 (myolo_bn_wgrad_stem_ok); `ws`: caller-owned scratch of
+ * myolo_bn_wgrad_stem_ws_bytes() bytes that no other launch in flight uses. */
+int myolo_bn_wgrad_stem_ok(const myolo_wgrad_desc* d, const myolo_tensor* gout);
+int64_t myolo_bn_wgrad_stem_ws_bytes(void);
+int myolo_bn_wgrad_stem(const myolo_wgrad_desc* d, const myolo_tensor* gout, const myolo_tensor* y, const float* saved, const float* gamma,
+                        const float* beta, int act, float* dgamma, float* dbeta, float* ws, int64_t ws_bytes, void* stream);
+
 /* ---- BatchNorm(+SiLU)(+residual) around a raw conv output (training mode) ----------------------
  * fwd: nn.BatchNorm2d batch-stat path + nn.SiLU + Bottleneck add (common.py:43,105), eps/momentum from
  * initialize_weights (torch_utils.py:150-151).  `stats` are the sums produced by myolo_conv (MYOLO_STAT_COPIES copies).

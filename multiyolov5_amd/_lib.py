@@ -136,6 +136,9 @@ _PROTOS = {
     'myolo_conv_bn_act_ok': (C.c_int, [C.POINTER(ConvDesc)]),
     'myolo_conv_bn_act': (C.c_int, [C.POINTER(ConvDesc), C.POINTER(BnFwdFuse), P]),
     'myolo_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), P]),
+    'myolo_bn_wgrad_stem_ok': (C.c_int, [C.POINTER(WgradDesc), TP]),
+    'myolo_bn_wgrad_stem_ws_bytes': (C.c_int64, []),
+    'myolo_bn_wgrad_stem': (C.c_int, [C.POINTER(WgradDesc), TP, TP, P, P, P, C.c_int, P, P, P, C.c_int64, P]),
     'myolo_bn_act_fwd': (C.c_int, [TP, P, P, P, P, P, P, P, C.c_float, C.c_float, C.c_int, TP, TP, P]),
     'myolo_bn_act_bwd_reduce': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P]),
     'myolo_bn_act_bwd_apply': (C.c_int, [TP, TP, P, P, P, C.c_int, P, P, P, TP, TP, C.c_int, P]),

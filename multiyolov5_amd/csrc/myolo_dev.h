@@ -305,7 +305,8 @@ int myolo_bnb_fallback(const myolo_conv_desc* d, const myolo_tensor* gout_full, 
 
 // bn_act.hip: "bn_fused" (0 off / 1 on), "bn_fused_cap" (largest resident grid of the one-launch BatchNorm backward)
 int myolo_bn_set(const char* name, int value);
-int myolo_pool_set(const char* name, int value);      // pool_resize.hip: "spp_naive"
+int myolo_pool_set(const char* name, int value);
+int myolo_stem_set(const char* name, int value);      // stem_wgrad.hip: "stem_wgrad" (0 off), "stem_ks" (workgroups)      // pool_resize.hip: "spp_naive"
 // conv_stream.hip: streaming variant of myolo_conv; -1 = layer does not qualify
 int myolo_conv_stream_try(const myolo_conv_desc* d, void* stream, int* bnb_done);
 // conv_halo.hip: LDS-staged input tiles for k x k stride-1 convolutions; -1 = layer does not qualify

@@ -48,7 +48,7 @@ template <class... Args> constexpr int nargs_of(int (*)(Args...)) { return (int)
 #define REG(f) {#f, [](const uint64_t* a, void* st) -> int { return call_packed(&f, a, st); }, nargs_of(&f)}
 const Entry g_table[] = {
     REG(myolo_pack_weight), REG(myolo_pack_weights_mt), REG(myolo_focus_pack), REG(myolo_conv), REG(myolo_conv_dgrad_s2), REG(myolo_conv_dgrad_bn), REG(myolo_conv_pair), REG(myolo_conv_bn_act),
-    REG(myolo_conv_wgrad), REG(myolo_bn_act_fwd), REG(myolo_bn_act_bwd_reduce), REG(myolo_bn_act_bwd_apply),
+    REG(myolo_conv_wgrad), REG(myolo_bn_wgrad_stem), REG(myolo_bn_act_fwd), REG(myolo_bn_act_bwd_reduce), REG(myolo_bn_act_bwd_apply),
     REG(myolo_bn_act_fwd_split), REG(myolo_bn_act_bwd_reduce_split), REG(myolo_bn_act_bwd_apply_split), REG(myolo_bn_act_bwd_fused), REG(myolo_spp_pool_fwd),
     REG(myolo_spp_pool_bwd), REG(myolo_copy_up_fwd), REG(myolo_copy_up_bwd), REG(myolo_bilinear_fwd), REG(myolo_bilinear_bwd),
     REG(myolo_adaptive_avgpool_fwd), REG(myolo_adaptive_avgpool_fwd_multi), REG(myolo_adaptive_avgpool_bwd), REG(myolo_adaptive_avgpool_bwd_multi),

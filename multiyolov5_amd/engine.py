@@ -45,6 +45,8 @@ BN_BWD_FUSED = int(os.environ.get('MYOLO_BN_BWD_FUSED', '2'))
 # (MYOLO_CONV_BN_ACT=1): in the step it measures neutral (7.72-7.735 against 7.71-7.72 ms, profiles/r6_conv_bn_act_step_ab.txt) -- the barrier costs
 # what the 6.4 us bn_act_fwd launch it replaces costs -- and a launch that needs every workgroup resident is the more fragile form
 CONV_BN_ACT = os.environ.get('MYOLO_CONV_BN_ACT', '0') != '0'
+# round 6: the first layer's BatchNorm backward + weight gradient as one pass over (gout, y, x) (myolo_bn_wgrad_stem)
+STEM_WGRAD = os.environ.get('MYOLO_STEM_WGRAD', '1') != '0'
 
 # MYOLO_NATIVE_EXEC=0: issue the launch lists one ctypes call at a time from Python (rounds 1-2) instead of through the native
 # executor (csrc/plan_exec.hip: one C call per launch list)
@@ -726,6 +728,30 @@ class ConvOp(Op):
             calls.append(Call('myolo_conv_wgrad', (C.byref(wd),), side=True))
             c0 += co
         self.wd = self.wds[0]
+        self._fuse_stem(plan, calls, two_pass, has_bn)
+
+    def _fuse_stem(self, plan, calls, two_pass, has_bn):
+        """round 6: a Conv + BatchNorm + SiLU layer WITHOUT an input gradient (the network's first layer) ends the backward with reduce -> apply ->
+        weight gradient over the step's largest tensors; dy has one reader and is linear in sums one pass can form, so the three launches
+        become `myolo_bn_wgrad_stem` (csrc/stem_wgrad.hip) on the MAIN stream (it is the critical tail; the side stream still holds the layer
+        above's weight gradient)."""
+        self.stem_fused = False
+        if not (STEM_WGRAD and two_pass and has_bn and not self.x.requires_grad and self.bn2 is None and self.weight2 is None and
+                self.sync_world == 1 and self.bias is None and self.act == L.ACT_SILU and plan.dtype == torch.float16 and
+                self.reduce_by is None and not getattr(self, 'bwd_fused', False) and not self.grd.ptr and len(self.wds) == 1):
+            return
+        names = [getattr(c, 'name', None) for c in calls]
+        want = ['myolo_bn_act_bwd_reduce', 'myolo_bn_act_bwd_apply', 'myolo_conv_wgrad']
+        if names[-3:] != want or not L.lib().myolo_bn_wgrad_stem_ok(C.byref(self.wd), C.byref(self.god)):
+            return
+        bn = self.bn
+        nbytes = int(L.lib().myolo_bn_wgrad_stem_ws_bytes())
+        self.stem_ws = torch.empty(nbytes // 4, dtype=torch.float32, device=plan.device)      # (its own scratch: the side stream's weight gradients own the plan's)
+        del calls[-3:]
+        calls.append(Call('myolo_bn_wgrad_stem', (C.byref(self.wd), C.byref(self.god), C.byref(self.yd), L.ptr(self.saved), L.ptr(bn.weight), L.ptr(bn.bias),
+                                                   self.act, L.ptr(plan.pgrad(bn.weight)), L.ptr(plan.pgrad(bn.bias)), L.ptr(self.stem_ws),
+                                                   C.c_int64(nbytes))))
+        self.stem_fused = True
 
 
 class SimpleOp(Op):
@@ -2195,6 +2221,9 @@ def call_algorithmic_bytes(call):
     if n in ('myolo_bn_act_bwd_apply', 'myolo_bn_act_bwd_apply_split'):
         g, gres = a[0], a[10]
         return _tensor_bytes(g) * 3 + (_tensor_bytes(gres) if gres.ptr else 0)
+    if n == 'myolo_bn_wgrad_stem':          # (the operand count of the three launches it replaces: reduce 2, apply 3, weight gradient x + dy + dw)
+        d, g = a[0], a[1]
+        return _tensor_bytes(g) * 5
     if n == 'myolo_bn_act_bwd_fused':       # (the operand count of the two launches it replaces: the family totals stay comparable across builds)
         g, gres = a[0], a[10]
         return _tensor_bytes(g) * 5 + (_tensor_bytes(gres) if gres.ptr else 0)
@@ -2206,7 +2235,7 @@ def plan_algorithmic_bytes(plan):
     out = {'conv': 0, 'wgrad': 0, 'batchnorm': 0}
     fam = {'myolo_conv': 'conv', 'myolo_conv_dgrad_s2': 'conv', 'myolo_conv_dgrad_bn': 'conv', 'myolo_conv_bn_act': 'conv', 'myolo_conv_wgrad': 'wgrad', 'myolo_bn_act_fwd': 'batchnorm', 'myolo_bn_act_bwd_reduce': 'batchnorm',
            'myolo_bn_act_bwd_apply': 'batchnorm', 'myolo_bn_act_fwd_split': 'batchnorm', 'myolo_bn_act_bwd_reduce_split': 'batchnorm',
-           'myolo_bn_act_bwd_apply_split': 'batchnorm', 'myolo_bn_act_bwd_fused': 'batchnorm'}
+           'myolo_bn_act_bwd_apply_split': 'batchnorm', 'myolo_bn_act_bwd_fused': 'batchnorm', 'myolo_bn_wgrad_stem': 'batchnorm'}
     for op in plan.ops:
         for c in list(op.fwd_calls) + list(op.bwd_calls):
             b = call_algorithmic_bytes(c)

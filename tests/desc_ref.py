@@ -195,16 +195,17 @@ def apply_fold_ref(d, f):
     return sc * dz + cb * y + cd, d0, d1
 
 
-def wgrad_ref(wd):
-    """dW[co,ci,t] = sum_pixels dy[n,oy,ox,co] * x[n,oy*s+dy_t,ox*s+dx_t,ci]; db[co] = sum dy"""
-    x, dy = read_tensor(wd.x), read_tensor(wd.dy)
+def wgrad_ref(wd, dy=None):
+    """dW[co,ci,t] = sum_pixels dy[n,oy,ox,co] * x[n,oy*s+dy_t,ox*s+dx_t,ci]; db[co] = sum dy  (dy: given instead of read from wd.dy)"""
+    x = read_tensor(wd.x)
+    dy = read_tensor(wd.dy) if dy is None else dy
     if wd.up_shift:
         r = 1 << wd.up_shift
         x = x.repeat_interleave(r, 1).repeat_interleave(r, 2)
-    cout = wd.cout if wd.cout > 0 else wd.dy.c
+    cout = wd.cout if wd.cout > 0 else dy.shape[-1]
     cin = wd.cin if wd.cin > 0 else wd.x.c
     nt = wd.ntaps
-    N, Ho, Wo = wd.dy.n, wd.dy.h, wd.dy.w
+    N, Ho, Wo = dy.shape[0], dy.shape[1], dy.shape[2]
     dyf = dy[..., :cout].reshape(-1, cout)
     out = torch.zeros(cout, cin, nt)
     for t, sl in enumerate(_shifted(x[..., :cin], list(wd.tap_dy[:nt]), list(wd.tap_dx[:nt]), Ho, Wo, wd.stride)):
@@ -254,7 +255,7 @@ def bn_fwd_ref(y, stats, gamma, beta, eps, act, res):
 
 BN_NAMES = ('myolo_bn_act_fwd', 'myolo_bn_act_fwd_split', 'myolo_bn_act_bwd_reduce', 'myolo_bn_act_bwd_reduce_split', 'myolo_bn_act_bwd_apply',
             'myolo_bn_act_bwd_apply_split', 'myolo_bn_act_bwd_fused')
-CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair', 'myolo_conv_bn_act')
+CONV_NAMES = ('myolo_conv', 'myolo_conv_dgrad_s2', 'myolo_conv_dgrad_bn', 'myolo_conv_wgrad', 'myolo_conv_pair', 'myolo_conv_bn_act', 'myolo_bn_wgrad_stem')
 
 
 class LaunchChecker:
@@ -383,6 +384,33 @@ class LaunchChecker:
                 rv1 = _split_vec(f.running_var, split.running_var2 if split else None, C, B.cs)
                 self._ck(what + '/running_mean', rm1, ((1 - mom) * rm0.double() + mom * mean).float(), 1e-4)
                 self._ck(what + '/running_var', rv1, ((1 - mom) * rv0.double() + mom * var * M / max(M - 1, 1)).float(), 1e-4)
+        elif name == 'myolo_bn_wgrad_stem':
+            # round 6: BatchNorm backward + weight gradient of the first layer in one pass.  dy never exists on the device: the reference forms it in
+            # fp64 from (gout, y, saved, gamma, beta) -- autograd of BatchNorm (train) + SiLU -- and contracts it with x
+            a = call.args
+            wd, god, yd = self._desc(a[0]), self._desc(a[1]), self._desc(a[2])
+            C = god.c
+            M = god.n * god.h * god.w
+            gout, y = read_tensor(god).double(), read_tensor(yd).double()
+            sv = read_f32(a[3], 2 * C).double()
+            mean, invstd = sv[:C], sv[C:]
+            gamma, beta = read_f32(a[4], C).double(), read_f32(a[5], C).double()
+            xhat = (y - mean) * invstd
+            z = xhat * gamma + beta
+            sg = torch.sigmoid(z)
+            g = gout * (sg * (1 + z * (1 - sg)))
+            d0, d1 = g.sum((0, 1, 2)), (g * xhat).sum((0, 1, 2))
+            dy_ref = (gamma * invstd) * (g - d0 / M - xhat * d1 / M)
+            ref_w, _ = wgrad_ref(wd, dy=dy_ref.float())
+            cin = wd.cin if wd.cin > 0 else wd.x.c
+            n = C * cin * wd.ntaps
+            w0, g0, b0 = read_f32(wd.dw, n), read_f32(a[7], C), read_f32(a[8], C)
+            self.orig(call, st)
+            torch.cuda.synchronize()
+            what = f'bn_wgrad_stem[{wd.x.n}x{wd.x.h}x{wd.x.w}x{cin}->{C} t{wd.ntaps}]#{self.k}'
+            self._ck(what + '/dw', read_f32(wd.dw, n) - w0, ref_w.reshape(-1), self.tol_w)
+            self._ck(what + '/dgamma', read_f32(a[7], C) - g0, d1.float(), self.tol_stat)
+            self._ck(what + '/dbeta', read_f32(a[8], C) - b0, d0.float(), self.tol_stat)
         elif name == 'myolo_conv_pair':         # myolo.h: b(a(x)), the intermediate rounded to the storage type, a->y not necessarily written
             a, b = self._desc(call.args[0]), self._desc(call.args[1])
             t = conv_epilogue(a, conv_acc(a))
