@@ -89,18 +89,19 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
     x_on[l] = hp < HH * HW && (v & 1) * SEG < p.Cin;
     x_hy[l] = hp / HW - 1; x_hx[l] = hp % HW - 1;
   }
-  // this thread's 8 channels: z = y * sc + sh, xhat = y * is + mb
-  float sc[SEG], sh[SEG], is[SEG], mb[SEG], s0[SEG], s1[SEG], sx[2][SEG];
-#pragma unroll
-  for (int i = 0; i < SEG; ++i) {
-    const int c = cd + i;
-    const bool in = c < p.Cout;
-    const float mean = in ? p.saved[c] : 0.f, istd = in ? p.saved[p.Cout + c] : 0.f;
-    sc[i] = in ? p.gamma[c] * istd : 0.f;
-    sh[i] = in ? p.beta[c] - mean * sc[i] : 0.f;
-    is[i] = istd; mb[i] = -mean * istd;
-    s0[i] = 0.f; s1[i] = 0.f; sx[0][i] = 0.f; sx[1][i] = 0.f;
+  // per-channel constants in LDS ([4][32]: z = y * sc + sh, xhat = y * is + mb), read once per tile: 32 registers less per thread is what
+  // lets three workgroups share a CU without scratch (the kernel is latency-bound: 2 per CU measured 160 us, HBM needs 85)
+  __shared__ float sK[4][32];
+  if (tid < 32) {
+    const bool in = tid < p.Cout;
+    const float mean = in ? p.saved[tid] : 0.f, istd = in ? p.saved[p.Cout + tid] : 0.f;
+    const float scv = in ? p.gamma[tid] * istd : 0.f;
+    sK[0][tid] = scv; sK[1][tid] = in ? p.beta[tid] - mean * scv : 0.f; sK[2][tid] = istd; sK[3][tid] = -mean * istd;
   }
+  __syncthreads();
+  float s0[SEG], s1[SEG], sx[2][SEG];
+#pragma unroll
+  for (int i = 0; i < SEG; ++i) { s0[i] = 0.f; s1[i] = 0.f; sx[0][i] = 0.f; sx[1][i] = 0.f; }
   // two tiles of loads in flight per thread (as wgrad_small_halo_kernel: the MFMAs of a tile take a fraction of the HBM latency)
   uint4 rg[2][2], ry[2][2], rx[2][2];
   auto issue = [&](int s, const int b) {
@@ -129,9 +130,16 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
   for (int t = 0; t < NT; ++t) tap_b[t] = (p.tap_dy[t] * HW + p.tap_dx[t]) * PX;
 
   auto step = [&](int s, const int b) {
+    float sc[SEG], sh[SEG], is[SEG], mb[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) { sc[i] = sK[0][cd + i]; sh[i] = sK[1][cd + i]; is[i] = sK[2][cd + i]; mb[i] = sK[3][cd + i]; }
 #pragma unroll
     for (int l = 0; l < 2; ++l) {
       const int v = tid + l * THREADS;
+      // (one piece at a time: the packed registers become "new" values behind the previous piece's last accumulate, or hipcc converts and
+      //  transforms both pieces side by side -- 32 more live registers)
+      asm volatile("" : "+v"(rg[b][l].x), "+v"(rg[b][l].y), "+v"(rg[b][l].z), "+v"(rg[b][l].w), "+v"(s0[0]), "+v"(s1[SEG - 1]));
+      asm volatile("" : "+v"(ry[b][l].x), "+v"(ry[b][l].y), "+v"(ry[b][l].z), "+v"(ry[b][l].w), "+v"(s0[0]));
       float fg[SEG], fy[SEG], gv[SEG], xh[SEG];
       Vec<half_t>::unpack(rg[b][l], fg); Vec<half_t>::unpack(ry[b][l], fy);
 #pragma unroll
@@ -165,18 +173,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int e = 0; e < 4; ++e) fa[4 * h + e] = (half_t)va[e];
       }
+      // all nine taps' fragments in flight before the first MFMA (one tap at a time was a read -> ~300-cycle wait -> one MFMA chain:
+      // 36 of them per tile and wave)
+      h8_t fb[NT];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        h8_t fb;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           fp16x4_t vb = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
               (__attribute__((address_space(3))) fp16x4_t*)(&sX[(hb + 4 * h) * PX + tap_b[t] + q * 8]));
 #pragma unroll
-          for (int e = 0; e < 4; ++e) fb[4 * h + e] = (half_t)vb[e];
+          for (int e = 0; e < 4; ++e) fb[t][4 * h + e] = (half_t)vb[e];
         }
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb, acc[t], 0, 0, 0);
       }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[t], acc[t], 0, 0, 0);
     }
     __syncthreads();
   };
@@ -211,40 +222,49 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(2, 2)))
   }
 }
 
-// totals[e] = sum over the splits of ws[s][e]: a workgroup owns 64 consecutive entries, its 4 waves take every 4th split
+// totals[e] = sum over the splits of ws[s][e]: a workgroup owns 64 consecutive entries, its 4 waves take every 4th split, 8 loads in flight per
+// lane (two in flight: 23 us for 512 splits -- one L2 round trip per pair)
 __global__ __launch_bounds__(256) void stem_reduce_kernel(const float* __restrict__ ws, float* __restrict__ tot, int ks) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = blockIdx.x * 64 + lane;
-  float a0 = 0.f, a1 = 0.f;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (e < WS_SPLIT) {
     int s = wave;
-    for (; s + 4 < ks; s += 8) { a0 += ws[(int64_t)s * WS_SPLIT + e]; a1 += ws[(int64_t)(s + 4) * WS_SPLIT + e]; }
-    if (s < ks) a0 += ws[(int64_t)s * WS_SPLIT + e];
+    for (; s + 28 < ks; s += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] += ws[(int64_t)(s + 4 * u) * WS_SPLIT + e];
+    }
+    for (; s < ks; s += 4) a[0] += ws[(int64_t)s * WS_SPLIT + e];
   }
-  red[wave][lane] = a0 + a1;
+  red[wave][lane] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (wave == 0 && e < WS_SPLIT) tot[e] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
 }
 
-// dW[co][ci][t] += sc[co] * (A - k0[co] * S[t][ci] - k1[co] * B); dgamma += sum g * xhat; dbeta += sum g.  One workgroup.
+// dW[co][ci][t] += sc[co] * (A - k0[co] * S[t][ci] - k1[co] * B); dgamma += sum g * xhat; dbeta += sum g.  One workgroup; the totals (48 KB)
+// go through LDS once (reading them where needed was 180 dependent L2 loads per thread: 32 us).
 __global__ __launch_bounds__(256) void stem_combine_kernel(const float* __restrict__ tot, const StemK p, float* dw, float* dgamma, float* dbeta, int cout_w,
                                                            int cin_w, float rM) {
+  __shared__ __attribute__((aligned(16))) float T[WS_SPLIT];
   __shared__ float S[NT][16];
   __shared__ float k0[32], k1[32], scs[32];
   const int tid = threadIdx.x;
+  static_assert(WS_SPLIT % 4 == 0, "vector copy");
+  for (int j = tid; j < WS_SPLIT / 4; j += 256) reinterpret_cast<f4_t*>(T)[j] = reinterpret_cast<const f4_t*>(tot)[j];
+  __syncthreads();
   for (int j = tid; j < NT * 16; j += 256) {
     const int t = j >> 4, ci = j & 15;
     float a = 0.f;
     for (int hp = 0; hp < HH * HW; ++hp) {                 // halo pixel (hy, hx) feeds tap t iff the output pixel (hy - dy, hx - dx) is inside the tile
       const int oy = hp / HW - 1 - p.tap_dy[t], ox = hp % HW - 1 - p.tap_dx[t];
-      if (oy >= 0 && oy < TH && ox >= 0 && ox < TW) a += tot[WS_ACC + WS_SUM + (hp * 2 + (ci >> 3)) * 8 + (ci & 7)];
+      if (oy >= 0 && oy < TH && ox >= 0 && ox < TW) a += T[WS_ACC + WS_SUM + (hp * 2 + (ci >> 3)) * 8 + (ci & 7)];
     }
     S[t][ci] = a;
   }
   if (tid < 32) {
     const bool in = tid < p.Cout;
-    const float d0 = in ? tot[WS_ACC + tid] : 0.f, d1 = in ? tot[WS_ACC + 32 + tid] : 0.f;
+    const float d0 = in ? T[WS_ACC + tid] : 0.f, d1 = in ? T[WS_ACC + 32 + tid] : 0.f;
     k0[tid] = d0 * rM; k1[tid] = d1 * rM;
     scs[tid] = in ? p.gamma[tid] * p.saved[p.Cout + tid] : 0.f;
     if (in) {
@@ -257,8 +277,8 @@ __global__ __launch_bounds__(256) void stem_combine_kernel(const float* __restri
     const int t = e % NT, ci = (e / NT) % cin_w, co = e / (NT * cin_w);
     // accumulator image: [row fragment f][tap][lane][r] with row = 4 * (lane >> 4) + r, column ci = lane & 15; g rows: f = co >> 4, xhat rows: 2 + (co >> 4)
     const int row = co & 15, ln = (row >> 2) * 16 + ci, r = row & 3;
-    const float A = tot[(((co >> 4) * NT + t) * 64 + ln) * 4 + r];
-    const float B = tot[(((2 + (co >> 4)) * NT + t) * 64 + ln) * 4 + r];
+    const float A = T[(((co >> 4) * NT + t) * 64 + ln) * 4 + r];
+    const float B = T[(((2 + (co >> 4)) * NT + t) * 64 + ln) * 4 + r];
     dw[e] += scs[co] * (A - k0[co] * S[t][ci] - k1[co] * B);
   }
 }

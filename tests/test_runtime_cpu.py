@@ -473,4 +473,8 @@ def test_benchmarked_plan_fuses_conv_bn_act_where_every_tile_is_resident(monkeyp
     merged = [op for op in fused if op.weight2 is not None]
     assert len(merged) == 5 and all(op.ffuse.split.contents.c_split == op.c1out for op in merged)      # C3's cv1 | cv2 pairs: two parameter sets
     assert bwd['myolo_bn_act_bwd_fused'] == 7
+    # the first layer (no input gradient): BatchNorm backward + weight gradient are ONE pass over (gout, y, x) on the main stream
+    stem = [op for op in plan.ops if getattr(op, 'stem_fused', False)]
+    assert bwd['myolo_bn_wgrad_stem'] == 1 and len(stem) == 1 and not stem[0].x.requires_grad and (stem[0].out.h, stem[0].out.w, stem[0].cout) == (256, 512, 32)
+    assert [c.name for c in stem[0].bwd_calls] == ['myolo_bn_wgrad_stem'] and not stem[0].bwd_calls[0].side
     del plan, m
