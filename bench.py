@@ -42,6 +42,8 @@ def parse():
                     help="dev only: 'fwdbwd' = model fwd+bwd with fixed output gradients (no loss/optimizer; NOT a valid "
                          "bench line), 'infer' = detect.py path FPS only")
     ap.add_argument('--infer-size', type=int, nargs=2, default=(1024, 2048), help="--stage infer: frame H W")
+    ap.add_argument('--eval-fork', default=None, choices=['sem', 'event'],
+                    help="--stage infer: how the segmentation head's stream is ordered behind the neck (runtime.EVAL_FORK; A/B of round 6's semaphore)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-infer', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -311,6 +313,9 @@ def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
     from multiyolov5_amd.models.yolo import Model
     from multiyolov5_amd.utils.general import non_max_suppression, seg_argmax
     from multiyolov5_amd import synth
+    if getattr(args, 'eval_fork', None):
+        from multiyolov5_amd import runtime as _R
+        _R.EVAL_FORK = args.eval_fork
     m = Model(os.path.join(ROOT, 'multiyolov5_amd', 'cfg', 'yolov5s_city_seg.yaml'))
     synth.randomize_(m, seed=0)
     import contextlib

@@ -628,6 +628,19 @@ uint64_t* myolo_prog_slot(void* prog, int op, int arg);        /* address of one
 int   myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream);  /* 0 or the failing launch's error */
 int   myolo_prog_last_op(void* prog);              /* index of the op the last failing run stopped at */
 
+/* ---- order between two HIP streams without an event (csrc/plan_exec.hip) --------------------------------------------------
+ * The eval forward of models/yolo.py:293-316 has two independent tails behind the neck (Detect, the segmentation head): they run
+ * on two streams.  A hipStreamWaitEvent between them costs 90-170 us per frame on this runtime; a counting semaphore in device
+ * memory costs about one.  sem: MYOLO_QUEUE_SEM_BYTES of zeroed device memory, 4-byte aligned (word 0 = count, word 32 = polls
+ * that ran into timeout_ms: the consumer went on WITHOUT its dependency -- the caller must check it before trusting results).
+ * myolo_queue_post: a one-lane kernel on `stream` that adds 1 behind everything enqueued on it so far.  myolo_queue_wait: a
+ * one-lane kernel on `stream` that polls until the count is positive, takes 1, and only then lets that stream's later kernels
+ * start.  Both are capturable into hipGraphs.  Enqueue the post BEFORE the wait when both streams may share a hardware queue
+ * (HIP maps streams onto GPU_MAX_HW_QUEUES queues): a poll in front of its own producer only ends by its timeout. */
+#define MYOLO_QUEUE_SEM_BYTES 256
+int myolo_queue_post(void* sem, void* stream);
+int myolo_queue_wait(void* sem, int timeout_ms, void* stream);
+
 /* ---- launch trace (test infrastructure; no reference counterpart) ----------------------------------------------------------
  * The dispatchers behind myolo_conv / myolo_conv_wgrad / ... pick a kernel family and a template variant (tile shape, ring
  * depth, epilogue flags) from the descriptor.  myolo_trace_start(1) clears the table and makes every launch site record

@@ -95,6 +95,7 @@ class SgdHyper(C.Structure):
 
 
 PROG_MAX_ARGS = 24
+QUEUE_SEM_BYTES = 256   # include/myolo.h MYOLO_QUEUE_SEM_BYTES
 OP_CALL, OP_CALL_SIDE, OP_JOIN, OP_MEMSET = 0, 1, 2, 3
 
 
@@ -211,6 +212,8 @@ _PROTOS = {
     'myolo_prog_slot': (C.POINTER(C.c_uint64), [C.c_void_p, C.c_int, C.c_int]),
     'myolo_prog_run': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     'myolo_prog_last_op': (C.c_int, [C.c_void_p]),
+    'myolo_queue_post': (C.c_int, [P, P]),
+    'myolo_queue_wait': (C.c_int, [P, C.c_int, P]),
     'myolo_trace_start': (C.c_int, [C.c_int]),
     'myolo_trace_read': (C.c_int64, [C.c_char_p, C.c_int64]),
     'myolo_nms_ws_bytes': (C.c_int64, [C.c_int, C.c_int]),

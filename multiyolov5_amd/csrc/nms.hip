@@ -794,6 +794,15 @@ __global__ __launch_bounds__(256) void nms_merge_kernel(const int* aux, const in
   }
 }
 
+// the launch sequence's counters back to zero in ONE launch (two hipMemsetAsync commands cost the detect.py frame ~30 us of queue bubbles between
+// Detect's decode and the filter kernel, profiles/r6_infer_fork_*.txt: rocclr fill commands do not pack behind kernels)
+__global__ __launch_bounds__(256) void nms_clear_kernel(int* __restrict__ counts, int batch, int* __restrict__ aux, int naux) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < batch + naux; i += gridDim.x * 256) {
+    if (i < batch) counts[i] = 0;
+    else aux[i - batch] = 0;
+  }
+}
+
 }  // namespace
 
 int g_nms_dbg = 0;      // myolo_set_option("nms_dbg", bits): profiling only
@@ -815,8 +824,7 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
     return MYOLO_EINVAL;
   static_assert(RANK_SKIP_BELOW == SORT_MAX && SORT_MAX == (1 << SLOT_BITS), "LDS sort key layout");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(counts, 0, batch * sizeof(int32_t), st);
-  if (e != hipSuccess) return (int)e;
+  hipError_t e = hipSuccess;
   // lists of up to SORT_MAX candidates (single label, cap == A): rank / scatter / bit matrix on the whole device + the one-wave scan
   const bool matrix = !sort_ws && mws && !((uintptr_t)mws & 15) && mws_bytes >= myolo_nms_ws_bytes(batch, cap) && cap == A &&
                       (int64_t)cap <= (1ll << IDX_BITS) && max_det <= 64 * MS_KR && !(g_nms_dbg & 16);
@@ -830,9 +838,9 @@ extern "C" int myolo_nms(const void* pred, int dtype, int batch, int A, int no, 
   int* aux = matrix ? kpos + (int64_t)batch * SORT_MAX : nullptr;
   // class on top of the sort key (classes are then suppressed side by side): single label (cap == A), class id and row must fit the key
   const int keymode = (matrix && !agnostic && no - 5 <= NMS_MAXC && A < (1 << 24) && !(g_nms_dbg & 32)) ? 1 : 0;
-  if (matrix) {
-    e = hipMemsetAsync(aux, 0, (size_t)batch * NMS_AUX_INTS * sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
+  {
+    const int naux = matrix ? batch * NMS_AUX_INTS : 0;
+    hipLaunchKernelGGL(nms_clear_kernel, dim3(grid_for(batch + naux, 256, 64)), dim3(256), 0, st, counts, batch, aux, naux);
   }
   const int es = dtype == MYOLO_F16 ? 2 : 4;
   const int filter_smem = 256 * no * es + 32;

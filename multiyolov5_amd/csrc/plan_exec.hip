@@ -115,6 +115,28 @@ extern "C" uint64_t* myolo_prog_slot(void* prog, int op, int arg) {
 
 extern "C" int myolo_prog_last_op(void* prog) { return prog ? static_cast<Prog*>(prog)->last_op : -1; }
 
+// MEMSET ops are a kernel of this library, not hipMemsetAsync: (1) a memset NODE of a captured graph is re-issued through the runtime's blit path
+// on every replay, and in the detect.py loop (graph replays + NMS's own launches in between) it stopped clearing the forward's fp32 accumulators after
+// a few hundred frames in about half of the processes -- whatever the fork mechanism, until the runtime's kernel-argument pool wrapped the next time
+// (scripts/ubench/fork_stress.py, profiles/r6_fork_stress.txt: the segmentation head's pooled sums grew to inf); a kernel node carries its own
+// arguments; (2) rocclr fill commands do not pack behind kernels: ~4 us of queue bubble each.
+namespace {
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p16, size_t n16, unsigned int* __restrict__ tail, int ntail) {
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p16[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+}
+int zero_fill(void* ptr, size_t bytes, hipStream_t st) {
+  if (!bytes) return 0;
+  if (!ptr || ((uintptr_t)ptr & 15) || (bytes & 3)) return (int)hipMemsetAsync(ptr, 0, bytes, st);     // (never the plans' arenas: 256-byte aligned fp32)
+  const size_t n16 = bytes >> 4;
+  const int ntail = (int)((bytes & 15) >> 2);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for((int64_t)(n16 ? n16 : 1), 256, 2048)), dim3(256), 0, st, static_cast<uint4*>(ptr), n16,
+                     reinterpret_cast<unsigned int*>(static_cast<char*>(ptr) + (n16 << 4)), ntail);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
 // (round 5, measured and removed: forking the weight-gradient stream once per K side calls instead of per call -- MYOLO_SIDE_BATCH=2 / 4 / 8:
 //  7.769 / 7.855 / 7.911 ms per step against 7.765; the held-back weight gradients start later and the exposed tail grows)
 extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream, void* side_stream) {
@@ -145,16 +167,59 @@ extern "C" int myolo_prog_run(void* prog, int first, int last, void* main_stream
           r = (int)e;
         }
         break;
-      case MYOLO_OP_MEMSET: {
-        const hipError_t e = hipMemsetAsync(reinterpret_cast<void*>(static_cast<uintptr_t>(o.a[0])), 0, (size_t)o.a[1], ms);
-        r = (int)e;
+      case MYOLO_OP_MEMSET:
+        r = zero_fill(reinterpret_cast<void*>(static_cast<uintptr_t>(o.a[0])), (size_t)o.a[1], ms);
         break;
-      }
       default:
         r = MYOLO_EINVAL;
     }
     if (r) { p->last_op = i; return r; }
   }
+  return 0;
+}
+
+// ---- order between two queues without a HIP event (include/myolo.h: myolo_queue_post / myolo_queue_wait) -------------------------------
+// hipEventRecord + hipStreamWaitEvent between two queues costs 90-170 us on this runtime whatever is waited for (scripts/ubench/two_queue_gap.py:
+// graph A | graph C on a second stream + graph B behind A: 423 us against ~330 for A + max(B, C); no HIP / ROCr switch moves it, and HIP's own
+// stream memory operations -- hipStreamWriteValue32 / hipStreamWaitValue32 -- sit in between at 373-392 us and made the real frame SLOWER, 866
+// against 1014 FPS: profiles/r6_two_queue_gap.txt, r6_infer_fork_ab.txt): the detect.py frame's main queue idled that long behind the backbone
+// graph.  A counting semaphore in device memory does the same job in about a microsecond: the producer queue runs a one-lane kernel that adds 1
+// behind its work, the consumer queue starts with a one-lane kernel that polls (agent-scope loads, s_sleep) until the count is positive and takes
+// 1.  What the producer wrote is visible to the consumer's NEXT kernel: every dispatch ends with an agent-scope release and starts with an
+// agent-scope acquire (checked the hard way: scripts/ubench/fork_stress.py, 1200 frames whose tensors all stay in the L2s, every frame against
+// the one-stream forward).  The poll is bounded (timeout_ms of the 100 MHz clock): on expiry the kernel counts a timeout in sem[32] and lets its
+// queue go on -- the host side (runtime.PlanHolder) reads that word and refuses the results.
+namespace {
+__global__ __launch_bounds__(64) void queue_post_kernel(unsigned int* sem) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add((gbar_u32*)sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(64) void queue_wait_kernel(unsigned int* sem, long long limit) {
+  if (threadIdx.x != 0) return;
+  gbar_u32* w = (gbar_u32*)sem;
+  const long long t0 = wall_clock64();
+  for (;;) {
+    if ((int)__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+      __hip_atomic_fetch_sub(w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(16);
+    if (wall_clock64() - t0 > limit) break;
+  }
+  __hip_atomic_fetch_add(w + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+extern "C" int myolo_queue_post(void* sem, void* stream) {
+  if (!sem || ((uintptr_t)sem & 3)) return MYOLO_EINVAL;
+  hipLaunchKernelGGL(queue_post_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<unsigned int*>(sem));
+  MYOLO_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int myolo_queue_wait(void* sem, int timeout_ms, void* stream) {
+  if (!sem || ((uintptr_t)sem & 3) || timeout_ms < 1) return MYOLO_EINVAL;
+  hipLaunchKernelGGL(queue_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, static_cast<unsigned int*>(sem), (long long)timeout_ms * 100000ll);
+  MYOLO_CHECK_LAUNCH();
   return 0;
 }
 

@@ -591,6 +591,13 @@ SPLIT_EVAL = True            # eval graphs: the side-stream branch is not joined
 EVAL_TAIL = 'g'              # (round 5 sweep: every other placement measured slower) graph B (neck tail + Detect, main stream)
 EVAL_HEAD = 'g'              # graph C (segmentation head, side stream)
 EVAL_ORDER = 'cb'            # host order of the two launches behind graph A
+# how the segmentation head's stream learns that the neck is done.  'event': hipEventRecord + hipStreamWaitEvent between graph A and graphs B / C --
+# whichever launch came second on the main queue then started 90-170 us late (profiles/r6_infer_fork_*.txt; scripts/ubench/two_queue_gap.py shows
+# the same for plain torch kernels, and no HIP / ROCr switch that changes it).  'sem' (round 6): ONE main-stream graph (chain up to the fork, a
+# myolo_queue_post launch, neck tail + Detect) and the head's graph behind a myolo_queue_wait launch: a device-memory semaphore, no event
+EVAL_FORK = 'sem'
+EVAL_SEM_TIMEOUT_MS = 2000
+EVAL_SEM_CHECK_EVERY = 64    # frames between two reads of the semaphore's timeout word (a host sync)
 
 
 class PlanHolder:
@@ -663,12 +670,24 @@ class PlanHolder:
                     pm, fork, ps = split
                     side = self.plan._side_stream()
                     gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        pm.run(0, fork)
-                    with torch.cuda.graph(gb):
-                        pm.run(fork, pm.n)
-                    with torch.cuda.graph(gc, stream=side):
-                        ps.run()
+                    if EVAL_FORK == 'sem':
+                        sem = st['_sem'] = torch.zeros(L.QUEUE_SEM_BYTES // 4, dtype=torch.int32, device=tensors[0].device)
+                        torch.cuda.synchronize()
+                        with torch.cuda.graph(g):
+                            pm.run(0, fork)
+                            L.check(L.lib().myolo_queue_post(L.ptr(sem), L.stream_ptr()), 'myolo_queue_post')
+                            pm.run(fork, pm.n)
+                        with torch.cuda.graph(gc, stream=side):
+                            L.check(L.lib().myolo_queue_wait(L.ptr(sem), EVAL_SEM_TIMEOUT_MS, L.stream_ptr()), 'myolo_queue_wait')
+                            ps.run()
+                        gb = None
+                    else:
+                        with torch.cuda.graph(g):
+                            pm.run(0, fork)
+                        with torch.cuda.graph(gb):
+                            pm.run(fork, pm.n)
+                        with torch.cuda.graph(gc, stream=side):
+                            ps.run()
                     st['_graph_b'], st['_graph_c'] = gb, gc
                     st['_split'] = split
                     st['_fork_ev'], st['_branch_done'] = torch.cuda.Event(), torch.cuda.Event()
@@ -690,6 +709,19 @@ class PlanHolder:
             for s_, t in zip(self._static_in, tensors):
                 if s_.data_ptr() != t.data_ptr():
                     s_.copy_(t)
+            if st.get('_sem') is not None:
+                n = st['_sem_frames'] = st.get('_sem_frames', 0) + 1
+                if n % EVAL_SEM_CHECK_EVERY == 0 and int(st['_sem'][32].item()):
+                    st['_graph_failed'] = True
+                    raise L.MyoloError('the segmentation head went on without the neck (myolo_queue_wait timed out): results of the last '
+                                       f'{EVAL_SEM_CHECK_EVERY} frames are not valid; later forwards run the eager launch list')
+                st['_graph'].replay()                    # post before wait in host order: correct even if both streams share one hardware queue
+                with torch.cuda.stream(side):
+                    st['_graph_c'].replay()
+                    st['_branch_done'].record(side)
+                st['_branch_pending'] = True
+                st['_branch_main'] = main
+                return self.output_tensors()
             st['_graph'].replay()
             st['_fork_ev'].record(main)
             pm, fork, ps = st['_split']

@@ -1,5 +1,6 @@
 """chronological listing of the LAST complete training step of a rocprofv3 kernel trace of bench.py: per kernel queue, start offset, duration,
-gap to the previous kernel of the same queue.  usage: python scripts/trace_list.py <kernel_trace.csv> [min_us]"""
+gap to the previous kernel of the same queue.  usage: python scripts/trace_list.py <kernel_trace.csv> [marker]
+(marker: substring of the kernel that ends a step; default mt_ema_kernel = the training step; `seg_argmax` = one detect.py frame)"""
 import csv
 import sys
 
@@ -7,7 +8,8 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r['s'], r['e'] = int(r['Start_Timestamp']), int(r['End_Timestamp'])
 rows.sort(key=lambda r: r['s'])
-ends = [i for i, r in enumerate(rows) if 'mt_ema_kernel' in r['Kernel_Name']]
+MARK = sys.argv[2] if len(sys.argv) > 2 else 'mt_ema_kernel'
+ends = [i for i, r in enumerate(rows) if MARK in r['Kernel_Name']]
 a, b = ends[-2] + 1, ends[-1] + 1
 step = rows[a:b]
 t0 = step[0]['s']

@@ -68,11 +68,11 @@ def _train_step_checked(args, tag, expect, bn=False, every=1, only=None):
 
 def test_every_conv_launch_of_the_benchmarked_training_step_matches_torch_fp32():
     """BASELINE configs[1]: 79 convolutions -> 70 forward launches (9 merged pairs), their dgrads (stride-2 ones as one fused launch, 1x1
-    Conv+BatchNorm+SiLU ones with the apply fold) and 79 weight-gradient launches"""
+    Conv+BatchNorm+SiLU ones with the apply fold) and 79 weight gradients: 78 myolo_conv_wgrad launches + the stem layer's one-pass BatchNorm-backward + weight-gradient launch"""
     # ... and EVERY BatchNorm launch of that step, unsampled (VERDICT r5 item 7; rounds 5's suite evaluated every fourth): forward with its
     # saved / running statistics, backward reduce, backward apply with dgamma / dbeta and the shortcut's gradient pass-through, plain and
     # split, and round 6's one-launch form (reduce + barrier + apply): the other 7.6 GB of the step's traffic
-    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 79, 'myolo_conv_dgrad_s2': 6, 'myolo_conv_dgrad_bn': 15,
+    lc, sites = _train_step_checked(_args(), 'bench16', {'myolo_conv': 90, 'myolo_conv_wgrad': 78, 'myolo_bn_wgrad_stem': 1, 'myolo_conv_dgrad_s2': 6, 'myolo_conv_dgrad_bn': 15,
                                                         'myolo_bn_act_fwd': 40, 'myolo_bn_act_bwd_reduce': 20, 'myolo_bn_act_bwd_apply': 18,
                                                         'myolo_bn_act_bwd_fused': 4}, bn=1)
     fam = ' '.join(sites)

@@ -66,17 +66,21 @@ def test_eval_fused_fp32_matches_reference_golden(tag):
                                     rseg, eps=1e-4)
 
 
-def test_eval_frames_with_the_unjoined_head_match_the_joined_forward(monkeypatch):
+@pytest.mark.parametrize('fork', ['sem', 'event'])
+def test_eval_frames_with_the_unjoined_head_match_the_joined_forward(monkeypatch, fork):
     """detect.py loop (forward -> NMS -> resize + argmax) over several different frames through the captured eval graphs: with the
     segmentation head left running on the side stream (three graphs, NMS beside the head) and with everything on one stream --
     decoded predictions identical, label maps identical (the head's pyramid pools sum through atomics: a near-tie pixel may differ);
-    the cross-frame hazards (next frame's neck overwriting what the previous head still reads) would show as differences"""
+    the cross-frame hazards (next frame's neck overwriting what the previous head still reads) would show as differences.  `fork`: how the
+    head's stream learns that the neck is done -- round 6's device-memory semaphore (two graphs: chain + post + tail | wait + head; a head that
+    started before its inputs were complete would differ from the one-stream forward) or the HIP event of rounds 3-5 (three graphs)"""
     from multiyolov5_amd import engine as E, runtime as R
     from multiyolov5_amd.utils.general import non_max_suppression, seg_argmax
     frames = [synth.synth_images(1, H, W, seed=s).to(DEV, torch.float16) for s in (1, 2, 3, 4, 5, 6)]
 
     def run(split, branch):
         monkeypatch.setattr(R, 'SPLIT_EVAL', split)
+        monkeypatch.setattr(R, 'EVAL_FORK', fork)
         monkeypatch.setattr(E, 'EVAL_BRANCH', branch)
         m, _ = build('s_psp')
         m.half().fuse().eval()
@@ -91,7 +95,12 @@ def test_eval_frames_with_the_unjoined_head_match_the_joined_forward(monkeypatch
         return outs, holders
 
     a, ha = run(True, True)
-    assert all(h.__dict__.get('_graph_c') is not None for h in ha)                # the three-graph path really ran
+    assert all(h.__dict__.get('_graph_c') is not None for h in ha)                # the un-joined path really ran
+    for h in ha:
+        if fork == 'sem':
+            assert h.__dict__.get('_graph_b') is None and h.__dict__['_sem'][:33:32].tolist() == [0, 0]     # every post taken, no poll timed out
+        else:
+            assert h.__dict__.get('_graph_b') is not None and h.__dict__.get('_sem') is None
     b, hb = run(False, False)
     assert all(h.__dict__.get('_graph') is not None and h.__dict__.get('_graph_c') is None for h in hb)
     for i, ((pa, da, la), (pb, db, lb)) in enumerate(zip(a, b)):
