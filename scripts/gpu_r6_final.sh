@@ -38,10 +38,13 @@ for S in "1024 2048" "512 1024"; do
   T=$(echo $S | tr ' ' 'x')
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_itrace_$T -o tr -- python bench.py --stage infer --infer-size $S --steps 60 --no-cpu-baseline > gpurun_out/${TAG}_itrace_$T.log 2>&1
   python scripts/trace_infer_timeline.py $(find gpurun_out/${TAG}_itrace_$T -name "*kernel_trace.csv" | head -1) > gpurun_out/${TAG}_infer_timeline_$T.txt 2>&1
+  python scripts/trace_list.py $(find gpurun_out/${TAG}_itrace_$T -name "*kernel_trace.csv" | head -1) seg_argmax > gpurun_out/${TAG}_infer_listing_$T.txt 2>&1
   head -4 gpurun_out/${TAG}_infer_timeline_$T.txt | cut -c1-200
   cp $(find gpurun_out/${TAG}_itrace_$T -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}_infer${T}_kernel_stats.csv 2>/dev/null
   rm -rf gpurun_out/${TAG}_itrace_$T
 done
+echo "--- fork stress"
+for F in sem event joined; do for T in f32 f16; do FORK=$F python scripts/ubench/fork_stress.py $T 2>&1 | grep -v "Fusing\|amdgpu.ids" | tail -1 | cut -c1-200; done; done 2>&1 | tee gpurun_out/${TAG}_fork_stress.txt
 cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
 rm -rf gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_mlab gpurun_out/pmc_${TAG}_* 2>/dev/null
 du -sh gpurun_out | tail -1
