@@ -370,6 +370,18 @@ def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
     torch.cuda.synchronize()
     fps_unchanged = frames / (time.perf_counter() - t0)
     same_labels = bool(torch.equal(lab_u, frame()[1][0]))
+    # after all those replays the graphs must still compute what the plain launch list computes (round 6: a memset node of the captured graph had
+    # stopped clearing the head's accumulators after a few hundred frames, DESIGN section 3 zero_fill_kernel): same frame through both, label maps
+    # equal up to the near-tie pixels the head's atomics order can flip
+    from multiyolov5_amd import runtime as _R
+    lab_g = frame()[1]
+    _R.GRAPH_EVAL = False
+    try:
+        lab_e = frame()[1]
+    finally:
+        _R.GRAPH_EVAL = True
+    torch.cuda.synchronize()
+    label_px_vs_launch_list = int((lab_g != lab_e).sum())
     st = [0.0, 0.0, 0.0]
     k = 10
     for _ in range(k):
@@ -411,6 +423,7 @@ def infer_report(args, dev, frames=200, warm=16, H=1024, W=2048, cpu=False):
                               'head_unjoined the segmentation head (side stream) overlaps NMS, so the stages add up to more than the frame: '
                               'forward = whole forward incl. the join, forward_main_chain = what the main stream waits for before NMS'},
          'graph_replayed': replayed, 'forward_launches': nlaunch,
+         'label_pixels_differing_from_the_eager_launch_list_after_the_timed_loops': label_px_vs_launch_list,
          'roofline': {'bound': 'hbm', 'achieved': alg * fps / 1e9, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                       'frac': alg * fps / 1e9 / HBM_PEAK_GBS, 'algorithmic_bytes_per_frame': alg,
                       'what': 'SURVEY 8(d): conv input + weights + output once each, fp16 (200.8 MB per 512x1024 image) + NMS input rows + '

@@ -547,10 +547,8 @@ extern "C" int myolo_seg_upce_fwd_grad(const myolo_tensor* low, int H, int W, co
   if (low->dtype != MYOLO_F16 && low->dtype != MYOLO_F32) return MYOLO_EINVAL;
   if (low->c != 19) return MYOLO_EINVAL;                       // Cityscapes' 19 classes (the reference's only use): other counts take the unfused path
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(glow32, 0, (size_t)low->n * low->h * low->w * low->c * sizeof(float), st);
-  if (e != hipSuccess) return (int)e;
+  int e = myolo_fill_words2(acc, 2 * sizeof(double), 0u, glow32, (size_t)low->n * low->h * low->w * low->c * sizeof(float), 0u, st);
+  if (e) return e;
   const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
   int TY = 32;
   const int strips = (W + 255) / 256;
@@ -579,15 +577,14 @@ static int seg_upce_ohem_launch(const myolo_tensor* low, int H, int W, const int
   if (!low || !low->ptr || !target || !pix || H < 1 || W < 1) return MYOLO_EINVAL;
   if ((low->dtype != MYOLO_F16 && low->dtype != MYOLO_F32) || low->c != 19) return MYOLO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e;
   if (mode == 1) {
     if (!acc) return MYOLO_EINVAL;
-    e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
-    if (e != hipSuccess) return (int)e;
+    const int ef = myolo_fill_words2(acc, 2 * sizeof(double), 0u, nullptr, 0, 0u, st);
+    if (ef) return ef;
   } else {
     if (!sel || !glow32) return MYOLO_EINVAL;
-    e = hipMemsetAsync(glow32, 0, (size_t)low->n * low->h * low->w * low->c * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    const int ef = myolo_fill_words2(glow32, (size_t)low->n * low->h * low->w * low->c * sizeof(float), 0u, nullptr, 0, 0u, st);
+    if (ef) return ef;
   }
   const float sy = H > 1 ? (float)(low->h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(low->w - 1) / (float)(W - 1) : 0.f;
   int TY = 32;
@@ -634,8 +631,8 @@ static int seg_ce_fwd_impl(const void* logits, void* grad, int dtype, int n, int
   const bool dense = dense_cl(logits, dtype, c, h, w, sn, sc, sh, sw);
   if (grad && (!dense || ((uintptr_t)grad & 15))) return MYOLO_EINVAL;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(acc, 0, 2 * sizeof(double), st);
-  if (e != hipSuccess) return (int)e;
+  const int e = myolo_fill_words2(acc, 2 * sizeof(double), 0u, nullptr, 0, 0u, st);
+  if (e) return e;
   const int64_t total = (int64_t)n * h * w;
   Strided4 x{const_cast<void*>(logits), sn, sc, sh, sw, dtype};
   if (dense) {                                                     // all pixels of all images are one contiguous [P][C] array
@@ -685,10 +682,8 @@ extern "C" int myolo_ohem_select(const float* pix, int64_t total, float thresh, 
                                  uint32_t* ws, float* loss, float* sel, void* stream) {
   if (!pix || !acc || !st || !ws || !loss || !sel || total < 1) return MYOLO_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(st, 0, 5 * sizeof(double), s);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(ws, 0, 2052 * sizeof(uint32_t), s);
-  if (e != hipSuccess) return (int)e;
+  const int e = myolo_fill_words2(st, 5 * sizeof(double), 0u, ws, 2052 * sizeof(uint32_t), 0u, s);
+  if (e) return e;
   const int grid = grid_for(total, 256, 2048);
   hipLaunchKernelGGL(ohem_thresh_kernel, dim3(grid), dim3(256), 0, s, pix, total, thresh, st);
   // 32-bit keys in passes of 11 + 11 + 10 bits
@@ -1004,10 +999,8 @@ extern "C" int myolo_detloss_fwd(const myolo_detloss_desc* d, void* stream) {
   int r = fill_detk(d, k, ncell);
   if (r) return r;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(k.winner, 0xff, ncell * sizeof(int), st);      // -1
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(k.acc, 0, 5 * 4 * sizeof(double), st);
-  if (e != hipSuccess) return (int)e;
+  const int e = myolo_fill_words2(k.winner, (size_t)ncell * sizeof(int), 0xffffffffu, k.acc, 5 * 4 * sizeof(double), 0u, st);      // -1 | 0
+  if (e) return e;
   const int ncand = 5 * k.na * k.nt;
   if (ncand > 0) {
     hipLaunchKernelGGL(det_cand_fwd_kernel, dim3(grid_for(ncand, 256, 256), k.nl), dim3(256), 0, st, k);

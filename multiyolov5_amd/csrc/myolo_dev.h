@@ -280,6 +280,11 @@ __device__ __forceinline__ float ld_agent_f32(const float* p) {
   return __hip_atomic_load((const __attribute__((address_space(1))) float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// hipMemsetAsync's replacement inside the library (csrc/plan_exec.hip): up to two regions of 32-bit words in ONE kernel launch.  rocclr fill
+// commands cost ~5 us each even for 16 bytes and do not pack behind kernels; as NODES of a captured graph they were seen to stop clearing
+// (zero_fill_kernel).  Regions: 4-byte aligned, sizes multiples of 4, 16-byte aligned bases beyond 1 KB.
+int myolo_fill_words2(void* a, size_t a_bytes, unsigned int av, void* b, size_t b_bytes, unsigned int bv, hipStream_t st);
+
 // ---- BatchNorm-backward statistics in a dgrad epilogue (myolo_conv_desc.bnb) ----
 struct BnbSeg {              // device-side copy of one myolo_bn_bwd_seg
   int c0, c1;

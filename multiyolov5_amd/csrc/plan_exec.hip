@@ -121,21 +121,59 @@ extern "C" int myolo_prog_last_op(void* prog) { return prog ? static_cast<Prog*>
 // (scripts/ubench/fork_stress.py, profiles/r6_fork_stress.txt: the segmentation head's pooled sums grew to inf); a kernel node carries its own
 // arguments; (2) rocclr fill commands do not pack behind kernels: ~4 us of queue bubble each.
 namespace {
-__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* __restrict__ p16, size_t n16, unsigned int* __restrict__ tail, int ntail) {
-  const uint4 z = {0u, 0u, 0u, 0u};
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p16[i] = z;
-  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0u;
+struct FillR { uint4* p16; size_t n16; unsigned int* tail; int ntail; unsigned int v; };
+__global__ __launch_bounds__(256) void fill_words_kernel(FillR a, FillR b) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+  const uint4 va = {a.v, a.v, a.v, a.v}, vb = {b.v, b.v, b.v, b.v};
+  for (size_t i = t; i < a.n16; i += step) a.p16[i] = va;
+  for (size_t i = t; i < b.n16; i += step) b.p16[i] = vb;
+  if (t < (size_t)a.ntail) a.tail[t] = a.v;
+  if (t < (size_t)b.ntail) b.tail[t] = b.v;
 }
-int zero_fill(void* ptr, size_t bytes, hipStream_t st) {
-  if (!bytes) return 0;
-  if (!ptr || ((uintptr_t)ptr & 15) || (bytes & 3)) return (int)hipMemsetAsync(ptr, 0, bytes, st);     // (never the plans' arenas: 256-byte aligned fp32)
-  const size_t n16 = bytes >> 4;
-  const int ntail = (int)((bytes & 15) >> 2);
-  hipLaunchKernelGGL(zero_fill_kernel, dim3(grid_for((int64_t)(n16 ? n16 : 1), 256, 2048)), dim3(256), 0, st, static_cast<uint4*>(ptr), n16,
-                     reinterpret_cast<unsigned int*>(static_cast<char*>(ptr) + (n16 << 4)), ntail);
-  return (int)hipGetLastError();
+FillR fill_region(void* ptr, size_t bytes, unsigned int v) {
+  FillR r{nullptr, 0, nullptr, 0, v};
+  if (!ptr || !bytes) return r;
+  char* p = static_cast<char*>(ptr);
+  size_t words = bytes >> 2;
+  size_t head = ((uintptr_t)p & 15) ? (16 - ((uintptr_t)p & 15)) >> 2 : 0;       // words up to the first 16-byte boundary
+  if (head > words) head = words;
+  if (head || words < 4) {                       // small or unaligned: everything through the word path (<= 256 words), else split
+    if (words <= 256) { r.tail = reinterpret_cast<unsigned int*>(p); r.ntail = (int)words; return r; }
+  }
+  // aligned body + word tail (callers pass 16-byte aligned bases for anything larger than 1 KB)
+  r.p16 = reinterpret_cast<uint4*>(p); r.n16 = words >> 2;
+  r.tail = reinterpret_cast<unsigned int*>(p + (r.n16 << 4)); r.ntail = (int)(words & 3);
+  return r;
 }
 }  // namespace
+
+// hipMemsetAsync's replacement inside the library: up to two regions of 32-bit words in ONE launch (value 0 or any word pattern)
+int myolo_fill_words2(void* a, size_t a_bytes, unsigned int av, void* b, size_t b_bytes, unsigned int bv, hipStream_t st) {
+  if ((a_bytes & 3) || (b_bytes & 3) || ((uintptr_t)a & 3) || ((uintptr_t)b & 3)) return MYOLO_EINVAL;
+  // (a large region off the 16-byte grid: the runtime's memset for that one -- byte patterns only; the library's callers never get here)
+  if (a_bytes > 1024 && ((uintptr_t)a & 15)) {
+    if (av != 0u && av != 0xffffffffu) return MYOLO_EINVAL;
+    const hipError_t e = hipMemsetAsync(a, (int)(av & 0xff), a_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    a = nullptr; a_bytes = 0;
+  }
+  if (b_bytes > 1024 && ((uintptr_t)b & 15)) {
+    if (bv != 0u && bv != 0xffffffffu) return MYOLO_EINVAL;
+    const hipError_t e = hipMemsetAsync(b, (int)(bv & 0xff), b_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    b = nullptr; b_bytes = 0;
+  }
+  const FillR ra = fill_region(a, a_bytes, av), rb = fill_region(b, b_bytes, bv);
+  const size_t work = ra.n16 > rb.n16 ? ra.n16 : rb.n16;
+  if (!work && !ra.ntail && !rb.ntail) return 0;
+  hipLaunchKernelGGL(fill_words_kernel, dim3(grid_for((int64_t)(work ? work : 1), 256, 2048)), dim3(256), 0, st, ra, rb);
+  return (int)hipGetLastError();
+}
+static int zero_fill(void* ptr, size_t bytes, hipStream_t st) {
+  if (!bytes) return 0;
+  if (!ptr || ((uintptr_t)ptr & 15) || (bytes & 3)) return (int)hipMemsetAsync(ptr, 0, bytes, st);     // (never the plans' arenas: 256-byte aligned fp32)
+  return myolo_fill_words2(ptr, bytes, 0u, nullptr, 0, 0u, st);
+}
 
 // (round 5, measured and removed: forking the weight-gradient stream once per K side calls instead of per call -- MYOLO_SIDE_BATCH=2 / 4 / 8:
 //  7.769 / 7.855 / 7.911 ms per step against 7.765; the held-back weight gradients start later and the exposed tail grows)

@@ -45,6 +45,6 @@ for S in "1024 2048" "512 1024"; do
 done
 echo "--- fork stress"
 for F in sem event joined; do for T in f32 f16; do FORK=$F python scripts/ubench/fork_stress.py $T 2>&1 | grep -v "Fusing\|amdgpu.ids" | tail -1 | cut -c1-200; done; done 2>&1 | tee gpurun_out/${TAG}_fork_stress.txt
-cp profiles/${TAG}_* gpurun_out/ 2>/dev/null
+cp -n profiles/${TAG}_* gpurun_out/ 2>/dev/null     # (what prof_summary / pmc_summary wrote into profiles/ on the box travels back through gpurun_out; never over a file this run produced)
 rm -rf gpurun_out/prof_$TAG gpurun_out/prof_${TAG}_mlab gpurun_out/pmc_${TAG}_* 2>/dev/null
 du -sh gpurun_out | tail -1
