@@ -365,7 +365,7 @@ extern "C" int myolo_set_option(const char* name, int value) {
   if (!strcmp(name, "stream_per_cu")) { g_stream_per_cu = value; return 0; }
   if (!strcmp(name, "nms_dbg")) { g_nms_dbg = value; return 0; }
   if (!strncmp(name, "bn_", 3)) return myolo_bn_set(name, value);
-  if (!strncmp(name, "spp_", 4)) return myolo_pool_set(name, value);
+  if (!strncmp(name, "spp_", 4) || !strncmp(name, "pool_", 5)) return myolo_pool_set(name, value);
   if (!strncmp(name, "stem_", 5)) return myolo_stem_set(name, value);
   if (!strncmp(name, "igemm_", 6)) return myolo_conv_igemm_set(name, value);
   if (!strncmp(name, "midx_", 5)) return myolo_conv_midx_set(name, value);

@@ -9,8 +9,10 @@
 
 // myolo_set_option("spp_naive", 1): the per-output-vector SPP kernels (what planes too large for the LDS take) for every map (tests)
 static int g_spp_naive = 0;
+static int g_spp_bwd_form = 0;     // myolo_set_option("spp_bwd_form", 1): round 5's plane kernel (a thread = a pixel x 8 channels) instead of round 6's channel-lane kernel
 int myolo_pool_set(const char* name, int value) {
   if (!strcmp(name, "spp_naive")) { g_spp_naive = value; return 0; }
+  if (!strcmp(name, "spp_bwd_form")) { g_spp_bwd_form = value; return 0; }
   return MYOLO_EINVAL;
 }
 #include <stdlib.h>
@@ -275,6 +277,94 @@ __global__ __launch_bounds__(256) void spp_bwd_plane_kernel(myolo_tensor g5, myo
 #pragma unroll
     for (int i = 0; i < SEG; ++i) a[i] = accum[(size_t)p * SEG + i];
     T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    if (acc) {
+      float o[SEG];
+      Vec<T>::unpack(ldg16(gp), o);
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) a[i] += o[i];
+    }
+    stg16(gp, Vec<T>::pack(a));
+  }
+}
+
+// Round 6: the same transpose with the LANES ON THE CHANNELS.  The plane kernel above gives a thread one pixel x 8 channels: (1) its 16-byte
+// loads are gx.c * 2 bytes apart (512 B at 256 channels: a quarter of every 64-byte sector is used -- the PMC counted 185 MB read for 22 MB of
+// operands), and (2) neighbouring pixels usually share an arg-max position, so the lanes of a wave add to the SAME LDS address and the atomics
+// serialise (90 us for a 4 MB tensor).  Here a workgroup owns CH = 32 consecutive channels of one image: 32 lanes read one pixel's 64 bytes
+// (gradient) / 32 bytes (index) and add to 32 consecutive LDS words -- distinct banks whatever the arg-max pattern; 1024 threads = 32 runs of
+// pixels per workgroup.
+template <typename T, int CH, int NT>
+__global__ __launch_bounds__(NT) void spp_bwd_chan_kernel(myolo_tensor g5, myolo_tensor g9, myolo_tensor g13,
+                                                          const uint8_t* __restrict__ idx, myolo_tensor gx, int acc) {
+  constexpr int SEG = ET<T>::SEG, NPL = NT / CH;
+  extern __shared__ __attribute__((aligned(16))) float accum[];           // [HW][CH]
+  const int HW = gx.h * gx.w, W = gx.w;
+  const int GC = gx.c / CH;
+  const int n = blockIdx.x / GC, c0 = (blockIdx.x - n * GC) * CH;
+  for (int i = threadIdx.x; i < HW * CH / 4; i += NT) reinterpret_cast<float4*>(accum)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int lc = threadIdx.x % CH, pl = threadIdx.x / CH;
+  const int64_t plane = (int64_t)gx.n * HW * gx.c;
+  const uint8_t* ib = idx + (int64_t)n * HW * gx.c + c0 + lc;
+  const T* b5 = static_cast<const T*>(g5.ptr) + (int64_t)n * g5.sn + c0 + lc;
+  const T* b9 = static_cast<const T*>(g9.ptr) + (int64_t)n * g9.sn + c0 + lc;
+  const T* b13 = static_cast<const T*>(g13.ptr) + (int64_t)n * g13.sn + c0 + lc;
+  // A thread walks RUN consecutive pixels of the row-major plane for its channel.  Neighbouring outputs mostly share their arg-max position (a
+  // maximum owns the windows around it), so the gradient of a run of equal targets is summed in a register and reaches the LDS as ONE atomic:
+  // fp32 LDS atomics are the kernel's bound (6.3 M of them took 44-67 us whatever the load schedule -- about one lane per 2-4 clocks and CU).
+  // U pixels are loaded per step before the first use (clamped indices, zero weights past the end: no predicated loads).
+  constexpr int U = 4;
+  const int RUN = (HW + NPL - 1) / NPL;
+  const int pbeg = pl * RUN;
+  int cur[3] = {-1, -1, -1};
+  float sm[3] = {0.f, 0.f, 0.f};
+  for (int u0 = 0; u0 < RUN; u0 += U) {
+    T f[U][3];
+    uint8_t id[U][3];
+    int yy[U], xc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int p = pbeg + u0 + u;
+      p = p < HW ? p : HW - 1;
+      const int y = p / W, xx = p - y * W;
+      yy[u] = y; xc[u] = xx;
+      f[u][0] = b5[(int64_t)y * g5.sh + (int64_t)xx * g5.sw];
+      f[u][1] = b9[(int64_t)y * g9.sh + (int64_t)xx * g9.sw];
+      f[u][2] = b13[(int64_t)y * g13.sh + (int64_t)xx * g13.sw];
+      id[u][0] = ib[(int64_t)p * gx.c];
+      id[u][1] = ib[plane + (int64_t)p * gx.c];
+      id[u][2] = ib[2 * plane + (int64_t)p * gx.c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const bool live = u0 + u < RUN && pbeg + u0 + u < HW;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        const int K = 5 + 4 * w, r = 2 + 2 * w;
+        const int i = id[u][w];
+        const int t = live ? (yy[u] + i / K - r) * W + xc[u] + i % K - r : -1;
+        const float v = (float)f[u][w];
+        if (t == cur[w]) {
+          sm[w] += v;
+        } else {
+          if (cur[w] >= 0) atomicAdd(accum + (size_t)cur[w] * CH + lc, sm[w]);
+          cur[w] = t; sm[w] = v;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+    if (cur[w] >= 0) atomicAdd(accum + (size_t)cur[w] * CH + lc, sm[w]);
+  __syncthreads();
+  constexpr int GP = CH / SEG;                                            // 16-byte pieces per pixel
+  for (int v = threadIdx.x; v < HW * GP; v += NT) {
+    const int p = v / GP, g = v - p * GP;
+    const int y = p / W, xx = p - y * W;
+    float a[SEG];
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) a[i] = accum[(size_t)p * CH + g * SEG + i];
+    T* gp = vptr<T>(gx, n, y, xx) + c0 + g * SEG;
     if (acc) {
       float o[SEG];
       Vec<T>::unpack(ldg16(gp), o);
@@ -1229,6 +1319,25 @@ extern "C" int myolo_spp_pool_bwd(const myolo_tensor* g5, const myolo_tensor* g9
     return MYOLO_EINVAL;
   const int HW = gx->h * gx->w;
   const int seg = gx->dtype == MYOLO_F16 ? 8 : 4;
+  if (gx->c % 32 == 0 && (size_t)HW * 32 * sizeof(float) <= 144 * 1024 && !g_spp_naive && !(g_spp_bwd_form & 1)) {
+    hipStream_t st = (hipStream_t)stream;
+    // 16 channels per workgroup when 32 would leave CUs empty (the bs-16 step: 16 images x 8 groups of 32 = 128 workgroups on 256 CUs)
+    const bool narrow = (g_spp_bwd_form & 2) ? false : ((g_spp_bwd_form & 4) ? true : gx->n * (gx->c / 32) < 200);
+    const int ch = narrow ? 16 : 32;
+    const size_t smem = (size_t)HW * ch * sizeof(float);
+    const dim3 grid(gx->n * (gx->c / ch));
+#define SPP_BWD_CHAN(T_, CH_)                                                                                                   \
+    do {                                                                                                                        \
+      auto kern = spp_bwd_chan_kernel<T_, CH_, 1024>;                                                                           \
+      MYOLO_ENSURE_DYN_SMEM(kern, (int)smem);                                                                                   \
+      hipLaunchKernelGGL(kern, grid, dim3(1024), smem, st, *g5, *g9, *g13, idx, *gx, accumulate);                               \
+    } while (0)
+    if (gx->dtype == MYOLO_F16) { if (narrow) SPP_BWD_CHAN(half_t, 16); else SPP_BWD_CHAN(half_t, 32); }
+    else { if (narrow) SPP_BWD_CHAN(float, 16); else SPP_BWD_CHAN(float, 32); }
+#undef SPP_BWD_CHAN
+    MYOLO_CHECK_LAUNCH();
+    return 0;
+  }
   if ((size_t)HW * seg * sizeof(float) <= SPP_PLANE_LDS && !g_spp_naive) {
     DISPATCH(gx->dtype, spp_bwd_plane_kernel, gx->n * (gx->c / seg), 256, (size_t)HW * seg * sizeof(float), (hipStream_t)stream,
              *g5, *g9, *g13, idx, *gx, accumulate);

@@ -171,6 +171,53 @@ def test_block_spp_large_map_kernels(name, dtype, monkeypatch):
         L.lib().myolo_set_option(b'spp_naive', 0)
 
 
+def test_spp_pool_bwd_kernel_forms_agree_with_max_pool2d_autograd():
+    """myolo_spp_pool_bwd (SPP / C3SPP: nn.MaxPool2d(5 / 9 / 13, 1, pad), common.py:150-163): round 6's channel-lane kernel, round 5's plane
+    kernel (`spp_bwd_form` = 1) and the per-output-vector kernel (`spp_naive`) against autograd of F.max_pool2d on the same values -- with
+    TIES (a quarter of the inputs repeated: the index planes decide), accumulate, ragged maps, 32 .. 256 channels, both dtypes"""
+    import ctypes as C
+    import torch.nn.functional as F
+    from multiyolov5_amd import _lib as L
+    lib = L.lib()
+
+    def td(t, dt):
+        n, h, w, c = t.shape
+        return L.Tensor(L.ptr(t), n, h, w, c, h * w * c, w * c, c, L.DT[dt], 0)
+    try:
+        for dt in (torch.float16, torch.float32):
+            for (n, h, w, c) in ((2, 16, 32, 256), (1, 10, 18, 32), (3, 7, 9, 64), (1, 20, 40, 96)):
+                gen = torch.Generator().manual_seed(h * 131 + c)
+                x = (torch.randint(0, 40, (n, h, w, c), generator=gen).float() / 8).to(dt).to(DEV)      # coarse values: many ties
+                outs = [torch.empty_like(x) for _ in range(3)]
+                idx = torch.empty(3 * x.numel(), dtype=torch.uint8, device=DEV)
+                L.check(lib.myolo_spp_pool_fwd(C.byref(td(x, dt)), C.byref(td(outs[0], dt)), C.byref(td(outs[1], dt)), C.byref(td(outs[2], dt)),
+                                               L.ptr(idx), L.stream_ptr()), 'spp_fwd')
+                gs = [(torch.randn(n, h, w, c, generator=gen) * 0.5).to(dt).to(DEV) for _ in range(3)]
+                base = (torch.randn(n, h, w, c, generator=gen) * 0.5).to(dt).to(DEV)
+                xr = x.permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+                tot = 0
+                for k, g, o in zip((5, 9, 13), gs, outs):
+                    y = F.max_pool2d(xr, k, 1, k // 2)
+                    assert torch.equal(y.float(), o.permute(0, 3, 1, 2).float().cpu())
+                    tot = tot + (y * g.permute(0, 3, 1, 2).double().cpu()).sum()
+                tot.backward()
+                ref = xr.grad.permute(0, 2, 3, 1).float()
+                for form, opts in (('chan', {}), ('plane', {b'spp_bwd_form': 1}), ('naive', {b'spp_naive': 1})):
+                    for k_, v_ in opts.items():
+                        L.check(lib.myolo_set_option(k_, v_))
+                    for acc in (0, 1):
+                        gx = base.clone()
+                        L.check(lib.myolo_spp_pool_bwd(C.byref(td(gs[0], dt)), C.byref(td(gs[1], dt)), C.byref(td(gs[2], dt)), L.ptr(idx),
+                                                       C.byref(td(gx, dt)), acc, L.stream_ptr()), 'spp_bwd')
+                        want = ref + (base.float().cpu() if acc else 0)
+                        check(f'spp_bwd/{form}/{n}x{h}x{w}x{c}/acc{acc}/{dt}', gx, want, 2e-3 if dt == torch.float16 else 1e-5)
+                    for k_ in opts:
+                        L.check(lib.myolo_set_option(k_, 0))
+    finally:
+        lib.myolo_set_option(b'spp_bwd_form', 0)
+        lib.myolo_set_option(b'spp_naive', 0)
+
+
 def test_pyramid_bilinear_bwd_paths_agree():
     """myolo_bilinear_bwd: the split-reduction path (scratch given) and the one-workgroup-per-input-pixel path give the same
     gradient for the PyramidPooling footprints 1x1, 2x2, 3x3, 6x6 -> 64x128 (common.py:534-537), with and without accumulate"""
