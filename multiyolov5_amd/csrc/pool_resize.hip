@@ -475,21 +475,32 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(myolo_tensor gout, my
       float wy = 0.f;
       if (y0 == y) wy += 1.f - ly;
       if (y1 == y) wy += ly;
-      if (wy == 0.f) continue;
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float fx = sx * (float)ox;
-        const int x0 = (int)fx;
-        const int x1 = x0 + 1 < gx.w ? x0 + 1 : gx.w - 1;
-        const float lx = fx - (float)x0;
-        float wx = 0.f;
-        if (x0 == xx) wx += 1.f - lx;
-        if (x1 == xx) wx += lx;
-        if (wx == 0.f) continue;
-        float f[SEG];
-        Vec<T>::unpack(ldg16(vptr<T>(gout, n, oy, ox) + cg * SEG), f);
-        const float wgt = wy * wx;
+      if (wy == 0.f) continue;                       // (a wave's lanes share y but for a row change: a uniform branch)
+      // round 6: four output columns per step, their loads issued together (clamped column, weight 0 past the range) -- the per-column
+      // `continue` kept every load next to its wait
+      for (int ox0 = xlo; ox0 <= xhi; ox0 += 4) {
+        uint4 raw[4];
+        float wgt[4];
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) a[i] += wgt * f[i];
+        for (int j = 0; j < 4; ++j) {
+          const int oxr = ox0 + j, ox = oxr <= xhi ? oxr : xhi;
+          raw[j] = ldg16(vptr<T>(gout, n, oy, ox) + cg * SEG);
+          const float fx = sx * (float)ox;
+          const int x0 = (int)fx;
+          const int x1 = x0 + 1 < gx.w ? x0 + 1 : gx.w - 1;
+          const float lx = fx - (float)x0;
+          float wx = 0.f;
+          if (x0 == xx) wx += 1.f - lx;
+          if (x1 == xx) wx += lx;
+          wgt[j] = oxr <= xhi ? wy * wx : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float f[SEG];
+          Vec<T>::unpack(raw[j], f);
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) a[i] += wgt[j] * f[i];
+        }
       }
     }
     T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
@@ -1119,28 +1130,44 @@ __global__ __launch_bounds__(256) void aap_bwd_multi_kernel(AapMulti m, myolo_te
   GRID_STRIDE(v, total) {
     int n, y, xx, cg;
     dec(v, G, gx.w, gx.h, n, y, xx, cg);
+    // every load of a pixel is issued before the first use (round 6): a pixel lies in one or two bins per axis and pool -- always 2 x 2 candidate
+    // bins per pool, clamped indices, weight 0 for the absent ones -- instead of loops whose trip counts come out of the LDS tables (hipcc kept each
+    // load next to its wait: 63 us for a 67 MB read-modify-write)
+    uint4 raw[4][4];
+    float wgt[4][4];
+    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+    uint4 old = {0u, 0u, 0u, 0u};
+    if (acc) old = ldg16(gp);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool on = t < m.n;
+      const myolo_tensor& gout = m.g[on ? t : 0];
+      const int rv = rowt[(on ? t : 0) * gx.h + y], cv = colt[(on ? t : 0) * gx.w + xx];
+      const int by0 = rv & 15, nby = rv >> 4, bx0 = cv & 15, nbx = cv >> 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int by = by0 + (j < nby ? j : 0), bx = bx0 + (i < nbx ? i : 0);
+          raw[t][j * 2 + i] = ldg16(vptr<T>(gout, n, by, bx) + cg * SEG);
+          wgt[t][j * 2 + i] = (on && j < nby && i < nbx) ? 1.f / (float)((int)exth[t * 8 + by] * (int)extw[t * 8 + bx]) : 0.f;
+        }
+    }
     float a[SEG];
 #pragma unroll
     for (int i = 0; i < SEG; ++i) a[i] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      if (t >= m.n) break;
-      const myolo_tensor& gout = m.g[t];
-      const int rv = rowt[t * gx.h + y], cv = colt[t * gx.w + xx];
-      const int by0 = rv & 15, nby = rv >> 4, bx0 = cv & 15, nbx = cv >> 4;
-      for (int by = by0; by < by0 + nby; ++by)
-        for (int bx = bx0; bx < bx0 + nbx; ++bx) {
-          float f[SEG];
-          Vec<T>::unpack(ldg16(vptr<T>(gout, n, by, bx) + cg * SEG), f);
-          const float inv = 1.f / (float)((int)exth[t * 8 + by] * (int)extw[t * 8 + bx]);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int i = 0; i < SEG; ++i) a[i] += f[i] * inv;
-        }
-    }
-    T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
+      for (int q = 0; q < 4; ++q) {
+        float f[SEG];
+        Vec<T>::unpack(raw[t][q], f);
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) a[i] += f[i] * wgt[t][q];
+      }
     if (acc) {
       float o[SEG];
-      Vec<T>::unpack(ldg16(gp), o);
+      Vec<T>::unpack(old, o);
 #pragma unroll
       for (int i = 0; i < SEG; ++i) a[i] += o[i];
     }
