@@ -737,18 +737,29 @@ __global__ __launch_bounds__(256) void pyr_up_bwd_kernel(PyrUp p, float* __restr
 #pragma unroll
       for (int i = 0; i < SEG; ++i) row[j][i] = 0.f;
     const T* rp = gb + (int64_t)y * p.gout.sh;
-    for (int x = lane16; x < p.gout.w; x += 16) {
-      float f[SEG];
-      Vec<T>::unpack(ldg16(rp + (int64_t)x * p.gout.sw), f);
-      const float fx = sx * (float)x;
-      const int j0 = (int)fx;
-      const float lx = fx - (float)j0;
-      const int j1 = j0 + 1 < k ? j0 + 1 : k - 1;
+    for (int xq = lane16; xq < p.gout.w; xq += 64) {         // four pixels' loads in flight (round 6; clamped column, weight 0 past the row)
+      uint4 raw[4];
 #pragma unroll
-      for (int j = 0; j < KMAX; ++j) {
-        const float w = (j == j0 ? 1.f - lx : 0.f) + (j == j1 ? lx : 0.f);
+      for (int u = 0; u < 4; ++u) {
+        const int x = xq + 16 * u;
+        raw[u] = ldg16(rp + (int64_t)(x < p.gout.w ? x : p.gout.w - 1) * p.gout.sw);
+      }
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) row[j][i] += w * f[i];
+      for (int u = 0; u < 4; ++u) {
+        const int x = xq + 16 * u;
+        float f[SEG];
+        Vec<T>::unpack(raw[u], f);
+        const float live = x < p.gout.w ? 1.f : 0.f;
+        const float fx = sx * (float)x;
+        const int j0 = (int)fx;
+        const float lx = fx - (float)j0;
+        const int j1 = j0 + 1 < k ? j0 + 1 : k - 1;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+          const float w = ((j == j0 ? 1.f - lx : 0.f) + (j == j1 ? lx : 0.f)) * live;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) row[j][i] += w * f[i];
+        }
       }
     }
 #pragma unroll
@@ -972,16 +983,49 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
       hi[p][j] = ok ? ((bb + 1) * x.w + k - 1) / k : 0;
     }
   }
+  // Round 6: the row sums stay in registers while a pool's VERTICAL bin (pair) does not change and reach the LDS table once per run of rows, not
+  // once per row: fp32 LDS atomics retire at about one lane per 2-4 clocks and CU (spp_bwd_chan_kernel above), and ~50 of them per thread and
+  // row were this kernel's time (the loads were not: round 5 measured four in flight neutral).  A bin of the 64-row map spans 11-64 rows, a
+  // workgroup's strip 4: one flush per pool and workgroup instead of four, unless a bin boundary crosses the strip.
+  float acc[AAP_MAXP][3][SEG];
+  int cby[AAP_MAXP], cnby[AAP_MAXP];
+#pragma unroll
+  for (int p = 0; p < AAP_MAXP; ++p) {
+    cby[p] = -1; cnby[p] = -1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) acc[p][j][i] = 0.f;
+  }
+  auto flush = [&](int p) {          // (p is a constant after unrolling: acc stays in registers)
+    if (cby[p] < 0) return;
+    const int k = mp.k[p];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int bx = bA[p] + j;
+      if (!(bx >= k || hi[p][j] <= xa || lo[p][j] >= xb)) {           // bin touched by this thread's range
+        float* d0 = sbin + (mp.bin0[p] + cby[p] * k + bx) * C + cg * SEG;
+#pragma unroll
+        for (int i = 0; i < SEG; ++i) atomicAdd(d0 + i, acc[p][j][i]);
+        if (cnby[p] >= 0) {
+          float* d1 = sbin + (mp.bin0[p] + cnby[p] * k + bx) * C + cg * SEG;
+#pragma unroll
+          for (int i = 0; i < SEG; ++i) atomicAdd(d1 + i, acc[p][j][i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < SEG; ++i) acc[p][j][i] = 0.f;
+    }
+  };
   for (int y = r0; y < r1; ++y) {
-    float acc[AAP_MAXP][3][SEG];
 #pragma unroll
-    for (int p = 0; p < AAP_MAXP; ++p)
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) acc[p][j][i] = 0.f;
-    // (round 5: four pixels' loads in flight per thread instead of one dependent 16-byte load per iteration measured NEUTRAL -- 89.7 vs 90.4 us
-    //  for the two launches of a training step, profiles/r5_kernel_stats.csv: the pass is not waiting on its loads -- and was taken out again)
+    for (int p = 0; p < AAP_MAXP; ++p) {
+      if (p < mp.np) {
+        int by, nby;
+        aap_bins(y, x.h, mp.k[p], by, nby);
+        if (by != cby[p] || nby != cnby[p]) { flush(p); cby[p] = by; cnby[p] = nby; }
+      }
+    }
     for (int xx = xa; xx < xb; ++xx) {
       float f[SEG];
       Vec<T>::unpack(ldg16(vptr<T>(x, n, y, xx) + cg * SEG), f);
@@ -994,27 +1038,9 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
           for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
         }
     }
-#pragma unroll
-    for (int p = 0; p < AAP_MAXP; ++p) {
-      if (p >= mp.np) continue;
-      const int k = mp.k[p];
-      int by, nby;
-      aap_bins(y, x.h, k, by, nby);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int bx = bA[p] + j;
-        if (bx >= k || hi[p][j] <= xa || lo[p][j] >= xb) continue;     // bin not touched by this thread's range
-        float* d0 = sbin + (mp.bin0[p] + by * k + bx) * C + cg * SEG;
-#pragma unroll
-        for (int i = 0; i < SEG; ++i) atomicAdd(d0 + i, acc[p][j][i]);
-        if (nby >= 0) {
-          float* d1 = sbin + (mp.bin0[p] + nby * k + bx) * C + cg * SEG;
-#pragma unroll
-          for (int i = 0; i < SEG; ++i) atomicAdd(d1 + i, acc[p][j][i]);
-        }
-      }
-    }
   }
+#pragma unroll
+  for (int p = 0; p < AAP_MAXP; ++p) flush(p);
   __syncthreads();
   const int rep = (blockIdx.x + blockIdx.y) % AAP_REPL;
   float* dst = scratch + ((int64_t)rep * gridDim.y + n) * mp.nbins * C;

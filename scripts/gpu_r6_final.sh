@@ -12,6 +12,7 @@ if [ "$2" != nosuite ]; then
 fi
 echo "--- smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-400
 echo "--- bench"; timeout 900 python bench.py > gpurun_out/bench_$TAG.log 2> gpurun_out/bench_$TAG.err; tail -1 gpurun_out/bench_$TAG.log | cut -c1-900
+python -c "import json,sys; l=[x for x in open(sys.argv[1]).read().splitlines() if x.startswith(chr(123))][-1]; json.dump(json.loads(l), open(sys.argv[2], 'w'), indent=1)" gpurun_out/bench_$TAG.log gpurun_out/${TAG}_bench.json
 echo "--- prof"; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$TAG -o train -- python bench.py --steps 5 --warmup 2 --no-kernel-timing --no-infer --no-cpu-baseline > gpurun_out/prof_$TAG.log 2>&1
 TR=$(find gpurun_out/prof_$TAG -name 'train_kernel_trace.csv' | head -1)
 python scripts/prof_summary.py $(find gpurun_out/prof_$TAG -name 'train_kernel_stats.csv' | head -1) $TAG 7 gpurun_out/bench_$TAG.log
