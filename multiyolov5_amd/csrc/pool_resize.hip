@@ -9,10 +9,12 @@
 
 // myolo_set_option("spp_naive", 1): the per-output-vector SPP kernels (what planes too large for the LDS take) for every map (tests)
 static int g_spp_naive = 0;
+static int g_aap_wgs = 256;        // myolo_set_option("pool_aap_wgs", n): workgroup target of the one-pass pyramid pools (myolo_adaptive_avgpool_fwd_multi)
 static int g_spp_bwd_form = 0;     // myolo_set_option("spp_bwd_form", 1): round 5's plane kernel (a thread = a pixel x 8 channels) instead of round 6's channel-lane kernel
 int myolo_pool_set(const char* name, int value) {
   if (!strcmp(name, "spp_naive")) { g_spp_naive = value; return 0; }
   if (!strcmp(name, "spp_bwd_form")) { g_spp_bwd_form = value; return 0; }
+  if (!strcmp(name, "pool_aap_wgs")) { if (value < 1) return MYOLO_EINVAL; g_aap_wgs = value; return 0; }
   return MYOLO_EINVAL;
 }
 #include <stdlib.h>
@@ -1026,17 +1028,27 @@ __global__ __launch_bounds__(256) void aap_fwd_multi_kernel(myolo_tensor x, AapF
         if (by != cby[p] || nby != cnby[p]) { flush(p); cby[p] = by; cnby[p] = nby; }
       }
     }
-    for (int xx = xa; xx < xb; ++xx) {
-      float f[SEG];
-      Vec<T>::unpack(ldg16(vptr<T>(x, n, y, xx) + cg * SEG), f);
+    // three pixels' loads in flight (clamped column; a pixel past the range matches no bin interval).  Round 5 measured this neutral -- while the
+    // per-row LDS atomics were the bound; with those gone the dependent loads are what is left (36.6 us per launch for a 33 MB read)
+    constexpr int U = 3;            // (four: 242 VGPRs and a spill)
+    for (int x0 = xa; x0 < xb; x0 += U) {
+      uint4 raw[U];
 #pragma unroll
-      for (int p = 0; p < AAP_MAXP; ++p)
+      for (int u = 0; u < U; ++u) raw[u] = ldg16(vptr<T>(x, n, y, x0 + u < xb ? x0 + u : xb - 1) + cg * SEG);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float m = (xx >= lo[p][j] && xx < hi[p][j]) ? 1.f : 0.f;
+      for (int u = 0; u < U; ++u) {
+        const int xx = x0 + u < xb ? x0 + u : 0x7ffffff0;
+        float f[SEG];
+        Vec<T>::unpack(raw[u], f);
 #pragma unroll
-          for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
-        }
+        for (int p = 0; p < AAP_MAXP; ++p)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const float m = (xx >= lo[p][j] && xx < hi[p][j]) ? 1.f : 0.f;
+#pragma unroll
+            for (int i = 0; i < SEG; ++i) acc[p][j][i] += m * f[i];
+          }
+      }
     }
   }
 #pragma unroll
@@ -1156,41 +1168,46 @@ __global__ __launch_bounds__(256) void aap_bwd_multi_kernel(AapMulti m, myolo_te
   GRID_STRIDE(v, total) {
     int n, y, xx, cg;
     dec(v, G, gx.w, gx.h, n, y, xx, cg);
-    // every load of a pixel is issued before the first use (round 6): a pixel lies in one or two bins per axis and pool -- always 2 x 2 candidate
-    // bins per pool, clamped indices, weight 0 for the absent ones -- instead of loops whose trip counts come out of the LDS tables (hipcc kept each
-    // load next to its wait: 63 us for a 67 MB read-modify-write)
-    uint4 raw[4][4];
-    float wgt[4][4];
+    // round 6: the loads every pixel needs -- its first bin of each pool and the old gradient -- are issued together before the first use; the
+    // second bin of an axis (only pixels on a fractional bin boundary have one) keeps the loop.  (All 2 x 2 candidates unconditionally with zero
+    // weights measured SLOWER, 81 against 63 us: sixteen 16-byte vectors to unpack and scale per pixel made the pass VALU-bound.)
     T* gp = vptr<T>(gx, n, y, xx) + cg * SEG;
     uint4 old = {0u, 0u, 0u, 0u};
     if (acc) old = ldg16(gp);
+    uint4 raw[4];
+    float w0[4];
+    int by0[4], nby[4], bx0[4], nbx[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const bool on = t < m.n;
-      const myolo_tensor& gout = m.g[on ? t : 0];
-      const int rv = rowt[(on ? t : 0) * gx.h + y], cv = colt[(on ? t : 0) * gx.w + xx];
-      const int by0 = rv & 15, nby = rv >> 4, bx0 = cv & 15, nbx = cv >> 4;
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int by = by0 + (j < nby ? j : 0), bx = bx0 + (i < nbx ? i : 0);
-          raw[t][j * 2 + i] = ldg16(vptr<T>(gout, n, by, bx) + cg * SEG);
-          wgt[t][j * 2 + i] = (on && j < nby && i < nbx) ? 1.f / (float)((int)exth[t * 8 + by] * (int)extw[t * 8 + bx]) : 0.f;
-        }
+      const int tt = on ? t : 0;
+      const int rv = rowt[tt * gx.h + y], cv = colt[tt * gx.w + xx];
+      by0[t] = rv & 15; nby[t] = on ? rv >> 4 : 0; bx0[t] = cv & 15; nbx[t] = on ? cv >> 4 : 0;
+      raw[t] = ldg16(vptr<T>(m.g[tt], n, by0[t], bx0[t]) + cg * SEG);
+      w0[t] = on ? 1.f / (float)((int)exth[tt * 8 + by0[t]] * (int)extw[tt * 8 + bx0[t]]) : 0.f;
     }
     float a[SEG];
 #pragma unroll
     for (int i = 0; i < SEG; ++i) a[i] = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < 4; ++t) {
+      float f[SEG];
+      Vec<T>::unpack(raw[t], f);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float f[SEG];
-        Vec<T>::unpack(raw[t][q], f);
+      for (int i = 0; i < SEG; ++i) a[i] += f[i] * w0[t];
+      if (nby[t] * nbx[t] > 1) {                                     // a boundary pixel: the other one to three bins
+        for (int j = 0; j < nby[t]; ++j)
+          for (int q = 0; q < nbx[t]; ++q) {
+            if (j == 0 && q == 0) continue;
+            const int by = by0[t] + j, bx = bx0[t] + q;
+            float f2[SEG];
+            Vec<T>::unpack(ldg16(vptr<T>(m.g[t], n, by, bx) + cg * SEG), f2);
+            const float inv = 1.f / (float)((int)exth[t * 8 + by] * (int)extw[t * 8 + bx]);
 #pragma unroll
-        for (int i = 0; i < SEG; ++i) a[i] += f[i] * wgt[t][q];
+            for (int i = 0; i < SEG; ++i) a[i] += f2[i] * inv;
+          }
       }
+    }
     if (acc) {
       float o[SEG];
       Vec<T>::unpack(old, o);
@@ -1511,7 +1528,7 @@ extern "C" int myolo_adaptive_avgpool_fwd_multi(const myolo_tensor* x, const myo
   // 64 / 128 / 256 / 512 workgroups 144 / 78 / 44.7 / 45.2 us for the training map (fewer workgroups: the per-row work serialises; more: the
   // zeroing and flushing of the bin tables, nbins * C words and as many atomics per workgroup, grows with the count); splitting the ROW over
   // workgroups as well 57.7 us at 1024, 98.6 at 2048; one bin table per wave 46.2 -> 48.0 us; four loads in flight per thread neutral
-  int rows = (int)(((int64_t)x->h * x->n + 255) / 256);
+  int rows = (int)(((int64_t)x->h * x->n + g_aap_wgs - 1) / g_aap_wgs);
   if (rows < 1) rows = 1;
   const int gx = (x->h + rows - 1) / rows;
   hipStream_t st = (hipStream_t)stream;
