@@ -242,6 +242,74 @@ __global__ __launch_bounds__(256) void spp_fwd_plane_kernel(myolo_tensor x, myol
   }
 }
 
+// Eval, fp16 (the detect.py frame: no index planes): the same separable pooling on the PACKED halves -- max is exact in fp16, so the 13 + 27
+// taps per output vector are 4 v_pk_max_f16 each instead of 8 unpacks + 8 compare / selects in fp32 (the plane kernel above was VALU-bound at
+// batch 1: 22 us on the frame's critical path for a 1 MB map).  NaN: a NaN input loses against any number (as `f > m` above).
+typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint4 pkmax8(uint4 a, uint4 b) {
+  uint4 r;
+  unsigned int* ra = reinterpret_cast<unsigned int*>(&a);
+  unsigned int* rb = reinterpret_cast<unsigned int*>(&b);
+  unsigned int* rr = reinterpret_cast<unsigned int*>(&r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    h2v_t x = *reinterpret_cast<h2v_t*>(&ra[i]), y = *reinterpret_cast<h2v_t*>(&rb[i]);
+    h2v_t m = __builtin_elementwise_max(x, y);
+    rr[i] = *reinterpret_cast<unsigned int*>(&m);
+  }
+  return r;
+}
+__global__ __launch_bounds__(256) void spp_fwd_plane_h_kernel(myolo_tensor x, myolo_tensor o5, myolo_tensor o9, myolo_tensor o13, int band_rows) {
+  constexpr int SEG = 8;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int W = x.w, H = x.h;
+  const int yb0 = blockIdx.y * band_rows, yb1 = yb0 + band_rows < H ? yb0 + band_rows : H;
+  const int ty0 = yb0 - 6 > 0 ? yb0 - 6 : 0, ty1 = yb1 + 6 < H ? yb1 + 6 : H;
+  const int HW = (ty1 - ty0) * W;
+  const int cap = (band_rows + 12) * W;
+  uint4* tile = reinterpret_cast<uint4*>(smem);                            // [cap]
+  uint4* rv = tile + cap;                                                  // [3][cap] row maxima
+  const int G = x.c / SEG;
+  const int n = blockIdx.x / G, cg = blockIdx.x - n * G;
+  const uint4 ninf = {0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u, 0xfc00fc00u};
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int y = ty0 + p / W, xx = p % W;
+    tile[p] = ldg16(vptr<half_t>(x, n, y, xx) + cg * SEG);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += blockDim.x) {
+    const int yl = p / W, xx = p - yl * W;
+    uint4 m5 = ninf, m9 = ninf, m13 = ninf;
+#pragma unroll
+    for (int dx = -6; dx <= 6; ++dx) {
+      const int ix = xx + dx;
+      if (ix < 0 || ix >= W) continue;
+      const uint4 v = tile[yl * W + ix];
+      m13 = pkmax8(m13, v);
+      if (dx >= -4 && dx <= 4) m9 = pkmax8(m9, v);
+      if (dx >= -2 && dx <= 2) m5 = pkmax8(m5, v);
+    }
+    rv[p] = m5; rv[cap + p] = m9; rv[2 * cap + p] = m13;
+  }
+  __syncthreads();
+  const int nout = (yb1 - yb0) * W;
+  for (int p = threadIdx.x; p < nout; p += blockDim.x) {
+    const int y = yb0 + p / W, xx = p % W;
+#pragma unroll
+    for (int w = 0; w < 3; ++w) {
+      const int r = 2 + 2 * w;
+      uint4 m = ninf;
+      for (int dy = -r; dy <= r; ++dy) {
+        const int iy = y + dy;
+        if (iy < 0 || iy >= H) continue;
+        m = pkmax8(m, rv[(size_t)w * cap + (iy - ty0) * W + xx]);
+      }
+      const myolo_tensor& o = w == 0 ? o5 : (w == 1 ? o9 : o13);
+      stg16(vptr<half_t>(o, n, y, xx) + cg * SEG, m);
+    }
+  }
+}
+
 // transpose of the above: every output pixel adds its three gradients to the recorded arg-max positions of the plane (LDS fp32
 // atomics), then the plane is written once.
 template <typename T>
@@ -1361,6 +1429,14 @@ extern "C" int myolo_spp_pool_fwd(const myolo_tensor* x, const myolo_tensor* o5,
   const size_t smem = need(band);
   if (smem <= 150 * 1024 && !g_spp_naive) {
     const dim3 grid(blocks, nb);
+    if (x->dtype == MYOLO_F16 && !idx && !(g_spp_bwd_form & 8)) {           // eval: packed-half maxima (option spp_bwd_form bit 3: the fp32 plane kernel)
+      const size_t smem_h = (size_t)(band + 12) * x->w * 16 * 4;
+      auto kern = spp_fwd_plane_h_kernel;
+      MYOLO_ENSURE_DYN_SMEM(kern, (int)smem_h);
+      hipLaunchKernelGGL(kern, grid, dim3(256), smem_h, st, *x, *o5, *o9, *o13, band);
+      MYOLO_CHECK_LAUNCH();
+      return 0;
+    }
     if (x->dtype == MYOLO_F16) {
       if (idx) { auto kern = spp_fwd_plane_kernel<half_t, true>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
       else { auto kern = spp_fwd_plane_kernel<half_t, false>; MYOLO_ENSURE_DYN_SMEM(kern, (int)smem); hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, *x, *o5, *o9, *o13, idx, band); }
